@@ -1,0 +1,983 @@
+/*
+ * pano_oracle.c - see pano_oracle.h.  TEST INFRASTRUCTURE, PARITY UNPINNED.
+ *
+ * Every function names the OpenCV-3.4 routine it restates and the reference
+ * call site (file:line under /root/reference) that reaches it.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC (see Makefile).
+ * -ffp-contract=off matters: OpenCV's x86 builds do not fuse a*b+c, and the f32
+ * expressions below are written in OpenCV's evaluation order.
+ */
+#define _GNU_SOURCE
+#include "pano_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PO_PI_F ((float)3.1415926535897932384626433832795)
+
+static int g_threads = 1;
+void po_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int po_get_threads(void) { return g_threads; }
+
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+/* cvRound(float): SSE cvtss2si / cvtps2dq - round-half-even; "integer indefinite"
+ * (INT_MIN) on overflow or NaN. */
+static inline int cv_round_f(float v) {
+    if (!(v >= -2147483648.f && v < 2147483648.f)) return INT_MIN;
+    return (int)lrintf(v);
+}
+static inline int cv_round_d(double v) {
+    if (!(v >= -2147483648.0 && v < 2147483648.0)) return INT_MIN;
+    return (int)lrint(v);
+}
+static inline int16_t sat16(int v) { return (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+static inline uint8_t sat8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+/* cv::borderInterpolate (core/src/copy.cpp) for REFLECT / REFLECT_101 / CONSTANT(-1) */
+static inline int border_interpolate(int p, int len, int border) {
+    if ((unsigned)p < (unsigned)len) return p;
+    if (border == PO_BORDER_CONSTANT) return -1;
+    {
+        int delta = border == PO_BORDER_REFLECT_101;
+        if (len == 1) return 0;
+        do {
+            if (p < 0) p = -p - 1 + delta;
+            else p = len - 1 - (p - len) - delta;
+        } while ((unsigned)p >= (unsigned)len);
+    }
+    return p;
+}
+
+/* ======================================================================== A1 */
+
+/* cv::invert, n==3, CV_32F (core/src/lapack.cpp): closed form in double, rounded to float */
+static void invert3x3_f(const float* S, float* D) {
+#define Sf(r, c) S[(r) * 3 + (c)]
+    double d = Sf(0, 0) * ((double)Sf(1, 1) * Sf(2, 2) - (double)Sf(1, 2) * Sf(2, 1)) -
+               Sf(0, 1) * ((double)Sf(1, 0) * Sf(2, 2) - (double)Sf(1, 2) * Sf(2, 0)) +
+               Sf(0, 2) * ((double)Sf(1, 0) * Sf(2, 1) - (double)Sf(1, 1) * Sf(2, 0));
+    if (d != 0.) {
+        double t[9];
+        d = 1. / d;
+        t[0] = (((double)Sf(1, 1) * Sf(2, 2) - (double)Sf(1, 2) * Sf(2, 1)) * d);
+        t[1] = (((double)Sf(0, 2) * Sf(2, 1) - (double)Sf(0, 1) * Sf(2, 2)) * d);
+        t[2] = (((double)Sf(0, 1) * Sf(1, 2) - (double)Sf(0, 2) * Sf(1, 1)) * d);
+        t[3] = (((double)Sf(1, 2) * Sf(2, 0) - (double)Sf(1, 0) * Sf(2, 2)) * d);
+        t[4] = (((double)Sf(0, 0) * Sf(2, 2) - (double)Sf(0, 2) * Sf(2, 0)) * d);
+        t[5] = (((double)Sf(0, 2) * Sf(1, 0) - (double)Sf(0, 0) * Sf(1, 2)) * d);
+        t[6] = (((double)Sf(1, 0) * Sf(2, 1) - (double)Sf(1, 1) * Sf(2, 0)) * d);
+        t[7] = (((double)Sf(0, 1) * Sf(2, 0) - (double)Sf(0, 0) * Sf(2, 1)) * d);
+        t[8] = (((double)Sf(0, 0) * Sf(1, 1) - (double)Sf(0, 1) * Sf(1, 0)) * d);
+        for (int i = 0; i < 9; i++) D[i] = (float)t[i];
+    } else {
+        for (int i = 0; i < 9; i++) D[i] = 0.f;
+    }
+#undef Sf
+}
+
+/* cv::gemm small-matrix path, 3x3 CV_32F (core/src/matmul.cpp): f32 products summed left to right */
+static void matmul3x3_f(const float* a, const float* b, float* d) {
+    for (int i = 0; i < 3; i++) {
+        float t0 = a[i * 3 + 0] * b[0] + a[i * 3 + 1] * b[3] + a[i * 3 + 2] * b[6];
+        float t1 = a[i * 3 + 0] * b[1] + a[i * 3 + 1] * b[4] + a[i * 3 + 2] * b[7];
+        float t2 = a[i * 3 + 0] * b[2] + a[i * 3 + 1] * b[5] + a[i * 3 + 2] * b[8];
+        d[i * 3 + 0] = t0;
+        d[i * 3 + 1] = t1;
+        d[i * 3 + 2] = t2;
+    }
+}
+
+/* ProjectorBase::setCameraParams (stitching/src/warpers.cpp); reached from
+ * RotationWarperBase::warp / warpRoi, reference ocvstitcher.hpp:1171, :1057 */
+void po_projector_set(po_projector* p, int kind, float scale, const float K[9], const float R[9]) {
+    float kinv[9];
+    p->kind = kind;
+    p->scale = scale;
+    for (int i = 0; i < 9; i++) p->k[i] = K[i];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) p->rinv[r * 3 + c] = R[c * 3 + r];
+    invert3x3_f(K, kinv);
+    matmul3x3_f(R, kinv, p->r_kinv);
+    matmul3x3_f(K, p->rinv, p->k_rinv);
+}
+
+/* SphericalProjector::mapForward / CylindricalProjector::mapForward (warpers_inl.hpp) */
+void po_map_forward(const po_projector* p, float x, float y, float* u, float* v) {
+    const float* m = p->r_kinv;
+    float x_ = m[0] * x + m[1] * y + m[2];
+    float y_ = m[3] * x + m[4] * y + m[5];
+    float z_ = m[6] * x + m[7] * y + m[8];
+    if (p->kind == PO_SPHERICAL) {
+        *u = p->scale * atan2f(x_, z_);
+        float w = y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_);
+        *v = p->scale * (PO_PI_F - acosf(w == w ? w : 0));
+    } else {
+        *u = p->scale * atan2f(x_, z_);
+        *v = p->scale * y_ / sqrtf(x_ * x_ + z_ * z_);
+    }
+}
+
+/* SphericalProjector::mapBackward / CylindricalProjector::mapBackward (warpers_inl.hpp) */
+void po_map_backward(const po_projector* p, float u, float v, float* x, float* y) {
+    const float* m = p->k_rinv;
+    float x_, y_, z_;
+    u /= p->scale;
+    v /= p->scale;
+    if (p->kind == PO_SPHERICAL) {
+        float sinv = sinf(PO_PI_F - v);
+        x_ = sinv * sinf(u);
+        y_ = cosf(PO_PI_F - v);
+        z_ = sinv * cosf(u);
+    } else {
+        x_ = sinf(u);
+        y_ = v;
+        z_ = cosf(u);
+    }
+    float z;
+    *x = m[0] * x_ + m[1] * y_ + m[2] * z_;
+    *y = m[3] * x_ + m[4] * y_ + m[5] * z_;
+    z = m[6] * x_ + m[7] * y_ + m[8] * z_;
+    if (z > 0) {
+        *x /= z;
+        *y /= z;
+    } else
+        *x = *y = -1;
+}
+
+/* ======================================================================== A2 */
+
+/* RotationWarperBase::detectResultRoiByBorder (warpers_inl.hpp) */
+static void roi_by_border(const po_projector* p, int w, int h, float* tl_u, float* tl_v, float* br_u, float* br_v) {
+    float tl_uf = 3.402823466e+38F, tl_vf = 3.402823466e+38F;
+    float br_uf = -3.402823466e+38F, br_vf = -3.402823466e+38F;
+    float u, v;
+    for (int x = 0; x < w; ++x) {
+        po_map_forward(p, (float)x, 0, &u, &v);
+        tl_uf = fminf(tl_uf, u); tl_vf = fminf(tl_vf, v);
+        br_uf = fmaxf(br_uf, u); br_vf = fmaxf(br_vf, v);
+        po_map_forward(p, (float)x, (float)(h - 1), &u, &v);
+        tl_uf = fminf(tl_uf, u); tl_vf = fminf(tl_vf, v);
+        br_uf = fmaxf(br_uf, u); br_vf = fmaxf(br_vf, v);
+    }
+    for (int y = 0; y < h; ++y) {
+        po_map_forward(p, 0, (float)y, &u, &v);
+        tl_uf = fminf(tl_uf, u); tl_vf = fminf(tl_vf, v);
+        br_uf = fmaxf(br_uf, u); br_vf = fmaxf(br_vf, v);
+        po_map_forward(p, (float)(w - 1), (float)y, &u, &v);
+        tl_uf = fminf(tl_uf, u); tl_vf = fminf(tl_vf, v);
+        br_uf = fmaxf(br_uf, u); br_vf = fmaxf(br_vf, v);
+    }
+    *tl_u = tl_uf; *tl_v = tl_vf; *br_u = br_uf; *br_v = br_vf;
+}
+
+/* SphericalWarper::detectResultRoi (stitching/src/warpers.cpp) = by-border + pole fix-up;
+ * CylindricalWarper::detectResultRoi = by-border only (stitching/detail/warpers.hpp) */
+void po_detect_result_roi(const po_projector* p, int w, int h, int tl[2], int br[2]) {
+    float tl_uf, tl_vf, br_uf, br_vf;
+    roi_by_border(p, w, h, &tl_uf, &tl_vf, &br_uf, &br_vf);
+    /* by-border truncates to int first, the spherical override then re-floats those ints */
+    int tlx = (int)tl_uf, tly = (int)tl_vf, brx = (int)br_uf, bry = (int)br_vf;
+    if (p->kind == PO_SPHERICAL) {
+        tl_uf = (float)tlx; tl_vf = (float)tly; br_uf = (float)brx; br_vf = (float)bry;
+        float x = p->rinv[1], y = p->rinv[4], z = p->rinv[7];
+        if (y > 0.f) {
+            float x_ = (p->k[0] * x + p->k[1] * y) / z + p->k[2];
+            float y_ = p->k[4] * y / z + p->k[5];
+            if (x_ > 0.f && x_ < w && y_ > 0.f && y_ < h) {
+                tl_uf = fminf(tl_uf, 0.f); tl_vf = fminf(tl_vf, (float)(3.1415926535897932384626433832795 * p->scale));
+                br_uf = fmaxf(br_uf, 0.f); br_vf = fmaxf(br_vf, (float)(3.1415926535897932384626433832795 * p->scale));
+            }
+        }
+        x = p->rinv[1]; y = -p->rinv[4]; z = p->rinv[7];
+        if (y > 0.f) {
+            float x_ = (p->k[0] * x + p->k[1] * y) / z + p->k[2];
+            float y_ = p->k[4] * y / z + p->k[5];
+            if (x_ > 0.f && x_ < w && y_ > 0.f && y_ < h) {
+                tl_uf = fminf(tl_uf, 0.f); tl_vf = fminf(tl_vf, 0.f);
+                br_uf = fmaxf(br_uf, 0.f); br_vf = fmaxf(br_vf, 0.f);
+            }
+        }
+        tlx = (int)tl_uf; tly = (int)tl_vf; brx = (int)br_uf; bry = (int)br_vf;
+    }
+    tl[0] = tlx; tl[1] = tly; br[0] = brx; br[1] = bry;
+}
+
+/* RotationWarperBase::warpRoi: Rect(tl, Point(br.x+1, br.y+1)); reference ocvstitcher.hpp:1057 */
+void po_warp_roi(const po_projector* p, int w, int h, int rect[4]) {
+    int tl[2], br[2];
+    po_detect_result_roi(p, w, h, tl, br);
+    rect[0] = tl[0]; rect[1] = tl[1];
+    rect[2] = br[0] + 1 - tl[0]; rect[3] = br[1] + 1 - tl[1];
+}
+
+/* cv::detail::resultRoi(corners, sizes) (stitching/src/util.cpp); reference ocvstitcher.hpp:1110 */
+void po_result_roi(int n, const int* corners, const int* sizes, int rect[4]) {
+    int tlx = INT_MAX, tly = INT_MAX, brx = INT_MIN, bry = INT_MIN;
+    for (int i = 0; i < n; i++) {
+        if (corners[2 * i] < tlx) tlx = corners[2 * i];
+        if (corners[2 * i + 1] < tly) tly = corners[2 * i + 1];
+        if (corners[2 * i] + sizes[2 * i] > brx) brx = corners[2 * i] + sizes[2 * i];
+        if (corners[2 * i + 1] + sizes[2 * i + 1] > bry) bry = corners[2 * i + 1] + sizes[2 * i + 1];
+    }
+    rect[0] = tlx; rect[1] = tly; rect[2] = brx - tlx; rect[3] = bry - tly;
+}
+
+/* ======================================================================== A3 */
+
+/* RotationWarperBase::buildMaps (warpers_inl.hpp): maps are (br-tl+1) sized, u,v integer grid */
+void po_build_maps(const po_projector* p, int sw, int sh, float* xmap, float* ymap) {
+    int tl[2], br[2];
+    po_detect_result_roi(p, sw, sh, tl, br);
+    int dw = br[0] - tl[0] + 1, dh = br[1] - tl[1] + 1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int v = 0; v < dh; ++v)
+        for (int u = 0; u < dw; ++u)
+            po_map_backward(p, (float)(u + tl[0]), (float)(v + tl[1]), &xmap[(size_t)v * dw + u], &ymap[(size_t)v * dw + u]);
+}
+
+/* cv::remap, CV_8U, map1/map2 CV_32FC1 (imgproc/src/imgwarp.cpp RemapInvoker + remapBilinear<FixedPtCast<int,uchar,15>>
+ * / remapNearest).  INTER_BITS=5, INTER_REMAP_COEF_BITS=15.  cval = 0. */
+void po_remap_8u(const uint8_t* src, int sw, int sh, size_t sstride, int cn, const float* xmap, const float* ymap,
+                 int dw, int dh, int interp, int border, uint8_t* dst, size_t dstride) {
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int dy = 0; dy < dh; ++dy) {
+        const float* sX = xmap + (size_t)dy * dw;
+        const float* sY = ymap + (size_t)dy * dw;
+        uint8_t* D = dst + (size_t)dy * dstride;
+        for (int dx = 0; dx < dw; ++dx) {
+            if (interp == PO_INTER_NEAREST) {
+                /* XY = saturate_cast<short>(float) = clamp(cvRound) */
+                int sx = sat16(cv_round_f(sX[dx])), sy = sat16(cv_round_f(sY[dx]));
+                if ((unsigned)sx < (unsigned)sw && (unsigned)sy < (unsigned)sh) {
+                    for (int c = 0; c < cn; c++) D[dx * cn + c] = src[(size_t)sy * sstride + sx * cn + c];
+                } else if (border == PO_BORDER_CONSTANT) {
+                    for (int c = 0; c < cn; c++) D[dx * cn + c] = 0;
+                } else {
+                    sx = border_interpolate(sx, sw, border);
+                    sy = border_interpolate(sy, sh, border);
+                    for (int c = 0; c < cn; c++) D[dx * cn + c] = src[(size_t)sy * sstride + sx * cn + c];
+                }
+                continue;
+            }
+            int isx = cv_round_f(sX[dx] * 32.f), isy = cv_round_f(sY[dx] * 32.f);
+            int a = isx & 31, b = isy & 31;
+            int sx = sat16(isx >> 5), sy = sat16(isy >> 5);
+            /* BilinearTab_i: exact for 1/32 fractions, sums to 32768 */
+            int w00 = (32 - a) * (32 - b) * 32, w01 = a * (32 - b) * 32, w10 = (32 - a) * b * 32, w11 = a * b * 32;
+            int x0, x1, y0, y1;
+            if (border == PO_BORDER_CONSTANT && (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0)) {
+                for (int c = 0; c < cn; c++) D[dx * cn + c] = 0;
+                continue;
+            }
+            x0 = border_interpolate(sx, sw, border);
+            x1 = border_interpolate(sx + 1, sw, border);
+            y0 = border_interpolate(sy, sh, border);
+            y1 = border_interpolate(sy + 1, sh, border);
+            for (int c = 0; c < cn; c++) {
+                int p00 = (x0 >= 0 && y0 >= 0) ? src[(size_t)y0 * sstride + x0 * cn + c] : 0;
+                int p01 = (x1 >= 0 && y0 >= 0) ? src[(size_t)y0 * sstride + x1 * cn + c] : 0;
+                int p10 = (x0 >= 0 && y1 >= 0) ? src[(size_t)y1 * sstride + x0 * cn + c] : 0;
+                int p11 = (x1 >= 0 && y1 >= 0) ? src[(size_t)y1 * sstride + x1 * cn + c] : 0;
+                D[dx * cn + c] = sat8((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15);
+            }
+        }
+    }
+}
+
+/* RotationWarperBase::warp (warpers_inl.hpp); reference ocvstitcher.hpp:1171 (LINEAR, REFLECT),
+ * :1085 (NEAREST, CONSTANT) */
+void po_warp_8u(const po_projector* p, const uint8_t* src, int sw, int sh, size_t sstride, int cn, int interp,
+                int border, uint8_t* dst, int corner[2]) {
+    int r[4];
+    po_warp_roi(p, sw, sh, r);
+    float* xmap = (float*)malloc(sizeof(float) * (size_t)r[2] * r[3]);
+    float* ymap = (float*)malloc(sizeof(float) * (size_t)r[2] * r[3]);
+    po_build_maps(p, sw, sh, xmap, ymap);
+    po_remap_8u(src, sw, sh, sstride, cn, xmap, ymap, r[2], r[3], interp, border, dst, (size_t)r[2] * cn);
+    free(xmap);
+    free(ymap);
+    corner[0] = r[0];
+    corner[1] = r[1];
+}
+
+/* ======================================================================== A4 */
+
+/* cv::pyrDown, CV_16S (pyramids.cpp pyrDown_<FixPtCast<short,8>>): 5x5 [1 4 6 4 1]^2, REFLECT_101,
+ * dst = ((w+1)/2, (h+1)/2), (v+128)>>8 */
+void po_pyr_down_16s(const int16_t* src, int w, int h, int cn, int16_t* dst) {
+    int dw = (w + 1) / 2, dh = (h + 1) / 2;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int y = 0; y < dh; y++) {
+        int* rows = (int*)malloc(sizeof(int) * 5 * (size_t)dw * cn);
+        for (int k = 0; k < 5; k++) {
+            int sy = border_interpolate(2 * y + k - 2, h, PO_BORDER_REFLECT_101);
+            const int16_t* s = src + (size_t)sy * w * cn;
+            int* row = rows + (size_t)k * dw * cn;
+            for (int x = 0; x < dw; x++) {
+                int x0 = border_interpolate(2 * x - 2, w, PO_BORDER_REFLECT_101) * cn;
+                int x1 = border_interpolate(2 * x - 1, w, PO_BORDER_REFLECT_101) * cn;
+                int x2 = 2 * x * cn;
+                int x3 = border_interpolate(2 * x + 1, w, PO_BORDER_REFLECT_101) * cn;
+                int x4 = border_interpolate(2 * x + 2, w, PO_BORDER_REFLECT_101) * cn;
+                for (int c = 0; c < cn; c++)
+                    row[x * cn + c] = s[x2 + c] * 6 + (s[x1 + c] + s[x3 + c]) * 4 + s[x0 + c] + s[x4 + c];
+            }
+        }
+        int16_t* d = dst + (size_t)y * dw * cn;
+        const int *r0 = rows, *r1 = rows + (size_t)dw * cn, *r2 = r1 + (size_t)dw * cn, *r3 = r2 + (size_t)dw * cn,
+                  *r4 = r3 + (size_t)dw * cn;
+        for (int x = 0; x < dw * cn; x++) d[x] = sat16((r2[x] * 6 + (r1[x] + r3[x]) * 4 + r0[x] + r4[x] + 128) >> 8);
+        free(rows);
+    }
+}
+
+/* cv::pyrDown, CV_32F (pyrDown_<FltCast<float,8>>), scalar (non-SIMD) evaluation order:
+ * row = s2*6 + (s1+s3)*4 + s0 + s4;  dst = (r2*6 + (r1+r3)*4 + r0 + r4) * (1/256).
+ * NOTE: OpenCV's SSE2/NEON vertical kernels associate the same sum differently
+ * ((r0+r4)+(r2+r2) + ((r1+r3)+r2)*4); the last ulp of f32 weights is therefore
+ * platform-defined in OpenCV itself.  We fix the scalar order. */
+void po_pyr_down_32f(const float* src, int w, int h, float* dst) {
+    int dw = (w + 1) / 2, dh = (h + 1) / 2;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int y = 0; y < dh; y++) {
+        float* rows = (float*)malloc(sizeof(float) * 5 * (size_t)dw);
+        for (int k = 0; k < 5; k++) {
+            int sy = border_interpolate(2 * y + k - 2, h, PO_BORDER_REFLECT_101);
+            const float* s = src + (size_t)sy * w;
+            float* row = rows + (size_t)k * dw;
+            for (int x = 0; x < dw; x++) {
+                int x0 = border_interpolate(2 * x - 2, w, PO_BORDER_REFLECT_101);
+                int x1 = border_interpolate(2 * x - 1, w, PO_BORDER_REFLECT_101);
+                int x3 = border_interpolate(2 * x + 1, w, PO_BORDER_REFLECT_101);
+                int x4 = border_interpolate(2 * x + 2, w, PO_BORDER_REFLECT_101);
+                row[x] = s[2 * x] * 6 + (s[x1] + s[x3]) * 4 + s[x0] + s[x4];
+            }
+        }
+        const float *r0 = rows, *r1 = rows + dw, *r2 = r1 + dw, *r3 = r2 + dw, *r4 = r3 + dw;
+        float* d = dst + (size_t)y * dw;
+        for (int x = 0; x < dw; x++) d[x] = (r2[x] * 6 + (r1[x] + r3[x]) * 4 + r0[x] + r4[x]) * (1.f / 256);
+        free(rows);
+    }
+}
+
+/* cv::pyrUp, CV_16S (pyrUp_<FixPtCast<short,6>>), dst exactly 2w x 2h (always true inside
+ * MultiBandBlender because every tile/canvas is a multiple of 2^bands).
+ * Horizontal: even 6s[x]+s[x-1]+s[x+1], odd 4(s[x]+s[x+1]); left edge reflect-101
+ * (6s0+2s1), right edge replicate (s[n-2]+7s[n-1], 8s[n-1]); rows likewise; (v+32)>>6. */
+void po_pyr_up_16s(const int16_t* src, int w, int h, int cn, int16_t* dst) {
+    int dw = 2 * w;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int y = 0; y < h; y++) {
+        int* rows = (int*)malloc(sizeof(int) * 3 * (size_t)dw * cn);
+        for (int k = 0; k < 3; k++) {
+            int sy = y + k - 1;
+            /* borderInterpolate(sy*2, h*2, REFLECT_101)/2 */
+            sy = border_interpolate(sy * 2, h * 2, PO_BORDER_REFLECT_101) / 2;
+            const int16_t* s = src + (size_t)sy * w * cn;
+            int* row = rows + (size_t)k * dw * cn;
+            for (int x = 0; x < w; x++) {
+                int xm = x > 0 ? x - 1 : (w > 1 ? 1 : 0);
+                int xp = x < w - 1 ? x + 1 : w - 1;
+                for (int c = 0; c < cn; c++) {
+                    row[(2 * x) * cn + c] = s[xm * cn + c] + s[x * cn + c] * 6 + s[xp * cn + c];
+                    row[(2 * x + 1) * cn + c] = (s[x * cn + c] + s[xp * cn + c]) * 4;
+                }
+            }
+        }
+        const int *r0 = rows, *r1 = rows + (size_t)dw * cn, *r2 = r1 + (size_t)dw * cn;
+        int16_t* d0 = dst + (size_t)(2 * y) * dw * cn;
+        int16_t* d1 = d0 + (size_t)dw * cn;
+        for (int x = 0; x < dw * cn; x++) {
+            d1[x] = sat16(((r1[x] + r2[x]) * 4 + 32) >> 6);
+            d0[x] = sat16((r0[x] + r1[x] * 6 + r2[x] + 32) >> 6);
+        }
+        free(rows);
+    }
+}
+
+/* ======================================================================== misc imgproc */
+
+/* cv::copyMakeBorder (core/src/copy.cpp) */
+void po_copy_make_border_16s(const int16_t* src, int w, int h, int cn, int top, int bottom, int left, int right,
+                             int border, int16_t* dst) {
+    int dw = w + left + right, dh = h + top + bottom;
+    for (int y = 0; y < dh; y++) {
+        int sy = border_interpolate(y - top, h, border);
+        for (int x = 0; x < dw; x++) {
+            int sx = border_interpolate(x - left, w, border);
+            for (int c = 0; c < cn; c++)
+                dst[((size_t)y * dw + x) * cn + c] = (sx < 0 || sy < 0) ? 0 : src[((size_t)sy * w + sx) * cn + c];
+        }
+    }
+}
+void po_copy_make_border_32f(const float* src, int w, int h, int top, int bottom, int left, int right, float* dst) {
+    int dw = w + left + right, dh = h + top + bottom;
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            int sx = x - left, sy = y - top;
+            dst[(size_t)y * dw + x] = (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.f : src[(size_t)sy * w + sx];
+        }
+}
+
+/* cv::dilate(src, dst, Mat()) : 3x3 rect, centre anchor, BORDER_CONSTANT with the
+ * morphology default border value (= ignored for max).  reference ocvstitcher.hpp:1097,1255 */
+void po_dilate3x3_8u(const uint8_t* src, int w, int h, uint8_t* dst) {
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int m = 0;
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    int yy = y + dy, xx = x + dx;
+                    if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                    if (src[(size_t)yy * w + xx] > m) m = src[(size_t)yy * w + xx];
+                }
+            dst[(size_t)y * w + x] = (uint8_t)m;
+        }
+}
+
+/* cv::resize(..., INTER_LINEAR_EXACT), CV_8U (imgproc/src/resize.cpp resize_bitExact<uchar, interpolationLinear>):
+ * ufixedpoint16 (8.8) coefficients from IEEE-double src = (dst+0.5)/inv_scale - 0.5, round-half-even;
+ * horizontal pass keeps 8.8, vertical pass 16.16, final (v + 32768) >> 16.
+ * reference ocvstitcher.hpp:1099,1256 (mask upscale), :988 (seam-size frames) */
+typedef struct { int ofs; int c0, c1; } lin_coef;
+static void linear_exact_coeffs(int ssize, int dsize, lin_coef* co, int* pmin, int* pmax) {
+    double inv_scale = (double)dsize / ssize;
+    double scale = 1.0 / inv_scale;
+    int minofst = 0, maxofst = dsize;
+    for (int val = 0; val < dsize; val++) {
+        double fval = scale * ((double)val + 0.5) - 0.5;
+        int ival = (int)floor(fval);
+        co[val].ofs = 0; co[val].c0 = 256; co[val].c1 = 0;
+        if (ival >= 0 && ssize > 1) {
+            if (ival < ssize - 1) {
+                co[val].ofs = ival;
+                co[val].c1 = (int)lrint((fval - (double)ival) * 256.0); /* cvRound(softdouble*256) */
+                co[val].c0 = 256 - co[val].c1;
+            } else {
+                co[val].ofs = ssize - 1;
+                if (val < maxofst) maxofst = val;
+            }
+        } else {
+            if (val + 1 > minofst) minofst = val + 1;
+        }
+    }
+    *pmin = minofst;
+    *pmax = maxofst;
+}
+void po_resize_linear_exact_8u(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh) {
+    lin_coef* cx = (lin_coef*)malloc(sizeof(lin_coef) * dw);
+    lin_coef* cy = (lin_coef*)malloc(sizeof(lin_coef) * dh);
+    int minx, maxx, miny, maxy;
+    linear_exact_coeffs(sw, dw, cx, &minx, &maxx);
+    linear_exact_coeffs(sh, dh, cy, &miny, &maxy);
+    if (maxx < minx) maxx = minx;
+    if (maxy < miny) maxy = miny;
+    /* horizontal pass of every source row into 8.8 */
+    uint16_t* hbuf = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)sh * dw * cn);
+    for (int y = 0; y < sh; y++) {
+        const uint8_t* s = src + (size_t)y * sw * cn;
+        uint16_t* d = hbuf + (size_t)y * dw * cn;
+        for (int x = 0; x < dw; x++)
+            for (int c = 0; c < cn; c++) {
+                unsigned v;
+                if (x < minx) v = (unsigned)s[c] << 8;
+                else if (x >= maxx) v = (unsigned)s[(sw - 1) * cn + c] << 8;
+                else {
+                    unsigned a = s[cx[x].ofs * cn + c] * (unsigned)cx[x].c0;
+                    unsigned b = s[(cx[x].ofs + 1) * cn + c] * (unsigned)cx[x].c1;
+                    v = a + b;
+                    if (v > 65535u) v = 65535u;
+                }
+                d[x * cn + c] = (uint16_t)v;
+            }
+    }
+    for (int y = 0; y < dh; y++) {
+        uint8_t* d = dst + (size_t)y * dw * cn;
+        if (y < miny || y >= maxy) {
+            const uint16_t* r = hbuf + (size_t)(y < miny ? 0 : sh - 1) * dw * cn;
+            for (int x = 0; x < dw * cn; x++) d[x] = sat8((r[x] + 128) >> 8);
+        } else {
+            const uint16_t* r0 = hbuf + (size_t)cy[y].ofs * dw * cn;
+            const uint16_t* r1 = r0 + (size_t)dw * cn;
+            for (int x = 0; x < dw * cn; x++) {
+                uint64_t v = (uint64_t)r0[x] * (unsigned)cy[y].c0 + (uint64_t)r1[x] * (unsigned)cy[y].c1;
+                if (v > 0xffffffffull) v = 0xffffffffull;
+                d[x] = sat8((int)((v + 32768) >> 16));
+            }
+        }
+    }
+    free(hbuf);
+    free(cx);
+    free(cy);
+}
+
+/* cv::distanceTransform(src, dst, DIST_L1, 3) (imgproc/src/distransform.cpp distanceTransform_3x3 with
+ * mask {1,2}): exact city-block distance to the nearest zero pixel; image border = infinitely far. */
+void po_distance_l1(const uint8_t* src, int w, int h, float* dst) {
+    const int BIG = INT_MAX >> 2 >> 16 << 0; /* DIST_MAX >> DIST_SHIFT magnitude (~8191) */
+    int* t = (int*)malloc(sizeof(int) * (size_t)w * h);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int v;
+            if (!src[(size_t)y * w + x]) v = 0;
+            else {
+                v = BIG * 4;
+                if (x > 0 && t[(size_t)y * w + x - 1] + 1 < v) v = t[(size_t)y * w + x - 1] + 1;
+                if (y > 0 && t[(size_t)(y - 1) * w + x] + 1 < v) v = t[(size_t)(y - 1) * w + x] + 1;
+            }
+            t[(size_t)y * w + x] = v;
+        }
+    for (int y = h - 1; y >= 0; y--)
+        for (int x = w - 1; x >= 0; x--) {
+            int v = t[(size_t)y * w + x];
+            if (x < w - 1 && t[(size_t)y * w + x + 1] + 1 < v) v = t[(size_t)y * w + x + 1] + 1;
+            if (y < h - 1 && t[(size_t)(y + 1) * w + x] + 1 < v) v = t[(size_t)(y + 1) * w + x] + 1;
+            t[(size_t)y * w + x] = v;
+            dst[(size_t)y * w + x] = (float)v;
+        }
+    free(t);
+}
+
+/* ======================================================================== A5 */
+
+/* ocvstitcher.hpp:1188-1195 / stitching_detailed.cpp:855-864 */
+int po_bands_from_strength(int dst_w, int dst_h, float strength) {
+    float blend_width = sqrtf((float)(dst_w * dst_h)) * strength / 100.f;
+    if (blend_width < 1.f) return -1;
+    return (int)(ceil((double)logf(blend_width) / log(2.)) - 1.);
+}
+
+#define PO_MAX_LEVELS 16
+struct po_blender {
+    int requested_bands; /* actual_num_bands_, or -1 for Blender::NO */
+    int num_bands;
+    int dst_roi[4], dst_roi_final[4];
+    int lw[PO_MAX_LEVELS], lh[PO_MAX_LEVELS];
+    int16_t* lap[PO_MAX_LEVELS];
+    float* wgt[PO_MAX_LEVELS];
+    uint8_t* dst_mask; /* Blender::NO */
+    int last_tile[4], last_tblr[4];
+};
+
+po_blender* po_blender_create(int num_bands) {
+    po_blender* b = (po_blender*)calloc(1, sizeof(po_blender));
+    b->requested_bands = num_bands;
+    return b;
+}
+static void blender_free_levels(po_blender* b) {
+    for (int i = 0; i < PO_MAX_LEVELS; i++) {
+        free(b->lap[i]); b->lap[i] = NULL;
+        free(b->wgt[i]); b->wgt[i] = NULL;
+    }
+    free(b->dst_mask); b->dst_mask = NULL;
+}
+void po_blender_destroy(po_blender* b) {
+    if (!b) return;
+    blender_free_levels(b);
+    free(b);
+}
+
+/* MultiBandBlender::prepare(Rect) / Blender::prepare (blenders.cpp); reference ocvstitcher.hpp:1198 */
+void po_blender_prepare(po_blender* b, int n, const int* corners, const int* sizes) {
+    int roi[4];
+    po_result_roi(n, corners, sizes, roi);
+    blender_free_levels(b);
+    memcpy(b->dst_roi_final, roi, sizeof(roi));
+    if (b->requested_bands < 0) { /* Blender::NO */
+        b->num_bands = 0;
+        memcpy(b->dst_roi, roi, sizeof(roi));
+        b->lw[0] = roi[2]; b->lh[0] = roi[3];
+        b->lap[0] = (int16_t*)calloc((size_t)roi[2] * roi[3] * 3, sizeof(int16_t));
+        b->dst_mask = (uint8_t*)calloc((size_t)roi[2] * roi[3], 1);
+        return;
+    }
+    double max_len = (double)(roi[2] > roi[3] ? roi[2] : roi[3]);
+    int crop = (int)ceil(log(max_len) / log(2.0));
+    b->num_bands = b->requested_bands < crop ? b->requested_bands : crop;
+    int m = 1 << b->num_bands;
+    roi[2] += (m - roi[2] % m) % m;
+    roi[3] += (m - roi[3] % m) % m;
+    memcpy(b->dst_roi, roi, sizeof(roi));
+    b->lw[0] = roi[2]; b->lh[0] = roi[3];
+    for (int i = 1; i <= b->num_bands; i++) {
+        b->lw[i] = (b->lw[i - 1] + 1) / 2;
+        b->lh[i] = (b->lh[i - 1] + 1) / 2;
+    }
+    for (int i = 0; i <= b->num_bands; i++) {
+        b->lap[i] = (int16_t*)calloc((size_t)b->lw[i] * b->lh[i] * 3, sizeof(int16_t));
+        b->wgt[i] = (float*)calloc((size_t)b->lw[i] * b->lh[i], sizeof(float));
+    }
+}
+
+/* MultiBandBlender::feed / Blender::feed (blenders.cpp); reference ocvstitcher.hpp:1202 */
+void po_blender_feed(po_blender* b, const int16_t* img, const uint8_t* mask, int w, int h, int tlx, int tly) {
+    if (b->requested_bands < 0) { /* Blender::feed: masked copy, mask OR */
+        int dx = tlx - b->dst_roi[0], dy = tly - b->dst_roi[1], W = b->dst_roi[2];
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                size_t d = (size_t)(dy + y) * W + dx + x;
+                if (mask[(size_t)y * w + x])
+                    for (int c = 0; c < 3; c++) b->lap[0][d * 3 + c] = img[((size_t)y * w + x) * 3 + c];
+                b->dst_mask[d] |= mask[(size_t)y * w + x];
+            }
+        return;
+    }
+    const int nb = b->num_bands;
+    const int* R = b->dst_roi;
+    int gap = 3 * (1 << nb);
+    int tl_new_x = R[0] > tlx - gap ? R[0] : tlx - gap;
+    int tl_new_y = R[1] > tly - gap ? R[1] : tly - gap;
+    int br_new_x = (R[0] + R[2]) < (tlx + w + gap) ? (R[0] + R[2]) : (tlx + w + gap);
+    int br_new_y = (R[1] + R[3]) < (tly + h + gap) ? (R[1] + R[3]) : (tly + h + gap);
+    tl_new_x = R[0] + (((tl_new_x - R[0]) >> nb) << nb);
+    tl_new_y = R[1] + (((tl_new_y - R[1]) >> nb) << nb);
+    int width = br_new_x - tl_new_x, height = br_new_y - tl_new_y;
+    width += ((1 << nb) - width % (1 << nb)) % (1 << nb);
+    height += ((1 << nb) - height % (1 << nb)) % (1 << nb);
+    br_new_x = tl_new_x + width;
+    br_new_y = tl_new_y + height;
+    int dy = br_new_y - (R[1] + R[3]); if (dy < 0) dy = 0;
+    int dx = br_new_x - (R[0] + R[2]); if (dx < 0) dx = 0;
+    tl_new_x -= dx; br_new_x -= dx;
+    tl_new_y -= dy; br_new_y -= dy;
+    int top = tly - tl_new_y, left = tlx - tl_new_x;
+    int bottom = br_new_y - tly - h, right = br_new_x - tlx - w;
+    b->last_tile[0] = tl_new_x - R[0]; b->last_tile[1] = tl_new_y - R[1];
+    b->last_tile[2] = width; b->last_tile[3] = height;
+    b->last_tblr[0] = top; b->last_tblr[1] = bottom; b->last_tblr[2] = left; b->last_tblr[3] = right;
+
+    /* source Laplacian pyramid (createLaplacePyr, 16S branch) */
+    int16_t* pyr[PO_MAX_LEVELS];
+    float* wp[PO_MAX_LEVELS];
+    int pw[PO_MAX_LEVELS], ph[PO_MAX_LEVELS];
+    pw[0] = width; ph[0] = height;
+    pyr[0] = (int16_t*)malloc(sizeof(int16_t) * (size_t)width * height * 3);
+    po_copy_make_border_16s(img, w, h, 3, top, bottom, left, right, PO_BORDER_REFLECT, pyr[0]);
+    for (int i = 0; i < nb; i++) {
+        pw[i + 1] = (pw[i] + 1) / 2; ph[i + 1] = (ph[i] + 1) / 2;
+        pyr[i + 1] = (int16_t*)malloc(sizeof(int16_t) * (size_t)pw[i + 1] * ph[i + 1] * 3);
+        po_pyr_down_16s(pyr[i], pw[i], ph[i], 3, pyr[i + 1]);
+    }
+    for (int i = 0; i < nb; i++) {
+        int16_t* tmp = (int16_t*)malloc(sizeof(int16_t) * (size_t)pw[i] * ph[i] * 3);
+        po_pyr_up_16s(pyr[i + 1], pw[i + 1], ph[i + 1], 3, tmp); /* sizes are exact doubles here */
+        size_t cnt = (size_t)pw[i] * ph[i] * 3;
+        for (size_t k = 0; k < cnt; k++) pyr[i][k] = sat16((int)pyr[i][k] - (int)tmp[k]);
+        free(tmp);
+    }
+    /* weight Gaussian pyramid: mask * (1/255.) as f32, CONSTANT border, pyrDown */
+    {
+        float* wm = (float*)malloc(sizeof(float) * (size_t)w * h);
+        const float s = (float)(1. / 255.);
+        for (size_t k = 0; k < (size_t)w * h; k++) wm[k] = (float)mask[k] * s;
+        wp[0] = (float*)malloc(sizeof(float) * (size_t)width * height);
+        po_copy_make_border_32f(wm, w, h, top, bottom, left, right, wp[0]);
+        free(wm);
+        for (int i = 0; i < nb; i++) {
+            wp[i + 1] = (float*)malloc(sizeof(float) * (size_t)pw[i + 1] * ph[i + 1]);
+            po_pyr_down_32f(wp[i], pw[i], ph[i], wp[i + 1]);
+        }
+    }
+    int y_tl = tl_new_y - R[1], y_br = br_new_y - R[1], x_tl = tl_new_x - R[0], x_br = br_new_x - R[0];
+    for (int i = 0; i <= nb; i++) {
+        int rw = x_br - x_tl, rh = y_br - y_tl;
+        for (int y = 0; y < rh; y++) {
+            const int16_t* srow = pyr[i] + (size_t)y * pw[i] * 3;
+            const float* wrow = wp[i] + (size_t)y * pw[i];
+            int16_t* drow = b->lap[i] + ((size_t)(y_tl + y) * b->lw[i] + x_tl) * 3;
+            float* dwrow = b->wgt[i] + (size_t)(y_tl + y) * b->lw[i] + x_tl;
+            for (int x = 0; x < rw; x++) {
+                float wv = wrow[x];
+                drow[x * 3 + 0] = (int16_t)(drow[x * 3 + 0] + (int16_t)(srow[x * 3 + 0] * wv));
+                drow[x * 3 + 1] = (int16_t)(drow[x * 3 + 1] + (int16_t)(srow[x * 3 + 1] * wv));
+                drow[x * 3 + 2] = (int16_t)(drow[x * 3 + 2] + (int16_t)(srow[x * 3 + 2] * wv));
+                dwrow[x] += wv;
+            }
+        }
+        x_tl /= 2; y_tl /= 2; x_br /= 2; y_br /= 2;
+    }
+    for (int i = 0; i <= nb; i++) { free(pyr[i]); free(wp[i]); }
+}
+
+/* MultiBandBlender::blend + normalizeUsingWeightMap + restoreImageFromLaplacePyr + Blender::blend
+ * (blenders.cpp); reference ocvstitcher.hpp:1207 */
+void po_blender_blend(po_blender* b, int16_t* dst, uint8_t* dst_mask) {
+    const float WEIGHT_EPS = 1e-5f;
+    int fw = b->dst_roi_final[2], fh = b->dst_roi_final[3];
+    if (b->requested_bands < 0) {
+        for (int y = 0; y < fh; y++)
+            for (int x = 0; x < fw; x++) {
+                size_t k = (size_t)y * fw + x;
+                uint8_t m = b->dst_mask[k];
+                for (int c = 0; c < 3; c++) dst[k * 3 + c] = m ? b->lap[0][k * 3 + c] : 0;
+                dst_mask[k] = m;
+            }
+        return;
+    }
+    int nb = b->num_bands;
+    for (int i = 0; i <= nb; i++) {
+        size_t cnt = (size_t)b->lw[i] * b->lh[i];
+        for (size_t k = 0; k < cnt; k++) {
+            float wv = b->wgt[i][k] + WEIGHT_EPS;
+            b->lap[i][k * 3 + 0] = (int16_t)(b->lap[i][k * 3 + 0] / wv);
+            b->lap[i][k * 3 + 1] = (int16_t)(b->lap[i][k * 3 + 1] / wv);
+            b->lap[i][k * 3 + 2] = (int16_t)(b->lap[i][k * 3 + 2] / wv);
+        }
+    }
+    for (int i = nb; i > 0; --i) {
+        size_t cnt = (size_t)b->lw[i - 1] * b->lh[i - 1] * 3;
+        int16_t* tmp = (int16_t*)malloc(sizeof(int16_t) * cnt);
+        po_pyr_up_16s(b->lap[i], b->lw[i], b->lh[i], 3, tmp);
+        for (size_t k = 0; k < cnt; k++) b->lap[i - 1][k] = sat16((int)tmp[k] + (int)b->lap[i - 1][k]);
+        free(tmp);
+    }
+    int W = b->lw[0];
+    for (int y = 0; y < fh; y++)
+        for (int x = 0; x < fw; x++) {
+            size_t s = (size_t)y * W + x, d = (size_t)y * fw + x;
+            uint8_t m = b->wgt[0][s] > WEIGHT_EPS ? 255 : 0;
+            dst_mask[d] = m;
+            for (int c = 0; c < 3; c++) dst[d * 3 + c] = m ? b->lap[0][s * 3 + c] : 0;
+        }
+}
+
+int po_blender_num_bands(const po_blender* b) { return b->num_bands; }
+void po_blender_dst_roi(const po_blender* b, int r[4]) { memcpy(r, b->dst_roi, 4 * sizeof(int)); }
+void po_blender_dst_roi_final(const po_blender* b, int r[4]) { memcpy(r, b->dst_roi_final, 4 * sizeof(int)); }
+void po_blender_level_size(const po_blender* b, int level, int wh[2]) { wh[0] = b->lw[level]; wh[1] = b->lh[level]; }
+const int16_t* po_blender_level_laplace(const po_blender* b, int level) { return b->lap[level]; }
+const float* po_blender_level_weights(const po_blender* b, int level) { return b->wgt[level]; }
+void po_blender_last_tile(const po_blender* b, int rect[4], int tblr[4]) {
+    memcpy(rect, b->last_tile, 4 * sizeof(int));
+    memcpy(tblr, b->last_tblr, 4 * sizeof(int));
+}
+
+/* ======================================================================== A7 */
+
+/* overlapRoi (stitching/src/util.cpp) */
+static int overlap_roi(const int* tl1, const int* tl2, const int* sz1, const int* sz2, int roi[4]) {
+    int x_tl = tl1[0] > tl2[0] ? tl1[0] : tl2[0];
+    int y_tl = tl1[1] > tl2[1] ? tl1[1] : tl2[1];
+    int x_br = (tl1[0] + sz1[0]) < (tl2[0] + sz2[0]) ? (tl1[0] + sz1[0]) : (tl2[0] + sz2[0]);
+    int y_br = (tl1[1] + sz1[1]) < (tl2[1] + sz2[1]) ? (tl1[1] + sz1[1]) : (tl2[1] + sz2[1]);
+    if (x_tl < x_br && y_tl < y_br) {
+        roi[0] = x_tl; roi[1] = y_tl; roi[2] = x_br - x_tl; roi[3] = y_br - y_tl;
+        return 1;
+    }
+    return 0;
+}
+
+/* VoronoiSeamFinder::findInPair (stitching/src/seam_finders.cpp) */
+static void voronoi_in_pair(const int* tl1, const int* tl2, const int* sz1, const int* sz2, uint8_t* mask1,
+                            uint8_t* mask2, const int roi[4]) {
+    const int gap = 10;
+    int W = roi[2] + 2 * gap, H = roi[3] + 2 * gap;
+    uint8_t* sub1 = (uint8_t*)malloc((size_t)W * H);
+    uint8_t* sub2 = (uint8_t*)malloc((size_t)W * H);
+    for (int y = -gap; y < roi[3] + gap; ++y)
+        for (int x = -gap; x < roi[2] + gap; ++x) {
+            int y1 = roi[1] - tl1[1] + y, x1 = roi[0] - tl1[0] + x;
+            sub1[(size_t)(y + gap) * W + x + gap] =
+                (y1 >= 0 && x1 >= 0 && y1 < sz1[1] && x1 < sz1[0]) ? mask1[(size_t)y1 * sz1[0] + x1] : 0;
+            int y2 = roi[1] - tl2[1] + y, x2 = roi[0] - tl2[0] + x;
+            sub2[(size_t)(y + gap) * W + x + gap] =
+                (y2 >= 0 && x2 >= 0 && y2 < sz2[1] && x2 < sz2[0]) ? mask2[(size_t)y2 * sz2[0] + x2] : 0;
+        }
+    /* unique = submask with collisions zeroed; distanceTransform(unique == 0) */
+    uint8_t* in1 = (uint8_t*)malloc((size_t)W * H);
+    uint8_t* in2 = (uint8_t*)malloc((size_t)W * H);
+    for (size_t k = 0; k < (size_t)W * H; k++) {
+        int coll = sub1[k] != 0 && sub2[k] != 0;
+        uint8_t u1 = coll ? 0 : sub1[k], u2 = coll ? 0 : sub2[k];
+        in1[k] = u1 == 0 ? 255 : 0;
+        in2[k] = u2 == 0 ? 255 : 0;
+    }
+    float* d1 = (float*)malloc(sizeof(float) * (size_t)W * H);
+    float* d2 = (float*)malloc(sizeof(float) * (size_t)W * H);
+    po_distance_l1(in1, W, H, d1);
+    po_distance_l1(in2, W, H, d2);
+    for (int y = 0; y < roi[3]; ++y)
+        for (int x = 0; x < roi[2]; ++x) {
+            size_t k = (size_t)(y + gap) * W + x + gap;
+            if (d1[k] < d2[k])
+                mask2[(size_t)(roi[1] - tl2[1] + y) * sz2[0] + (roi[0] - tl2[0] + x)] = 0;
+            else
+                mask1[(size_t)(roi[1] - tl1[1] + y) * sz1[0] + (roi[0] - tl1[0] + x)] = 0;
+        }
+    free(sub1); free(sub2); free(in1); free(in2); free(d1); free(d2);
+}
+
+/* PairwiseSeamFinder::run + VoronoiSeamFinder::find; reference stitching_detailed.cpp:728-729,758 */
+void po_voronoi_find(int n, const int* corners, const int* sizes, uint8_t** masks) {
+    for (int i = 0; i < n - 1; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            int roi[4];
+            if (overlap_roi(corners + 2 * i, corners + 2 * j, sizes + 2 * i, sizes + 2 * j, roi))
+                voronoi_in_pair(corners + 2 * i, corners + 2 * j, sizes + 2 * i, sizes + 2 * j, masks[i], masks[j], roi);
+        }
+}
+
+/* ======================================================================== A8 */
+
+/* cv::resize CV_32FC1 INTER_LINEAR (resize.cpp resizeGeneric_ with HResizeLinear<float,float,float,1> and
+ * VResizeLinear<float,float,float,Cast>) */
+void po_resize_linear_32f(const float* src, int sw, int sh, float* dst, int dw, int dh) {
+    double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    int* xo = (int*)malloc(sizeof(int) * dw);
+    float* xa = (float*)malloc(sizeof(float) * 2 * dw);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xo[dx] = sx;
+        xa[2 * dx] = 1.f - fx;
+        xa[2 * dx + 1] = fx;
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        int sy0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+        int sy1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
+        float b0 = 1.f - fy, b1 = fy;
+        const float* S0 = src + (size_t)sy0 * sw;
+        const float* S1 = src + (size_t)sy1 * sw;
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = xo[dx];
+            int sx1 = sx + 1 < sw ? sx + 1 : sx;
+            float h0 = S0[sx] * xa[2 * dx] + S0[sx1] * xa[2 * dx + 1];
+            float h1 = S1[sx] * xa[2 * dx] + S1[sx1] * xa[2 * dx + 1];
+            dst[(size_t)dy * dw + dx] = h0 * b0 + h1 * b1;
+        }
+    }
+    free(xo);
+    free(xa);
+}
+
+/* BlocksGainCompensator::apply inner loop (exposure_compensate.cpp): saturate_cast<uchar>(px * gain);
+ * reference stitching_detailed.cpp:841 */
+void po_gain_apply_8uc3(uint8_t* img, int w, int h, const float* g) {
+    for (size_t k = 0; k < (size_t)w * h; k++)
+        for (int c = 0; c < 3; c++) img[k * 3 + c] = sat8(cv_round_f(img[k * 3 + c] * g[k]));
+}
+
+/* ======================================================================== mask preparation */
+
+/* ocvStitcher::initSeam (ocvstitcher.hpp:975-1101) with VoronoiSeamFinder in place of GraphCut
+ * (stitching_detailed.cpp:728-729 is the reference's own Voronoi option) */
+void po_prepare_masks_voronoi(int n, int kind, int sw, int sh, const float* Ks, const float* Rs, float wscale,
+                              uint8_t** masks_out) {
+    double swa = sqrt(1e5 / ((double)sh * sw));
+    if (swa > 1.0) swa = 1.0;
+    int ssw = cv_round_d(sw * swa), ssh = cv_round_d(sh * swa);
+    float seam_scale = (float)(wscale * swa);
+    float swa_f = (float)swa;
+    int* corners = (int*)malloc(sizeof(int) * 2 * n);
+    int* sizes = (int*)malloc(sizeof(int) * 2 * n);
+    uint8_t** mw = (uint8_t**)malloc(sizeof(uint8_t*) * n);
+    uint8_t* ones = (uint8_t*)malloc((size_t)(ssw > sw ? ssw : sw) * (ssh > sh ? ssh : sh));
+    memset(ones, 255, (size_t)(ssw > sw ? ssw : sw) * (ssh > sh ? ssh : sh));
+    for (int i = 0; i < n; i++) {
+        float K[9];
+        memcpy(K, Ks + 9 * i, sizeof(K));
+        K[0] *= swa_f; K[2] *= swa_f; K[4] *= swa_f; K[5] *= swa_f;
+        po_projector p;
+        po_projector_set(&p, kind, seam_scale, K, Rs + 9 * i);
+        int r[4];
+        po_warp_roi(&p, ssw, ssh, r);
+        corners[2 * i] = r[0]; corners[2 * i + 1] = r[1];
+        sizes[2 * i] = r[2]; sizes[2 * i + 1] = r[3];
+        mw[i] = (uint8_t*)malloc((size_t)r[2] * r[3]);
+        int c[2];
+        po_warp_8u(&p, ones, ssw, ssh, (size_t)ssw, 1, PO_INTER_NEAREST, PO_BORDER_CONSTANT, mw[i], c);
+    }
+    po_voronoi_find(n, corners, sizes, mw);
+    for (int i = 0; i < n; i++) {
+        po_projector p;
+        po_projector_set(&p, kind, wscale, Ks + 9 * i, Rs + 9 * i);
+        int r[4], c[2];
+        po_warp_roi(&p, sw, sh, r);
+        uint8_t* full = (uint8_t*)malloc((size_t)r[2] * r[3]);
+        po_warp_8u(&p, ones, sw, sh, (size_t)sw, 1, PO_INTER_NEAREST, PO_BORDER_CONSTANT, full, c);
+        uint8_t* dil = (uint8_t*)malloc((size_t)sizes[2 * i] * sizes[2 * i + 1]);
+        po_dilate3x3_8u(mw[i], sizes[2 * i], sizes[2 * i + 1], dil);
+        uint8_t* seam = (uint8_t*)malloc((size_t)r[2] * r[3]);
+        po_resize_linear_exact_8u(dil, sizes[2 * i], sizes[2 * i + 1], 1, seam, r[2], r[3]);
+        for (size_t k = 0; k < (size_t)r[2] * r[3]; k++) masks_out[i][k] = seam[k] & full[k];
+        free(full); free(dil); free(seam); free(mw[i]);
+    }
+    free(ones); free(mw); free(corners); free(sizes);
+}
+
+/* ======================================================================== whole frame */
+
+static __thread double g_ms[3];
+void po_last_timings(double ms[3]) { ms[0] = g_ms[0]; ms[1] = g_ms[1]; ms[2] = g_ms[2]; }
+
+/* ocvStitcher::process (ocvstitcher.hpp:1141-1216); with gain_maps != NULL the exposure apply of
+ * stitching_detailed.cpp:841 sits between warp and the 16S conversion */
+int po_compose(const po_compose_args* a, uint8_t* out, int out_wh[2]) {
+    int n = a->n;
+    int* corners = (int*)malloc(sizeof(int) * 2 * n);
+    int* sizes = (int*)malloc(sizeof(int) * 2 * n);
+    po_projector* P = (po_projector*)malloc(sizeof(po_projector) * n);
+    g_ms[0] = g_ms[1] = g_ms[2] = 0;
+    for (int i = 0; i < n; i++) {
+        int r[4];
+        po_projector_set(&P[i], a->kind, a->scale, a->K9s + 9 * i, a->R9s + 9 * i);
+        po_warp_roi(&P[i], a->src_w, a->src_h, r);
+        corners[2 * i] = r[0]; corners[2 * i + 1] = r[1];
+        sizes[2 * i] = r[2]; sizes[2 * i + 1] = r[3];
+    }
+    po_blender* bl = po_blender_create(a->num_bands);
+    po_blender_prepare(bl, n, corners, sizes);
+    for (int i = 0; i < n; i++) {
+        int w = sizes[2 * i], h = sizes[2 * i + 1], c[2];
+        double t0 = now_ms();
+        uint8_t* warped = (uint8_t*)malloc((size_t)w * h * 3);
+        po_warp_8u(&P[i], a->frames[i], a->src_w, a->src_h, (size_t)a->src_w * 3, 3, PO_INTER_LINEAR, PO_BORDER_REFLECT,
+                   warped, c);
+        if (a->gain_maps && a->gain_maps[i]) po_gain_apply_8uc3(warped, w, h, a->gain_maps[i]);
+        int16_t* ws = (int16_t*)malloc(sizeof(int16_t) * (size_t)w * h * 3);
+        for (size_t k = 0; k < (size_t)w * h * 3; k++) ws[k] = warped[k];
+        double t1 = now_ms();
+        po_blender_feed(bl, ws, a->masks[i], w, h, corners[2 * i], corners[2 * i + 1]);
+        double t2 = now_ms();
+        g_ms[0] += t1 - t0;
+        g_ms[1] += t2 - t1;
+        free(warped);
+        free(ws);
+    }
+    double t0 = now_ms();
+    int fr[4];
+    po_blender_dst_roi_final(bl, fr);
+    int16_t* res = (int16_t*)malloc(sizeof(int16_t) * (size_t)fr[2] * fr[3] * 3);
+    uint8_t* rmask = (uint8_t*)malloc((size_t)fr[2] * fr[3]);
+    po_blender_blend(bl, res, rmask);
+    int cx = a->cut[0], cy = a->cut[1], cw = a->cut[2], ch = a->cut[3];
+    if (cw == 0 || ch == 0) { cx = cy = 0; cw = fr[2]; ch = fr[3]; }
+    int rc = 0;
+    if (cx < 0 || cy < 0 || cx + cw > fr[2] || cy + ch > fr[3]) rc = -1;
+    else
+        for (int y = 0; y < ch; y++)
+            for (int x = 0; x < cw * 3; x++) out[(size_t)y * cw * 3 + x] = sat8(res[((size_t)(y + cy) * fr[2] + cx) * 3 + x]);
+    out_wh[0] = cw; out_wh[1] = ch;
+    g_ms[2] = now_ms() - t0;
+    free(res); free(rmask); free(corners); free(sizes); free(P);
+    po_blender_destroy(bl);
+    return rc;
+}

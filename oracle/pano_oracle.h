@@ -1,0 +1,134 @@
+/*
+ * pano_oracle.h - CPU restatement of the OpenCV-3.4 CPU semantics that
+ * LeRoii/Img-Stitching's per-frame compose path (include/ocvstitcher.hpp:1141-1216,
+ * src/stitching_detailed.cpp:778-904) executes through cv::detail::
+ * {SphericalWarper, CylindricalWarper, MultiBandBlender, VoronoiSeamFinder,
+ * BlocksGainCompensator}.
+ *
+ * THIS IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product (img-stitching_amd/, include/pano.h)
+ * never links, imports or calls anything in this directory.
+ *
+ * PARITY UNPINNED: the reference ships no expected outputs and OpenCV (the
+ * un-vendored dependency that carries the arithmetic, "opencv >= 3.4.0",
+ * reference CMakeLists.txt:57-58, README.md:4-5) is not available in the build
+ * container, so this restatement follows OpenCV 3.4's published algorithms
+ * (modules/stitching/include/opencv2/stitching/detail/warpers_inl.hpp,
+ * modules/stitching/src/{warpers,blenders,seam_finders,exposure_compensate}.cpp,
+ * modules/imgproc/src/{imgwarp,pyramids,resize,morph,distransform}.cpp) and is
+ * cross-checked only against an independent NumPy restatement (oracle/np_oracle.py)
+ * and the ROI integers in SURVEY.md Appendix C.
+ */
+#ifndef PANO_ORACLE_H
+#define PANO_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PO_SPHERICAL = 0, PO_CYLINDRICAL = 1 };
+enum { PO_INTER_NEAREST = 0, PO_INTER_LINEAR = 1 };
+enum { PO_BORDER_CONSTANT = 0, PO_BORDER_REFLECT = 2, PO_BORDER_REFLECT_101 = 4 };
+
+/* ---- A1: projectors (warpers_inl.hpp: ProjectorBase::setCameraParams,
+ *          SphericalProjector / CylindricalProjector mapForward/mapBackward) */
+typedef struct po_projector {
+    int kind;
+    float scale;
+    float k[9], rinv[9], r_kinv[9], k_rinv[9];
+} po_projector;
+
+void po_projector_set(po_projector* p, int kind, float scale, const float K[9], const float R[9]);
+void po_map_forward(const po_projector* p, float x, float y, float* u, float* v);
+void po_map_backward(const po_projector* p, float u, float v, float* x, float* y);
+
+/* ---- A2: ROI (warpers.cpp detectResultRoi / detectResultRoiByBorder, warpRoi; util.cpp resultRoi) */
+void po_detect_result_roi(const po_projector* p, int src_w, int src_h, int tl[2], int br[2]);
+void po_warp_roi(const po_projector* p, int src_w, int src_h, int rect_xywh[4]);
+void po_result_roi(int n, const int* corners_xy, const int* sizes_wh, int rect_xywh[4]);
+
+/* ---- A3: buildMaps + remap (imgwarp.cpp, 8U, INTER_LINEAR fixed point / INTER_NEAREST) */
+void po_build_maps(const po_projector* p, int src_w, int src_h, float* xmap, float* ymap);
+void po_remap_8u(const uint8_t* src, int sw, int sh, size_t sstride, int cn,
+                 const float* xmap, const float* ymap, int dw, int dh,
+                 int interp, int border, uint8_t* dst, size_t dstride);
+/* RotationWarper::warp: dst must hold warp_roi.w * warp_roi.h * cn bytes; returns tl in corner[2] */
+void po_warp_8u(const po_projector* p, const uint8_t* src, int sw, int sh, size_t sstride, int cn,
+                int interp, int border, uint8_t* dst, int corner[2]);
+
+/* ---- A4: pyramids (pyramids.cpp pyrDown_/pyrUp_, BORDER_REFLECT_101 / default) */
+void po_pyr_down_16s(const int16_t* src, int w, int h, int cn, int16_t* dst);
+void po_pyr_down_32f(const float* src, int w, int h, float* dst);
+void po_pyr_up_16s(const int16_t* src, int w, int h, int cn, int16_t* dst); /* dst is exactly 2w x 2h */
+
+/* ---- misc imgproc used on the path */
+void po_copy_make_border_16s(const int16_t* src, int w, int h, int cn, int top, int bottom, int left, int right,
+                             int border, int16_t* dst);
+void po_copy_make_border_32f(const float* src, int w, int h, int top, int bottom, int left, int right, float* dst);
+void po_dilate3x3_8u(const uint8_t* src, int w, int h, uint8_t* dst);
+void po_resize_linear_exact_8u(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh);
+void po_distance_l1(const uint8_t* src, int w, int h, float* dst);
+
+/* ---- A5: band rule of the callers (ocvstitcher.hpp:1188-1195).  Returns -1 for Blender::NO */
+int po_bands_from_strength(int dst_w, int dst_h, float strength);
+
+/* ---- A5: MultiBandBlender (blenders.cpp) */
+typedef struct po_blender po_blender;
+po_blender* po_blender_create(int num_bands /* >=0: MultiBand; -1: Blender::NO */);
+void po_blender_destroy(po_blender* b);
+void po_blender_prepare(po_blender* b, int n, const int* corners_xy, const int* sizes_wh);
+void po_blender_feed(po_blender* b, const int16_t* img16sc3, const uint8_t* mask, int w, int h, int tl_x, int tl_y);
+/* result is dst_roi_final sized (w*h*3 int16 + w*h uint8) */
+void po_blender_blend(po_blender* b, int16_t* dst16sc3, uint8_t* dst_mask);
+/* introspection for stage-level parity tests */
+int po_blender_num_bands(const po_blender* b);
+void po_blender_dst_roi(const po_blender* b, int rect_xywh[4]);        /* padded */
+void po_blender_dst_roi_final(const po_blender* b, int rect_xywh[4]);
+void po_blender_level_size(const po_blender* b, int level, int wh[2]);
+const int16_t* po_blender_level_laplace(const po_blender* b, int level);
+const float* po_blender_level_weights(const po_blender* b, int level);
+/* geometry of the last feed(): bordered tile rect in canvas coords + border widths */
+void po_blender_last_tile(const po_blender* b, int rect_xywh[4], int tblr[4]);
+
+/* ---- A7: VoronoiSeamFinder::find (seam_finders.cpp) on u8 masks, in place */
+void po_voronoi_find(int n, const int* corners_xy, const int* sizes_wh, uint8_t** masks);
+
+/* ---- A8: BlocksGainCompensator::apply (exposure_compensate.cpp, 3.4) */
+void po_resize_linear_32f(const float* src, int sw, int sh, float* dst, int dw, int dh);
+void po_gain_apply_8uc3(uint8_t* img, int w, int h, const float* gain_map /* w*h */);
+
+/* ---- mask preparation of ocvStitcher::initSeam / updateMask with a Voronoi seam finder
+ *      (ocvstitcher.hpp:975-1101, 1218-1261; stitching_detailed.cpp:726-756, 838-850).
+ * masks_out[i] must hold warp_roi(i).w * warp_roi(i).h bytes. */
+void po_prepare_masks_voronoi(int n, int kind, int src_w, int src_h, const float* K9s, const float* R9s,
+                              float warped_image_scale, uint8_t** masks_out);
+
+/* ---- whole per-frame path, ocvStitcher::process (ocvstitcher.hpp:1141-1216) */
+typedef struct po_compose_args {
+    int n;              /* num_images */
+    int kind;           /* projector */
+    int src_w, src_h;
+    const uint8_t* const* frames;   /* n BGR8 interleaved, stride = src_w*3 */
+    const float* K9s;   /* n*9 */
+    const float* R9s;   /* n*9 */
+    float scale;        /* warped_image_scale */
+    const uint8_t* const* masks;    /* n, each warp_roi(i) sized (m_blenderMask) */
+    int num_bands;      /* -1: Blender::NO */
+    const float* const* gain_maps;  /* NULL, or n maps each warp_roi(i) sized (exposure apply) */
+    int cut[4];         /* x,y,w,h inside dst_roi_final; w==0 -> full */
+} po_compose_args;
+/* out must hold cut.w*cut.h*3 bytes (or the full pano).  Returns 0 on success. */
+int po_compose(const po_compose_args* a, uint8_t* out, int out_wh[2]);
+/* stage timings of the last po_compose on this thread, ms: warp, feed(pyramids+accumulate), blend */
+void po_last_timings(double ms[3]);
+
+void po_set_threads(int n);
+int po_get_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

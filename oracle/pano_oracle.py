@@ -1,0 +1,299 @@
+"""ctypes binding of oracle/libpano_oracle.so (CPU restatement, TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  PARITY UNPINNED - see pano_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpano_oracle.so")
+
+SPHERICAL, CYLINDRICAL = 0, 1
+INTER_NEAREST, INTER_LINEAR = 0, 1
+BORDER_CONSTANT, BORDER_REFLECT, BORDER_REFLECT_101 = 0, 2, 4
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "pano_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libpano_oracle.so"])
+    return _SO
+
+
+class Projector(C.Structure):
+    _fields_ = [("kind", C.c_int), ("scale", C.c_float), ("k", C.c_float * 9), ("rinv", C.c_float * 9),
+                ("r_kinv", C.c_float * 9), ("k_rinv", C.c_float * 9)]
+
+
+class ComposeArgs(C.Structure):
+    _fields_ = [("n", C.c_int), ("kind", C.c_int), ("src_w", C.c_int), ("src_h", C.c_int),
+                ("frames", C.POINTER(C.c_void_p)), ("K9s", C.POINTER(C.c_float)), ("R9s", C.POINTER(C.c_float)),
+                ("scale", C.c_float), ("masks", C.POINTER(C.c_void_p)), ("num_bands", C.c_int),
+                ("gain_maps", C.POINTER(C.c_void_p)), ("cut", C.c_int * 4)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.po_blender_create.restype = C.c_void_p
+        _lib.po_blender_level_laplace.restype = C.c_void_p
+        _lib.po_blender_level_weights.restype = C.c_void_p
+        _lib.po_bands_from_strength.argtypes = [C.c_int, C.c_int, C.c_float]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f9(v):
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(9))
+
+
+def set_threads(n):
+    lib().po_set_threads(int(n))
+
+
+def projector(kind, scale, K, R):
+    p = Projector()
+    K = _f9(K); R = _f9(R)
+    lib().po_projector_set(C.byref(p), int(kind), C.c_float(scale), _p(K), _p(R))
+    return p
+
+
+def map_forward(p, x, y):
+    u = C.c_float(); v = C.c_float()
+    lib().po_map_forward(C.byref(p), C.c_float(x), C.c_float(y), C.byref(u), C.byref(v))
+    return u.value, v.value
+
+
+def map_backward(p, u, v):
+    x = C.c_float(); y = C.c_float()
+    lib().po_map_backward(C.byref(p), C.c_float(u), C.c_float(v), C.byref(x), C.byref(y))
+    return x.value, y.value
+
+
+def warp_roi(p, w, h):
+    r = (C.c_int * 4)()
+    lib().po_warp_roi(C.byref(p), int(w), int(h), r)
+    return tuple(r)
+
+
+def result_roi(corners, sizes):
+    c = np.ascontiguousarray(np.asarray(corners, dtype=np.int32).reshape(-1))
+    s = np.ascontiguousarray(np.asarray(sizes, dtype=np.int32).reshape(-1))
+    r = (C.c_int * 4)()
+    lib().po_result_roi(len(c) // 2, _p(c), _p(s), r)
+    return tuple(r)
+
+
+def build_maps(p, w, h):
+    r = warp_roi(p, w, h)
+    xm = np.empty((r[3], r[2]), np.float32); ym = np.empty((r[3], r[2]), np.float32)
+    lib().po_build_maps(C.byref(p), int(w), int(h), _p(xm), _p(ym))
+    return xm, ym
+
+
+def remap(src, xmap, ymap, interp, border):
+    src = np.ascontiguousarray(src)
+    h, w = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dh, dw = xmap.shape
+    dst = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.uint8)
+    lib().po_remap_8u(_p(src), w, h, C.c_size_t(w * cn), cn, _p(np.ascontiguousarray(xmap)),
+                      _p(np.ascontiguousarray(ymap)), dw, dh, int(interp), int(border), _p(dst), C.c_size_t(dw * cn))
+    return dst
+
+
+def warp(p, src, interp=INTER_LINEAR, border=BORDER_REFLECT):
+    """RotationWarper::warp -> (corner, warped)"""
+    src = np.ascontiguousarray(src)
+    h, w = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    r = warp_roi(p, w, h)
+    dst = np.empty((r[3], r[2]) if src.ndim == 2 else (r[3], r[2], cn), np.uint8)
+    corner = (C.c_int * 2)()
+    lib().po_warp_8u(C.byref(p), _p(src), w, h, C.c_size_t(w * cn), cn, int(interp), int(border), _p(dst), corner)
+    return (corner[0], corner[1]), dst
+
+
+def pyr_down_16s(a):
+    a = np.ascontiguousarray(a, dtype=np.int16)
+    h, w = a.shape[:2]; cn = 1 if a.ndim == 2 else a.shape[2]
+    d = np.empty(((h + 1) // 2, (w + 1) // 2) + (() if a.ndim == 2 else (cn,)), np.int16)
+    lib().po_pyr_down_16s(_p(a), w, h, cn, _p(d))
+    return d
+
+
+def pyr_down_32f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    h, w = a.shape
+    d = np.empty(((h + 1) // 2, (w + 1) // 2), np.float32)
+    lib().po_pyr_down_32f(_p(a), w, h, _p(d))
+    return d
+
+
+def pyr_up_16s(a):
+    a = np.ascontiguousarray(a, dtype=np.int16)
+    h, w = a.shape[:2]; cn = 1 if a.ndim == 2 else a.shape[2]
+    d = np.empty((2 * h, 2 * w) + (() if a.ndim == 2 else (cn,)), np.int16)
+    lib().po_pyr_up_16s(_p(a), w, h, cn, _p(d))
+    return d
+
+
+def dilate3x3(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    d = np.empty_like(a)
+    lib().po_dilate3x3_8u(_p(a), a.shape[1], a.shape[0], _p(d))
+    return d
+
+
+def resize_linear_exact(a, dw, dh):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    h, w = a.shape[:2]; cn = 1 if a.ndim == 2 else a.shape[2]
+    d = np.empty((dh, dw) + (() if a.ndim == 2 else (cn,)), np.uint8)
+    lib().po_resize_linear_exact_8u(_p(a), w, h, cn, _p(d), int(dw), int(dh))
+    return d
+
+
+def resize_linear_32f(a, dw, dh):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    d = np.empty((dh, dw), np.float32)
+    lib().po_resize_linear_32f(_p(a), a.shape[1], a.shape[0], _p(d), int(dw), int(dh))
+    return d
+
+
+def distance_l1(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    d = np.empty(a.shape, np.float32)
+    lib().po_distance_l1(_p(a), a.shape[1], a.shape[0], _p(d))
+    return d
+
+
+def bands_from_strength(w, h, strength):
+    return lib().po_bands_from_strength(int(w), int(h), C.c_float(strength))
+
+
+def voronoi_find(corners, sizes, masks):
+    n = len(masks)
+    c = np.ascontiguousarray(np.asarray(corners, dtype=np.int32).reshape(-1))
+    s = np.ascontiguousarray(np.asarray(sizes, dtype=np.int32).reshape(-1))
+    ms = [np.ascontiguousarray(m, dtype=np.uint8).copy() for m in masks]
+    arr = (C.c_void_p * n)(*[m.ctypes.data for m in ms])
+    lib().po_voronoi_find(n, _p(c), _p(s), arr)
+    return ms
+
+
+def prepare_masks_voronoi(kind, w, h, Ks, Rs, scale):
+    Ks = np.ascontiguousarray(np.asarray(Ks, dtype=np.float32).reshape(-1, 9))
+    Rs = np.ascontiguousarray(np.asarray(Rs, dtype=np.float32).reshape(-1, 9))
+    n = Ks.shape[0]
+    masks = []
+    for i in range(n):
+        r = warp_roi(projector(kind, scale, Ks[i], Rs[i]), w, h)
+        masks.append(np.zeros((r[3], r[2]), np.uint8))
+    arr = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
+    lib().po_prepare_masks_voronoi(n, int(kind), int(w), int(h), _p(Ks), _p(Rs), C.c_float(scale), arr)
+    return masks
+
+
+class Blender:
+    """cv::detail::MultiBandBlender (num_bands >= 0) / Blender::NO (num_bands == -1)."""
+
+    def __init__(self, num_bands):
+        self.h = C.c_void_p(lib().po_blender_create(int(num_bands)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().po_blender_destroy(self.h)
+            self.h = None
+
+    def prepare(self, corners, sizes):
+        c = np.ascontiguousarray(np.asarray(corners, dtype=np.int32).reshape(-1))
+        s = np.ascontiguousarray(np.asarray(sizes, dtype=np.int32).reshape(-1))
+        lib().po_blender_prepare(self.h, len(c) // 2, _p(c), _p(s))
+
+    def feed(self, img16s, mask, tl):
+        img16s = np.ascontiguousarray(img16s, dtype=np.int16)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        h, w = mask.shape
+        assert img16s.shape == (h, w, 3)
+        lib().po_blender_feed(self.h, _p(img16s), _p(mask), w, h, int(tl[0]), int(tl[1]))
+
+    def blend(self):
+        r = self.dst_roi_final()
+        dst = np.empty((r[3], r[2], 3), np.int16)
+        m = np.empty((r[3], r[2]), np.uint8)
+        lib().po_blender_blend(self.h, _p(dst), _p(m))
+        return dst, m
+
+    def num_bands(self):
+        return lib().po_blender_num_bands(self.h)
+
+    def dst_roi(self):
+        r = (C.c_int * 4)(); lib().po_blender_dst_roi(self.h, r); return tuple(r)
+
+    def dst_roi_final(self):
+        r = (C.c_int * 4)(); lib().po_blender_dst_roi_final(self.h, r); return tuple(r)
+
+    def level_size(self, lvl):
+        r = (C.c_int * 2)(); lib().po_blender_level_size(self.h, lvl, r); return tuple(r)
+
+    def level_laplace(self, lvl):
+        w, h = self.level_size(lvl)
+        ptr = lib().po_blender_level_laplace(self.h, lvl)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(h, w, 3)).copy()
+
+    def level_weights(self, lvl):
+        w, h = self.level_size(lvl)
+        ptr = lib().po_blender_level_weights(self.h, lvl)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(h, w)).copy()
+
+    def last_tile(self):
+        r = (C.c_int * 4)(); t = (C.c_int * 4)()
+        lib().po_blender_last_tile(self.h, r, t)
+        return tuple(r), tuple(t)
+
+
+def compose(frames, Ks, Rs, scale, masks, num_bands, kind=SPHERICAL, gain_maps=None, cut=None):
+    """ocvStitcher::process.  Returns (pano u8 HxWx3, (warp_ms, feed_ms, blend_ms))."""
+    n = len(frames)
+    frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+    masks = [np.ascontiguousarray(m, dtype=np.uint8) for m in masks]
+    h, w = frames[0].shape[:2]
+    Ks = np.ascontiguousarray(np.asarray(Ks, dtype=np.float32).reshape(n, 9))
+    Rs = np.ascontiguousarray(np.asarray(Rs, dtype=np.float32).reshape(n, 9))
+    a = ComposeArgs()
+    a.n = n; a.kind = kind; a.src_w = w; a.src_h = h
+    fa = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+    ma = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
+    a.frames = C.cast(fa, C.POINTER(C.c_void_p)); a.masks = C.cast(ma, C.POINTER(C.c_void_p))
+    a.K9s = Ks.ctypes.data_as(C.POINTER(C.c_float)); a.R9s = Rs.ctypes.data_as(C.POINTER(C.c_float))
+    a.scale = scale; a.num_bands = int(num_bands)
+    if gain_maps is not None:
+        gain_maps = [np.ascontiguousarray(g, dtype=np.float32) for g in gain_maps]
+        ga = (C.c_void_p * n)(*[g.ctypes.data for g in gain_maps])
+        a.gain_maps = C.cast(ga, C.POINTER(C.c_void_p))
+    rois = [warp_roi(projector(kind, scale, Ks[i], Rs[i]), w, h) for i in range(n)]
+    full = result_roi([r[:2] for r in rois], [r[2:] for r in rois])
+    if cut is None:
+        cut = (0, 0, full[2], full[3])
+    for i in range(4):
+        a.cut[i] = int(cut[i])
+    out = np.empty((cut[3], cut[2], 3), np.uint8)
+    wh = (C.c_int * 2)()
+    rc = lib().po_compose(C.byref(a), _p(out), wh)
+    if rc != 0:
+        raise ValueError("cut rectangle outside the panorama")
+    ms = (C.c_double * 3)()
+    lib().po_last_timings(ms)
+    return out, tuple(ms)

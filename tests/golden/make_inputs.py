@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Generate the committed INPUT fixtures from the reference's data files.
+
+Run once in the build container (needs /root/reference, PIL).  Nothing here is
+executed on the GPU box; the outputs are committed:
+
+  c1_cam{0..3}.png   4 x 480x270 RGB8, box-downsampled (4x4 mean, round-half-up)
+                     from /root/reference/2222/{1..4}.png (1920x1080).  480x270 is
+                     the frame size the K in 2222/cameraparaout_1.txt was
+                     calibrated at (cx=240, cy=135).
+  c1_cams.json       last record of 2222/cameraparaout_1.txt (old 7-line format:
+                     one shared K, 4 R, scale), parsed verbatim as decimal strings
+                     -> floats.
+  r_cams.json        cfg/cameras.yaml `4cam-black / inputsz 960` structure
+                     (2 stitchers x 2 cams, 18*N+1 floats + cut) - data only.
+
+These are data (inputs), not reference source.
+"""
+import json
+import os
+import re
+
+import numpy as np
+from PIL import Image
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def box4(path):
+    a = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint32)
+    h, w, _ = a.shape
+    assert (w, h) == (1920, 1080)
+    a = a.reshape(h // 4, 4, w // 4, 4, 3).sum(axis=(1, 3))
+    return ((a + 8) // 16).astype(np.uint8)
+
+
+def last_record_old_format(path):
+    lines = [l.strip() for l in open(path) if l.strip()]
+    idx = max(i for i, l in enumerate(lines) if ":" in l)
+    rec = lines[idx:]
+    stamp = rec[0].rstrip(":")
+    K = [float(v) for v in rec[1].rstrip(",").split(",")]
+    assert len(K) == 9
+    Rs = []
+    for l in rec[2:6]:
+        r = [float(v) for v in l.rstrip(",").split(",")]
+        assert len(r) == 9
+        Rs.append(r)
+    scale = float(rec[6])
+    return {"timestamp": stamp, "K": K, "R": Rs, "scale": scale,
+            "width": 480, "height": 270, "source": "2222/cameraparaout_1.txt (last record)"}
+
+
+def structure_4cam_black_960(path):
+    txt = open(path).read()
+    # locate the structure block: sttype 4cam-black ... inputsz: 960
+    blocks = txt.split("\n -\n")
+    for b in blocks:
+        if "sttype: 4cam-black" in b and "inputsz: 960" in b:
+            cams = re.findall(r"cams:\s*\[([^\]]*)\]", b, flags=re.S)
+            cuts = re.findall(r"^\s*cut:\s*\[([^\]]*)\]", b, flags=re.M)
+            out = []
+            for c, cut in zip(cams, cuts):
+                vals = [float(v) for v in c.replace("\n", " ").split(",") if v.strip()]
+                assert len(vals) == 18 * 2 + 1
+                out.append({"cams": vals, "cut": [int(v) for v in cut.split(",")]})
+            return {"width": 960, "height": 540, "num_images": 2, "stitchers": out,
+                    "source": "cfg/cameras.yaml structure lijing/imx390/4cam-black/undistor/120/960"}
+    raise SystemExit("structure not found")
+
+
+def main():
+    for i in range(4):
+        im = box4(f"{REF}/2222/{i + 1}.png")
+        Image.fromarray(im, "RGB").save(f"{OUT}/c1_cam{i}.png", optimize=True)
+    json.dump(last_record_old_format(f"{REF}/2222/cameraparaout_1.txt"),
+              open(f"{OUT}/c1_cams.json", "w"), indent=1)
+    json.dump(structure_4cam_black_960(f"{REF}/cfg/cameras.yaml"),
+              open(f"{OUT}/r_cams.json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
