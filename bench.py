@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py - composed panoramas/s of the MI355X compose path on BASELINE.json config 2.
+
+One step = one 8-camera panorama: 8 x 1920x1080 BGR8 frames (resident in HBM), two groups of four
+cameras (the reference never stitches a full ring in one pass: README.md:27-29, src/master.cpp:314-318),
+spherical warp + 5-band multi-band blend per group, fixed K/R (imx390-derived f=1002.416, yaws
++-22.5/+-67.5 deg), Voronoi seam masks.  Synthetic frames.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1: launched by torch.distributed.run, one rank per GPU; cameras are sharded over the ranks
+  (rank r owns cameras [8r/N, 8(r+1)/N)), each rank warps + builds the Gaussian pyramids of its cameras,
+  ONE RCCL gather per group lands the pyramid slots on rank 0, which blends.  Total work per step is
+  fixed -> "scaling": "strong".
+
+Prints ONE JSON line (rank 0).  `roofline` is the warp kernel (K1): algorithmic bytes
+sum_cams(W*H*3 read once + Wt*Ht*6 written once) per launch / mean launch duration from HIP events
+recorded on the launch stream inside the timed region.  `cpu_baseline` is the CPU oracle
+(OpenCV-3.4-semantics restatement, kind "port") on a bounded sample of the same workload.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+class DevView:
+    """zero-copy torch view of a raw device allocation (for RCCL on the library's pyramid slots)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bands", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from helpers import c2_group, synth_frame
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    pano = importlib.import_module("img-stitching_amd")
+    g = c2_group()
+    W, H, NG, NC = g["w"], g["h"], 2, 4
+    ctxs = []
+    for grp in range(NG):
+        ctx = pano.Context(NC, W, H, scale=g["scale"], num_bands=args.bands, device=local)
+        for i in range(NC):
+            ctx.set_camera(i, g["K"][i], g["R"][i])
+        ctx.prepare()
+        ctx.build_masks_voronoi()
+        ctxs.append(ctx)
+    ow, oh = ctxs[0].output_size()
+    frames = [[torch.from_numpy(synth_frame(W, H, 42 + grp * NC + i)).cuda() for i in range(NC)] for grp in range(NG)]
+    outs = [torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in range(NG)]
+    fptr = [[t.data_ptr() for t in fr] for fr in frames]
+    strides = [W * 3] * NC
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # camera sharding (world > 1)
+    per_rank = (NG * NC) // world if world > 1 else NG * NC
+    if world > 1 and (NG * NC) % world:
+        raise SystemExit("gpus must divide 8")
+    my_cams = list(range(rank * per_rank, (rank + 1) * per_rank))
+    slot_views = []
+    for ctx in ctxs:
+        base, slot = ctx.pyramid_slots()
+        slot_views.append((torch.as_tensor(DevView(base, slot * NC), device="cuda"), slot))
+
+    def step_single():
+        for grp in range(NG):
+            ctxs[grp].compose(fptr[grp], strides, outs[grp].data_ptr(), ow * 3, stream)
+
+    def step_sharded():
+        for grp in range(NG):
+            cams = [c - grp * NC for c in my_cams if c // NC == grp]
+            bits = sum(1 << c for c in cams)
+            if bits:
+                ctxs[grp].feed_cameras(bits, fptr[grp], strides, stream)
+            buf, slot = slot_views[grp]
+            ranks_in_group = [r for r in range(world) if (r * per_rank) // NC == grp]
+            if per_rank >= NC:
+                # this rank (if it owns the group) holds every camera of it; only the panorama moves later
+                pass
+            else:
+                # each rank of the group contributes per_rank consecutive slots; root receives them in place
+                for r in ranks_in_group:
+                    lo = (r * per_rank - grp * NC) * slot
+                    view = buf[lo:lo + per_rank * slot]
+                    if r == 0:
+                        continue
+                    if rank == r:
+                        dist.send(view, dst=0)
+                    elif rank == 0:
+                        dist.recv(view, src=r)
+            if per_rank >= NC:
+                owner = ranks_in_group[0]
+                if rank == owner:
+                    ctxs[grp].blend(outs[grp].data_ptr(), ow * 3, stream)
+                if owner != 0:
+                    if rank == owner:
+                        dist.send(outs[grp], dst=0)
+                    elif rank == 0:
+                        dist.recv(outs[grp], src=owner)
+            elif rank == 0:
+                ctxs[grp].blend(outs[grp].data_ptr(), ow * 3, stream)
+
+    step = step_single if world == 1 else step_sharded
+
+    for c in ctxs:
+        c.set_profiling(True)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    for c in ctxs:
+        c.stage_stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = None
+    if rank == 0:
+        src_b, dst_b = ctxs[0].warp_bytes()
+        alg_bytes = src_b + dst_b  # per launch (one group of 4 cameras)
+        roofline = None
+        stage_ms, stage_n = [0.0] * 3, [0] * 3
+        for c in ctxs:
+            ms, n = c.stage_stats(reset=True)
+            stage_ms = [a + b for a, b in zip(stage_ms, ms)]
+            stage_n = [a + b for a, b in zip(stage_n, n)]
+        warp_ms, warp_launches = stage_ms[0], stage_n[0]
+        if world == 1 and warp_launches:
+            avg_ms = warp_ms / warp_launches
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "warp_traffic.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"kernel": "warp_tiles_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                        "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": NG}
+        result = {
+            "metric": "stitched panoramas/sec (8x1080p->pano)", "value": round(args.steps / dt, 2),
+            "unit": "panoramas/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8/int16 fixed-point (f32 weights)",
+            "data": "synthetic",
+            "config": {"workload": "C2: 8x1920x1080 BGR8 -> 2 groups x 4 cameras, spherical warp + %d-band "
+                                   "multi-band blend, Voronoi seams, pano 2 x %dx%d" % (args.bands, ow, oh),
+                       "parallelism": "single GPU" if world == 1 else "cameras sharded %d/rank, RCCL gather to rank 0" % per_rank},
+            "roofline": roofline,
+            "stage_us_per_launch": {k: round(stage_ms[i] / max(stage_n[i], 1) * 1e3, 2)
+                                    for i, k in enumerate(("warp", "pyramid", "blend"))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(ctxs, g, args.bands)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ctxs, g, bands):
+    """the CPU oracle (checker infrastructure, used here only as the timed CPU leg) on a bounded sample"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pano_oracle as po
+    from helpers import synth_frame
+    W, H = g["w"], g["h"]
+    threads = min(os.cpu_count() or 1, 16)
+    po.set_threads(threads)
+    masks = [ctxs[0].get_mask(i) for i in range(4)]
+    frames = [synth_frame(W, H, 42 + i) for i in range(4)]
+    t0 = time.perf_counter()
+    reps = 0
+    stage = [0.0, 0.0, 0.0]
+    while True:
+        # one panorama = two groups
+        for _ in range(2):
+            _, ms = po.compose(frames, g["K"], g["R"], g["scale"], masks, bands)
+            stage = [a + b for a, b in zip(stage, ms)]
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 20:
+            break
+    po.set_threads(1)
+    return {"value": round(reps / el, 3), "unit": "panoramas/s", "cores": threads, "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": "%d panoramas of the same C2 workload (8x1080p, 2 groups, %d bands), OpenMP over rows; "
+                      "stage ms/pano warp %.0f feed %.0f blend %.0f" % (reps, bands, stage[0] / reps, stage[1] / reps, stage[2] / reps)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,302 @@
+"""img-stitching_amd - MI355X-native panorama composition (the `ocvStitcher::process` hot path of
+LeRoii/Img-Stitching) behind the C-ABI of include/pano.h.
+
+This module is the Python host-side mirror used by the tests and bench.py: a ctypes binding
+(`Context`) plus `Stitcher`, which keeps the reference class's surface
+(`init` / `calibration` / `process`, reference include/ocvstitcher.hpp:262, :592, :1141).
+The C++ mirror for drop-in use from master.cpp-style code is csrc/stitcher.hpp.
+
+There is no CPU fallback: if libpano_hip.so is missing or no GPU is present the compute calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpano_hip.so")
+
+SPHERICAL, CYLINDRICAL = 0, 1
+BANDS_NO_BLEND, BANDS_FROM_STRENGTH = -1, -2
+RET_OK, RET_ERR = 0, -1
+MAX_CAMS = 8
+
+_STATUS = {0: "PANO_OK", -1: "PANO_ERR", -2: "PANO_EINVAL", -3: "PANO_ESTATE", -4: "PANO_EHIP",
+           -5: "PANO_ENODEVICE", -6: "PANO_EWRAP", -7: "PANO_ENOMEM"}
+
+
+class PanoError(RuntimeError):
+    def __init__(self, status, msg=""):
+        self.status = status
+        super().__init__(f"{_STATUS.get(status, status)}: {msg}")
+
+
+class Config(C.Structure):
+    _fields_ = [("num_images", C.c_int), ("width", C.c_int), ("height", C.c_int), ("projector", C.c_int),
+                ("warped_image_scale", C.c_float), ("blend_strength", C.c_float), ("num_bands", C.c_int),
+                ("cut", C.c_int * 4), ("device", C.c_int)]
+
+
+def build(force=False):
+    """Compile csrc/ for gfx950 into libpano_hip.so (in-tree)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".cpp", ".hpp"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "pano.h"))
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", src_dir, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libpano_hip.so.  torch (when installed) bundles its own libamdhip64 with the same SONAME;
+    importing it first makes both share one HIP runtime so torch device pointers are valid here."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PanoError(-4, f"{LIB_PATH} is missing - run __graft_entry__.build(); there is no CPU fallback")
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = C.CDLL(LIB_PATH)
+    lib.pano_last_error.restype = C.c_char_p
+    lib.pano_version.restype = C.c_char_p
+    lib.pano_last_error.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+# every symbol include/pano.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = [
+    "pano_create", "pano_destroy", "pano_last_error", "pano_version", "pano_set_camera",
+    "pano_set_cameras_from_list", "pano_load_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
+    "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
+    "pano_build_masks_voronoi", "pano_get_mask", "pano_set_gain_map", "pano_warp", "pano_warp_mask", "pano_compose",
+    "pano_compose_host", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_set_profiling",
+    "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_debug_get_level", "pano_debug_get_weights",
+    "pano_debug_get_canvas_weights", "pano_debug_get_canvas",
+]
+
+
+def _vp(x):
+    return C.c_void_p(int(x))
+
+
+class Context:
+    """Thin RAII wrapper of pano_ctx."""
+
+    def __init__(self, num_images, width, height, scale=0.0, projector=SPHERICAL, num_bands=BANDS_FROM_STRENGTH,
+                 blend_strength=5.0, cut=(0, 0, 0, 0), device=0):
+        self.lib = load_library()
+        cfg = Config()
+        cfg.num_images = num_images; cfg.width = width; cfg.height = height; cfg.projector = projector
+        cfg.warped_image_scale = scale; cfg.blend_strength = blend_strength; cfg.num_bands = num_bands
+        for i in range(4):
+            cfg.cut[i] = int(cut[i])
+        cfg.device = device
+        self.h = C.c_void_p()
+        self.n = num_images
+        self.width, self.height = width, height
+        st = self.lib.pano_create(C.byref(cfg), C.byref(self.h))
+        if st != 0:
+            self.h = None
+            raise PanoError(st, "pano_create failed (no GPU / bad config); there is no CPU fallback")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pano_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _ck(self, st):
+        if st != 0:
+            raise PanoError(st, (self.lib.pano_last_error(self.h) or b"").decode())
+
+    # -- parameters
+    def set_camera(self, i, K, R):
+        K = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+        R = np.ascontiguousarray(np.asarray(R, np.float32).reshape(9))
+        self._ck(self.lib.pano_set_camera(self.h, i, _vp(K.ctypes.data), _vp(R.ctypes.data)))
+
+    def set_cameras_from_list(self, text):
+        self._ck(self.lib.pano_set_cameras_from_list(self.h, text.encode()))
+
+    def load_camera_file(self, path):
+        self._ck(self.lib.pano_load_camera_file(self.h, os.fsencode(path)))
+
+    def prepare(self):
+        self._ck(self.lib.pano_prepare(self.h))
+
+    def roi(self, i):
+        r = (C.c_int * 4)(); self._ck(self.lib.pano_get_roi(self.h, i, r)); return tuple(r)
+
+    def pano_rect(self):
+        r = (C.c_int * 4)(); self._ck(self.lib.pano_get_pano_rect(self.h, r)); return tuple(r)
+
+    def num_bands(self):
+        v = C.c_int(); self._ck(self.lib.pano_get_num_bands(self.h, C.byref(v))); return v.value
+
+    def feed_tile(self, i):
+        r = (C.c_int * 4)(); t = (C.c_int * 4)()
+        self._ck(self.lib.pano_get_feed_tile(self.h, i, r, t)); return tuple(r), tuple(t)
+
+    def set_cut(self, cut):
+        r = (C.c_int * 4)(*[int(v) for v in cut]); self._ck(self.lib.pano_set_cut(self.h, r))
+
+    def output_size(self):
+        w = C.c_int(); h = C.c_int()
+        self._ck(self.lib.pano_get_output_size(self.h, C.byref(w), C.byref(h))); return w.value, h.value
+
+    # -- masks / gains
+    def set_mask(self, i, mask):
+        mask = np.ascontiguousarray(mask, np.uint8)
+        self._ck(self.lib.pano_set_mask(self.h, i, _vp(mask.ctypes.data), mask.shape[1], mask.shape[0],
+                                        C.c_size_t(mask.strides[0])))
+
+    def build_masks_voronoi(self):
+        self._ck(self.lib.pano_build_masks_voronoi(self.h))
+
+    def get_mask(self, i):
+        r = self.roi(i)
+        m = np.empty((r[3], r[2]), np.uint8)
+        self._ck(self.lib.pano_get_mask(self.h, i, _vp(m.ctypes.data), C.c_size_t(r[2]))); return m
+
+    def set_gain_map(self, i, gain):
+        if gain is None:
+            self._ck(self.lib.pano_set_gain_map(self.h, i, None, 0, 0)); return
+        g = np.ascontiguousarray(gain, np.float32)
+        self._ck(self.lib.pano_set_gain_map(self.h, i, _vp(g.ctypes.data), g.shape[1], g.shape[0]))
+
+    # -- per-frame, host buffers (cv::Mat in / cv::Mat out)
+    def compose_host(self, frames):
+        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        assert len(frames) == self.n
+        for f in frames:
+            if f.shape != (self.height, self.width, 3):
+                raise PanoError(-2, "frame shape")
+        w, h = self.output_size()
+        out = np.empty((h, w, 3), np.uint8)
+        ptrs = (C.c_void_p * self.n)(*[f.ctypes.data for f in frames])
+        strides = (C.c_size_t * self.n)(*[f.strides[0] for f in frames])
+        self._ck(self.lib.pano_compose_host(self.h, ptrs, strides, _vp(out.ctypes.data), C.c_size_t(out.strides[0])))
+        return out
+
+    # -- per-frame, device pointers (ints); stream = hipStream_t as int (0 = null stream)
+    def compose(self, d_frames, strides, d_out, out_stride, stream=0):
+        ptrs = (C.c_void_p * self.n)(*[int(p) for p in d_frames])
+        st = (C.c_size_t * self.n)(*[int(s) for s in strides])
+        self._ck(self.lib.pano_compose(self.h, ptrs, st, _vp(d_out), C.c_size_t(out_stride), _vp(stream)))
+
+    def feed_cameras(self, cam_bits, d_frames, strides, stream=0):
+        ptrs = (C.c_void_p * self.n)(*[int(p) for p in d_frames])
+        st = (C.c_size_t * self.n)(*[int(s) for s in strides])
+        self._ck(self.lib.pano_feed_cameras(self.h, C.c_uint(cam_bits), ptrs, st, _vp(stream)))
+
+    def blend(self, d_out, out_stride, stream=0):
+        self._ck(self.lib.pano_blend(self.h, _vp(d_out), C.c_size_t(out_stride), _vp(stream)))
+
+    def pyramid_slots(self):
+        base = C.c_void_p(); sz = C.c_size_t()
+        self._ck(self.lib.pano_get_pyramid_slots(self.h, C.byref(base), C.byref(sz))); return base.value, sz.value
+
+    def warp(self, i, d_src, src_stride, d_dst, dst_stride, stream=0):
+        self._ck(self.lib.pano_warp(self.h, i, _vp(d_src), C.c_size_t(src_stride), _vp(d_dst), C.c_size_t(dst_stride),
+                                    _vp(stream)))
+
+    def warp_mask(self, i, d_dst, dst_stride, stream=0):
+        self._ck(self.lib.pano_warp_mask(self.h, i, _vp(d_dst), C.c_size_t(dst_stride), _vp(stream)))
+
+    # -- measurement
+    def set_profiling(self, on):
+        self._ck(self.lib.pano_set_profiling(self.h, int(bool(on))))
+
+    def stage_ms(self):
+        ms = (C.c_float * 3)(); self._ck(self.lib.pano_get_stage_ms(self.h, ms)); return tuple(ms)
+
+    def stage_stats(self, reset=True):
+        ms = (C.c_double * 3)(); n = (C.c_uint64 * 3)()
+        self._ck(self.lib.pano_get_stage_stats(self.h, ms, n, int(bool(reset)))); return tuple(ms), tuple(n)
+
+    def warp_bytes(self):
+        a = C.c_uint64(); b = C.c_uint64()
+        self._ck(self.lib.pano_get_warp_bytes(self.h, C.byref(a), C.byref(b))); return a.value, b.value
+
+    # -- stage inspection
+    def debug_level(self, i, level):
+        w = C.c_int(); h = C.c_int()
+        self._ck(self.lib.pano_debug_get_level(self.h, i, level, None, C.byref(w), C.byref(h)))
+        a = np.empty((h.value, w.value, 3), np.int16)
+        self._ck(self.lib.pano_debug_get_level(self.h, i, level, _vp(a.ctypes.data), C.byref(w), C.byref(h)))
+        return a
+
+    def debug_weights(self, i, level):
+        w = C.c_int(); h = C.c_int()
+        self._ck(self.lib.pano_debug_get_weights(self.h, i, level, None, C.byref(w), C.byref(h)))
+        a = np.empty((h.value, w.value), np.float32)
+        self._ck(self.lib.pano_debug_get_weights(self.h, i, level, _vp(a.ctypes.data), C.byref(w), C.byref(h)))
+        return a
+
+    def debug_canvas_weights(self, level):
+        w = C.c_int(); h = C.c_int()
+        self._ck(self.lib.pano_debug_get_canvas_weights(self.h, level, None, C.byref(w), C.byref(h)))
+        a = np.empty((h.value, w.value), np.float32)
+        self._ck(self.lib.pano_debug_get_canvas_weights(self.h, level, _vp(a.ctypes.data), C.byref(w), C.byref(h)))
+        return a
+
+    def debug_canvas(self, level):
+        w = C.c_int(); h = C.c_int()
+        self._ck(self.lib.pano_debug_get_canvas(self.h, level, None, C.byref(w), C.byref(h)))
+        a = np.empty((h.value, w.value, 3), np.int16)
+        self._ck(self.lib.pano_debug_get_canvas(self.h, level, _vp(a.ctypes.data), C.byref(w), C.byref(h)))
+        return a
+
+
+class Stitcher:
+    """Python mirror of `ocvStitcher` (reference include/ocvstitcher.hpp:254-1306) for the compose path.
+
+    init(cfg)          <- init(yamlPath) (:262): size, num_images, blend strength, default cams + cut
+    calibration(imgs)  <- calibration(imgs) (:592): K/R are fixed, so this is initSeam's mask half (:975-1139)
+                          with the Voronoi seam finder; returns RET_OK / RET_ERR
+    process(imgs)      <- process(imgs, ret) (:1141): returns the cut BGR panorama
+    """
+
+    def __init__(self):
+        self.ctx = None
+
+    def init(self, cfg):
+        """cfg: dict with outPutWidth, outPutHeight, num_images, stitcherBlenderStrength, cams (18N+1 list or
+        comma string), optional cut, projector, num_bands, device."""
+        try:
+            cams = cfg["cams"]
+            text = cams if isinstance(cams, str) else ",".join(repr(float(v)) for v in cams)
+            self.ctx = Context(int(cfg["num_images"]), int(cfg["outPutWidth"]), int(cfg["outPutHeight"]),
+                               projector=int(cfg.get("projector", SPHERICAL)),
+                               num_bands=int(cfg.get("num_bands", BANDS_FROM_STRENGTH)),
+                               blend_strength=float(cfg.get("stitcherBlenderStrength", 5.0)),
+                               cut=tuple(cfg.get("cut", (0, 0, 0, 0))), device=int(cfg.get("device", 0)))
+            self.ctx.set_cameras_from_list(text)
+            self.ctx.prepare()
+        except (PanoError, KeyError, ValueError):
+            self.ctx = None
+            return RET_ERR
+        return RET_OK
+
+    def calibration(self, imgs=None):
+        if self.ctx is None:
+            return RET_ERR
+        try:
+            self.ctx.build_masks_voronoi()
+        except PanoError:
+            return RET_ERR
+        return RET_OK
+
+    def process(self, imgs):
+        return self.ctx.compose_host(imgs)

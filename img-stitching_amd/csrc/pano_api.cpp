@@ -1,0 +1,969 @@
+// pano_api.cpp - C-ABI of libpano_hip.so (include/pano.h): context, buffers, launch sequencing.
+// Host code only; the arithmetic is in pano_kernels.hip, the init-time geometry in pano_plan.hpp.
+// No CPU fallback exists: every compute entry point launches HIP kernels or fails.
+
+#include "../../include/pano.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "pano_kernels.hpp"
+#include "pano_plan.hpp"
+
+using namespace pano;
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct pano_ctx {
+    pano_config cfg{};
+    bool have_cam[kMaxCams] = {};
+    float K[kMaxCams][9] = {}, R[kMaxCams][9] = {};
+    float scale = 0.f;
+    Plan plan;
+    bool prepared = false;
+    int device = -1;
+    int levels = 0;  // bands + 1 (1 for Blender::NO)
+
+    // per camera device data
+    float2 *colA[kMaxCams] = {}, *rowB[kMaxCams] = {};          // bordered-tile tables (K1)
+    float2 *colA_roi[kMaxCams] = {}, *rowB_roi[kMaxCams] = {};  // ROI tables (stage warp, mask warp)
+    uint8_t* mask[kMaxCams] = {};                                // m_blenderMask, ROI sized, tight rows
+    bool mask_set[kMaxCams] = {};
+    bool weights_dirty = true;
+    // gain
+    float* gain[kMaxCams] = {};
+    int gain_w[kMaxCams] = {}, gain_h[kMaxCams] = {};
+    int2 *gcol[kMaxCams] = {}, *grow[kMaxCams] = {}, *gcol_roi[kMaxCams] = {}, *grow_roi[kMaxCams] = {};
+    float2 *gcolw[kMaxCams] = {}, *groww[kMaxCams] = {}, *gcolw_roi[kMaxCams] = {}, *groww_roi[kMaxCams] = {};
+
+    // pyramid slots (one allocation), weights, canvas
+    char* pyr_base = nullptr;
+    size_t slot_bytes = 0;
+    size_t lvl_off[kMaxCams][kMaxLevels] = {};
+    int lvl_pitch[kMaxCams][kMaxLevels] = {};
+    float* wgt[kMaxCams][kMaxLevels] = {};
+    float* wsum[kMaxLevels] = {};
+    int16_t* canvas[kMaxLevels] = {};
+
+    PyrParams pyr{};
+    CanvasParams cv{};
+
+    // host-buffer entry point staging
+    uint8_t* stage_in[kMaxCams] = {};
+    size_t stage_in_pitch = 0;
+    uint8_t* stage_out = nullptr;
+    size_t stage_out_pitch = 0;
+    hipStream_t own_stream = nullptr;
+
+    // profiling: a ring of event quads so that the timed loop never has to wait for the GPU
+    static constexpr int kEvRing = 64;
+    struct EvSlot {
+        hipEvent_t e[PANO_NUM_STAGES + 1];
+        unsigned recorded;
+    };
+    bool profiling = false;
+    EvSlot ring[kEvRing] = {};
+    bool ev_valid = false;
+    int ev_head = 0, ev_count = 0, ev_cur = -1;
+    double acc_ms[PANO_NUM_STAGES] = {};
+    uint64_t acc_n[PANO_NUM_STAGES] = {};
+    float last_ms[PANO_NUM_STAGES] = {};
+
+    std::string err;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                     \
+            return PANO_EHIP;                                                                   \
+        }                                                                                       \
+    } while (0)
+
+pano_status fail(pano_ctx* c, pano_status s, const char* msg) {
+    if (c) c->err = msg;
+    return s;
+}
+
+template <typename T>
+pano_status upload(pano_ctx* c, T** dptr, const void* h, size_t bytes) {
+    if (*dptr) {
+        HIP_TRY(c, hipFree(*dptr));
+        *dptr = nullptr;
+    }
+    HIP_TRY(c, hipMalloc((void**)dptr, bytes ? bytes : 16));
+    if (bytes) HIP_TRY(c, hipMemcpy(*dptr, h, bytes, hipMemcpyHostToDevice));
+    return PANO_OK;
+}
+
+template <typename T>
+void dfree(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_device(pano_ctx* c) {
+    for (int i = 0; i < kMaxCams; i++) {
+        dfree(c->colA[i]); dfree(c->rowB[i]); dfree(c->colA_roi[i]); dfree(c->rowB_roi[i]);
+        dfree(c->mask[i]); dfree(c->gain[i]);
+        dfree(c->gcol[i]); dfree(c->grow[i]); dfree(c->gcol_roi[i]); dfree(c->grow_roi[i]);
+        dfree(c->gcolw[i]); dfree(c->groww[i]); dfree(c->gcolw_roi[i]); dfree(c->groww_roi[i]);
+        dfree(c->stage_in[i]);
+        for (int l = 0; l < kMaxLevels; l++) dfree(c->wgt[i][l]);
+    }
+    for (int l = 0; l < kMaxLevels; l++) {
+        dfree(c->wsum[l]);
+        dfree(c->canvas[l]);
+    }
+    dfree(c->pyr_base);
+    dfree(c->stage_out);
+    if (c->ev_valid)
+        for (auto& sl : c->ring)
+            for (auto& e : sl.e) (void)hipEventDestroy(e);
+    c->ev_valid = false;
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    c->own_stream = nullptr;
+}
+
+// WarpCam for the bordered feed() tile of camera i (pipeline) or its plain ROI (stage entries)
+WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t stride, bool roi_only) {
+    WarpCam w{};
+    w.src = src;
+    w.src_w = c->plan.src_w;
+    w.src_h = c->plan.src_h;
+    w.src_stride = (int)stride;
+    std::memcpy(w.m, c->plan.proj[i].k_rinv, sizeof(w.m));
+    if (roi_only) {
+        w.colA = c->colA_roi[i]; w.rowB = c->rowB_roi[i];
+        w.tw = c->plan.roi[i].w; w.th = c->plan.roi[i].h;
+        w.gcol = c->gcol_roi[i]; w.gcolw = c->gcolw_roi[i]; w.grow = c->grow_roi[i]; w.groww = c->groww_roi[i];
+    } else {
+        w.colA = c->colA[i]; w.rowB = c->rowB[i];
+        w.tw = c->plan.tile[i].rect.w; w.th = c->plan.tile[i].rect.h;
+        w.dst = c->pyr_base + (size_t)i * c->slot_bytes + c->lvl_off[i][0];
+        w.dst_pitch = c->lvl_pitch[i][0];
+        w.gcol = c->gcol[i]; w.gcolw = c->gcolw[i]; w.grow = c->grow[i]; w.groww = c->groww[i];
+    }
+    w.gain = c->gain[i];
+    w.gw = c->gain_w[i];
+    return w;
+}
+
+// cv::resize INTER_LINEAR (f32) coefficients of dst index d for ssize -> dsize
+inline void linear_coef(int d, int ssize, int dsize, int& s0, int& s1, float& a0, float& a1) {
+    double scale = (double)ssize / dsize;
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= s;
+    if (s < 0) { f = 0; s = 0; }
+    if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+    s0 = s;
+    s1 = std::min(s + 1, ssize - 1);
+    a0 = 1.f - f;
+    a1 = f;
+}
+
+pano_status upload_gain_tables(pano_ctx* c, int i) {
+    const Rect& roi = c->plan.roi[i];
+    const FeedTile& t = c->plan.tile[i];
+    int gw = c->gain_w[i], gh = c->gain_h[i];
+    auto build = [&](int n, int off, int len, int ssize, std::vector<int2>& idx, std::vector<float2>& wv, bool rows) {
+        idx.resize(n);
+        wv.resize(n);
+        for (int k = 0; k < n; k++) {
+            int d = reflect(k - off, len);
+            int s0, s1;
+            float a0, a1;
+            if (rows) {
+                // vertical: sy may be clamped on both taps independently (resizeGeneric_ row clipping)
+                double scale = (double)ssize / len;
+                float f = (float)((d + 0.5) * scale - 0.5);
+                int s = (int)floorf(f);
+                f -= s;
+                s0 = std::min(std::max(s, 0), ssize - 1);
+                s1 = std::min(std::max(s + 1, 0), ssize - 1);
+                a0 = 1.f - f;
+                a1 = f;
+            } else {
+                linear_coef(d, ssize, len, s0, s1, a0, a1);
+            }
+            idx[k] = make_int2(s0, s1);
+            wv[k] = make_float2(a0, a1);
+        }
+    };
+    std::vector<int2> ix;
+    std::vector<float2> wx;
+    pano_status s;
+    build(t.rect.w, t.left, roi.w, gw, ix, wx, false);
+    if ((s = upload(c, &c->gcol[i], ix.data(), ix.size() * sizeof(int2)))) return s;
+    if ((s = upload(c, &c->gcolw[i], wx.data(), wx.size() * sizeof(float2)))) return s;
+    build(t.rect.h, t.top, roi.h, gh, ix, wx, true);
+    if ((s = upload(c, &c->grow[i], ix.data(), ix.size() * sizeof(int2)))) return s;
+    if ((s = upload(c, &c->groww[i], wx.data(), wx.size() * sizeof(float2)))) return s;
+    build(roi.w, 0, roi.w, gw, ix, wx, false);
+    if ((s = upload(c, &c->gcol_roi[i], ix.data(), ix.size() * sizeof(int2)))) return s;
+    if ((s = upload(c, &c->gcolw_roi[i], wx.data(), wx.size() * sizeof(float2)))) return s;
+    build(roi.h, 0, roi.h, gh, ix, wx, true);
+    if ((s = upload(c, &c->grow_roi[i], ix.data(), ix.size() * sizeof(int2)))) return s;
+    if ((s = upload(c, &c->groww_roi[i], wx.data(), wx.size() * sizeof(float2)))) return s;
+    return PANO_OK;
+}
+
+// weight pyramids + canvas weight sums; runs when masks changed
+pano_status ensure_weights(pano_ctx* c, hipStream_t s) {
+    if (!c->weights_dirty) return PANO_OK;
+    const Plan& P = c->plan;
+    for (int i = 0; i < P.n; i++)
+        if (!c->mask_set[i]) return fail(c, PANO_ESTATE, "blend masks not set (pano_set_mask / pano_build_masks_voronoi)");
+    if (P.bands >= 0) {
+        for (int i = 0; i < P.n; i++) {
+            const FeedTile& t = P.tile[i];
+            launch_mask_to_weight(c->mask[i], P.roi[i].w, P.roi[i].h, P.roi[i].w, t.left, t.top, c->wgt[i][0], t.rect.w,
+                                  t.rect.h, c->lvl_pitch[i][0], s);
+            for (int l = 0; l < P.bands; l++)
+                launch_pyr_down_f32(c->wgt[i][l], t.rect.w >> l, t.rect.h >> l, c->lvl_pitch[i][l], c->wgt[i][l + 1],
+                                    c->lvl_pitch[i][l + 1], s);
+        }
+        for (int l = 0; l <= P.bands; l++) launch_sum_weights(c->pyr, l, c->wsum[l], P.canvas.w >> l, P.canvas.h >> l, s);
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->weights_dirty = false;
+    return PANO_OK;
+}
+
+// fold the oldest pending event quad into the accumulators (waits for it if the GPU is still behind)
+pano_status harvest_oldest(pano_ctx* c) {
+    if (c->ev_count == 0) return PANO_OK;
+    int idx = (c->ev_head - c->ev_count + pano_ctx::kEvRing) % pano_ctx::kEvRing;
+    pano_ctx::EvSlot& sl = c->ring[idx];
+    for (int k = PANO_NUM_STAGES; k >= 0; k--)
+        if (sl.recorded & (1u << k)) {
+            HIP_TRY(c, hipEventSynchronize(sl.e[k]));
+            break;
+        }
+    for (int k = 0; k < PANO_NUM_STAGES; k++)
+        if ((sl.recorded & (1u << k)) && (sl.recorded & (1u << (k + 1)))) {
+            float ms = 0.f;
+            HIP_TRY(c, hipEventElapsedTime(&ms, sl.e[k], sl.e[k + 1]));
+            c->acc_ms[k] += ms;
+            c->acc_n[k]++;
+            c->last_ms[k] = ms;
+        }
+    sl.recorded = 0;
+    c->ev_count--;
+    if (c->ev_cur == idx) c->ev_cur = -1;
+    return PANO_OK;
+}
+pano_status begin_slot(pano_ctx* c) {
+    if (c->ev_count == pano_ctx::kEvRing) {
+        pano_status s = harvest_oldest(c);
+        if (s != PANO_OK) return s;
+    }
+    c->ev_cur = c->ev_head;
+    c->ev_head = (c->ev_head + 1) % pano_ctx::kEvRing;
+    c->ev_count++;
+    c->ring[c->ev_cur].recorded = 0;
+    return PANO_OK;
+}
+pano_status record(pano_ctx* c, int k, hipStream_t s) {
+    HIP_TRY(c, hipEventRecord(c->ring[c->ev_cur].e[k], s));
+    c->ring[c->ev_cur].recorded |= 1u << k;
+    return PANO_OK;
+}
+
+pano_status check_compute(pano_ctx* c) {
+    if (!c) return PANO_EINVAL;
+    if (c->device < 0) return fail(c, PANO_ENODEVICE, "plan-only context (config.device < 0): no CPU fallback exists");
+    if (!c->prepared) return fail(c, PANO_ESTATE, "pano_prepare has not run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return PANO_OK;
+}
+
+bool parse_floats(const std::string& s, std::vector<float>& out) {
+    std::stringstream ss(s);
+    std::string tok;
+    while (std::getline(ss, tok, ',')) {
+        size_t b = tok.find_first_not_of(" \t\r\n");
+        if (b == std::string::npos) continue;
+        char* end = nullptr;
+        float v = strtof(tok.c_str() + b, &end);
+        if (end == tok.c_str() + b) return false;
+        out.push_back(v);
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pano_version(void) { return "pano-hip 0.1 (gfx950)"; }
+
+const char* pano_last_error(const pano_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+pano_status pano_create(const pano_config* cfg, pano_ctx** out) {
+    if (!cfg || !out) return PANO_EINVAL;
+    *out = nullptr;
+    if (cfg->num_images < 1 || cfg->num_images > PANO_MAX_CAMS || cfg->width < 2 || cfg->height < 2) return PANO_EINVAL;
+    if (cfg->projector != PANO_SPHERICAL && cfg->projector != PANO_CYLINDRICAL) return PANO_EINVAL;
+    if (cfg->num_bands > PANO_MAX_BANDS || cfg->num_bands < PANO_BANDS_FROM_STRENGTH) return PANO_EINVAL;
+    pano_ctx* c = new (std::nothrow) pano_ctx();
+    if (!c) return PANO_ENOMEM;
+    c->cfg = *cfg;
+    c->scale = cfg->warped_image_scale;
+    c->device = cfg->device;
+    if (c->device >= 0) {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || c->device >= ndev) {
+            // fail loudly: there is no CPU path
+            delete c;
+            return PANO_EHIP;
+        }
+    }
+    *out = c;
+    return PANO_OK;
+}
+
+void pano_destroy(pano_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->device >= 0 && ctx->prepared) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
+        free_device(ctx);
+    }
+    delete ctx;
+}
+
+pano_status pano_set_camera(pano_ctx* c, int i, const float K[9], const float R[9]) {
+    if (!c || !K || !R || i < 0 || i >= c->cfg.num_images) return PANO_EINVAL;
+    if (c->prepared) return fail(c, PANO_ESTATE, "cameras are fixed after pano_prepare");
+    if (!(K[0] > 0.f) || !(K[4] > 0.f)) return fail(c, PANO_EINVAL, "focal length must be positive");
+    std::memcpy(c->K[i], K, 9 * sizeof(float));
+    std::memcpy(c->R[i], R, 9 * sizeof(float));
+    c->have_cam[i] = true;
+    return PANO_OK;
+}
+
+pano_status pano_set_cameras_from_list(pano_ctx* c, const char* list) {
+    if (!c || !list) return PANO_EINVAL;
+    std::vector<float> v;
+    if (!parse_floats(list, v)) return fail(c, PANO_ERR, "camera list: not a number");
+    const int n = c->cfg.num_images;
+    if ((int)v.size() != 18 * n + 1) return fail(c, PANO_ERR, "camera list: expected 18*num_images+1 values");
+    for (int i = 0; i < n; i++) {
+        pano_status s = pano_set_camera(c, i, &v[18 * i], &v[18 * i + 9]);
+        if (s != PANO_OK) return s;
+    }
+    c->scale = v.back();
+    c->cfg.warped_image_scale = c->scale;
+    return PANO_OK;
+}
+
+pano_status pano_load_camera_file(pano_ctx* c, const char* path) {
+    if (!c || !path) return PANO_EINVAL;
+    std::ifstream fin(path);
+    if (!fin.is_open()) return fail(c, PANO_ERR, "cannot open camera parameter file");
+    std::vector<std::string> lines;
+    std::string l;
+    while (std::getline(fin, l)) {
+        while (!l.empty() && (l.back() == '\r' || l.back() == ' ')) l.pop_back();
+        if (!l.empty()) lines.push_back(l);
+    }
+    int last = -1;
+    for (int i = 0; i < (int)lines.size(); i++)
+        if (lines[i].find(':') != std::string::npos) last = i;
+    if (last < 0) return fail(c, PANO_ERR, "no record in camera parameter file");
+    const int n = c->cfg.num_images;
+    std::vector<std::vector<float>> rec;
+    for (int i = last + 1; i < (int)lines.size(); i++) {
+        std::vector<float> v;
+        if (!parse_floats(lines[i], v)) return fail(c, PANO_ERR, "camera parameter file: not a number");
+        rec.push_back(v);
+    }
+    if (rec.empty()) return fail(c, PANO_ERR, "camera parameter file: truncated record");
+    if (rec[0].size() == 18) {  // format written by saveCameraParams (ocvstitcher.hpp:522-562)
+        if ((int)rec.size() < n + 1 || rec[n].size() != 1) return fail(c, PANO_ERR, "camera parameter file: record shape");
+        for (int i = 0; i < n; i++) {
+            if (rec[i].size() != 18) return fail(c, PANO_ERR, "camera parameter file: record shape");
+            pano_status s = pano_set_camera(c, i, &rec[i][0], &rec[i][9]);
+            if (s != PANO_OK) return s;
+        }
+        c->scale = rec[n][0];
+    } else if (rec[0].size() == 9) {  // older shared-K format of 2222/cameraparaout_*.txt
+        if ((int)rec.size() < n + 2 || rec[n + 1].size() != 1) return fail(c, PANO_ERR, "camera parameter file: record shape");
+        for (int i = 0; i < n; i++) {
+            if (rec[i + 1].size() != 9) return fail(c, PANO_ERR, "camera parameter file: record shape");
+            pano_status s = pano_set_camera(c, i, &rec[0][0], &rec[i + 1][0]);
+            if (s != PANO_OK) return s;
+        }
+        c->scale = rec[n + 1][0];
+    } else {
+        return fail(c, PANO_ERR, "camera parameter file: record shape");
+    }
+    c->cfg.warped_image_scale = c->scale;
+    return PANO_OK;
+}
+
+pano_status pano_prepare(pano_ctx* c) {
+    if (!c) return PANO_EINVAL;
+    if (c->prepared) return fail(c, PANO_ESTATE, "already prepared");
+    const int n = c->cfg.num_images;
+    if (!(c->scale > 0.f)) return fail(c, PANO_EINVAL, "warped_image_scale must be positive");
+    Plan& P = c->plan;
+    P.n = n;
+    P.src_w = c->cfg.width;
+    P.src_h = c->cfg.height;
+    for (int i = 0; i < n; i++) {
+        if (!c->have_cam[i]) return fail(c, PANO_ESTATE, "camera parameters missing");
+        P.proj[i].set(c->cfg.projector, c->scale, c->K[i], c->R[i]);
+        P.roi[i] = warpRoi(P.proj[i], P.src_w, P.src_h);
+        // a camera whose ROI spans the whole u range straddles the +-pi seam (reference README.md:27-29)
+        if (P.roi[i].w >= (int)(2.0 * M_PI * c->scale) - 1 || P.roi[i].w <= 0 || P.roi[i].h <= 0)
+            return fail(c, PANO_EWRAP, "camera ROI wraps the projection seam; split the ring into groups");
+    }
+    Rect pano_rect = resultRoi(P.roi, n);
+    int req = c->cfg.num_bands;
+    if (req == PANO_BANDS_FROM_STRENGTH) req = bandsFromStrength(pano_rect.w, pano_rect.h, c->cfg.blend_strength);
+    if (req < 0) req = -1;
+    if (!makePlan(P, req)) return fail(c, PANO_EINVAL, "too many bands");
+    P.cut = Rect{c->cfg.cut[0], c->cfg.cut[1], c->cfg.cut[2], c->cfg.cut[3]};
+    if (P.cut.w == 0 || P.cut.h == 0) P.cut = Rect{0, 0, P.pano.w, P.pano.h};
+    if (P.cut.x < 0 || P.cut.y < 0 || P.cut.w < 0 || P.cut.h < 0 || P.cut.x + P.cut.w > P.pano.w ||
+        P.cut.y + P.cut.h > P.pano.h)
+        return fail(c, PANO_EINVAL, "cut rectangle outside the panorama");
+    c->levels = P.bands < 0 ? 1 : P.bands + 1;
+    c->prepared = true;
+    if (c->device < 0) return PANO_OK;  // plan-only
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    // pyramid slots: every level of one camera contiguous, every camera the same slot size
+    size_t slot = 0;
+    for (int i = 0; i < n; i++) {
+        size_t off = 0;
+        for (int l = 0; l < c->levels; l++) {
+            int w = P.tile[i].rect.w >> l, h = P.tile[i].rect.h >> l;
+            c->lvl_pitch[i][l] = (int)align_up((size_t)w, 8);
+            c->lvl_off[i][l] = off;
+            off += align_up((size_t)c->lvl_pitch[i][l] * h * 6, 256);
+        }
+        slot = std::max(slot, off);
+    }
+    c->slot_bytes = align_up(slot, 4096);
+    HIP_TRY(c, hipMalloc((void**)&c->pyr_base, c->slot_bytes * n));
+    HIP_TRY(c, hipMemset(c->pyr_base, 0, c->slot_bytes * n));
+    std::vector<float> a, b;
+    for (int i = 0; i < n; i++) {
+        const FeedTile& t = P.tile[i];
+        pano_status s;
+        trigTables(P.proj[i], P.roi[i], t.left, t.top, t.rect.w, t.rect.h, a, b);
+        if ((s = upload(c, &c->colA[i], a.data(), a.size() * sizeof(float)))) return s;
+        if ((s = upload(c, &c->rowB[i], b.data(), b.size() * sizeof(float)))) return s;
+        trigTables(P.proj[i], P.roi[i], 0, 0, P.roi[i].w, P.roi[i].h, a, b);
+        if ((s = upload(c, &c->colA_roi[i], a.data(), a.size() * sizeof(float)))) return s;
+        if ((s = upload(c, &c->rowB_roi[i], b.data(), b.size() * sizeof(float)))) return s;
+        HIP_TRY(c, hipMalloc((void**)&c->mask[i], (size_t)P.roi[i].w * P.roi[i].h));
+        if (P.bands >= 0)
+            for (int l = 0; l < c->levels; l++)
+                HIP_TRY(c, hipMalloc((void**)&c->wgt[i][l], (size_t)c->lvl_pitch[i][l] * (t.rect.h >> l) * sizeof(float)));
+    }
+    if (P.bands >= 0)
+        for (int l = 0; l < c->levels; l++) {
+            size_t px = (size_t)(P.canvas.w >> l) * (P.canvas.h >> l);
+            HIP_TRY(c, hipMalloc((void**)&c->wsum[l], px * sizeof(float)));
+            if (l > 0) HIP_TRY(c, hipMalloc((void**)&c->canvas[l], px * 6));
+        }
+    // kernel parameter blocks
+    c->pyr = PyrParams{};
+    c->pyr.ncam = n;
+    for (int i = 0; i < n; i++) {
+        PyrCam& pc = c->pyr.cam[i];
+        pc.w0 = P.tile[i].rect.w; pc.h0 = P.tile[i].rect.h;
+        pc.tx = P.tile[i].rect.x; pc.ty = P.tile[i].rect.y;
+        for (int l = 0; l < c->levels; l++) {
+            pc.lvl[l] = (int16_t*)(c->pyr_base + (size_t)i * c->slot_bytes + c->lvl_off[i][l]);
+            pc.wgt[l] = c->wgt[i][l];
+            pc.pitch[l] = c->lvl_pitch[i][l];
+        }
+    }
+    c->cv = CanvasParams{};
+    for (int l = 0; l < c->levels; l++) {
+        c->cv.img[l] = c->canvas[l];
+        c->cv.wsum[l] = c->wsum[l];
+    }
+    c->cv.w0 = P.canvas.w; c->cv.h0 = P.canvas.h;
+    c->cv.bands = P.bands;
+    c->cv.cut_x = P.cut.x; c->cv.cut_y = P.cut.y; c->cv.cut_w = P.cut.w; c->cv.cut_h = P.cut.h;
+    c->cv.final_w = P.pano.w; c->cv.final_h = P.pano.h;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    for (auto& sl : c->ring)
+        for (auto& e : sl.e) HIP_TRY(c, hipEventCreate(&e));
+    c->ev_valid = true;
+    return PANO_OK;
+}
+
+pano_status pano_get_roi(const pano_ctx* c, int i, int r[4]) {
+    if (!c || !r || !c->prepared || i < 0 || i >= c->plan.n) return PANO_EINVAL;
+    r[0] = c->plan.roi[i].x; r[1] = c->plan.roi[i].y; r[2] = c->plan.roi[i].w; r[3] = c->plan.roi[i].h;
+    return PANO_OK;
+}
+
+pano_status pano_get_pano_rect(const pano_ctx* c, int r[4]) {
+    if (!c || !r || !c->prepared) return PANO_EINVAL;
+    r[0] = c->plan.pano.x; r[1] = c->plan.pano.y; r[2] = c->plan.pano.w; r[3] = c->plan.pano.h;
+    return PANO_OK;
+}
+
+pano_status pano_get_num_bands(const pano_ctx* c, int* nb) {
+    if (!c || !nb || !c->prepared) return PANO_EINVAL;
+    *nb = c->plan.bands;
+    return PANO_OK;
+}
+
+pano_status pano_get_feed_tile(const pano_ctx* c, int i, int r[4], int tblr[4]) {
+    if (!c || !r || !tblr || !c->prepared || i < 0 || i >= c->plan.n) return PANO_EINVAL;
+    const FeedTile& t = c->plan.tile[i];
+    r[0] = t.rect.x; r[1] = t.rect.y; r[2] = t.rect.w; r[3] = t.rect.h;
+    tblr[0] = t.top; tblr[1] = t.bottom; tblr[2] = t.left; tblr[3] = t.right;
+    return PANO_OK;
+}
+
+pano_status pano_set_cut(pano_ctx* c, const int r[4]) {
+    if (!c || !r) return PANO_EINVAL;
+    if (!c->prepared) {
+        std::memcpy(c->cfg.cut, r, 4 * sizeof(int));
+        return PANO_OK;
+    }
+    Rect cut{r[0], r[1], r[2], r[3]};
+    if (cut.w == 0 || cut.h == 0) cut = Rect{0, 0, c->plan.pano.w, c->plan.pano.h};
+    if (cut.x < 0 || cut.y < 0 || cut.w < 0 || cut.h < 0 || cut.x + cut.w > c->plan.pano.w || cut.y + cut.h > c->plan.pano.h)
+        return fail(c, PANO_EINVAL, "cut rectangle outside the panorama");
+    c->plan.cut = cut;
+    c->cv.cut_x = cut.x; c->cv.cut_y = cut.y; c->cv.cut_w = cut.w; c->cv.cut_h = cut.h;
+    return PANO_OK;
+}
+
+pano_status pano_get_output_size(const pano_ctx* c, int* w, int* h) {
+    if (!c || !w || !h || !c->prepared) return PANO_EINVAL;
+    *w = c->plan.cut.w;
+    *h = c->plan.cut.h;
+    return PANO_OK;
+}
+
+pano_status pano_set_mask(pano_ctx* c, int i, const uint8_t* h_mask, int w, int h, size_t stride) {
+    pano_status s = check_compute(c);
+    if (s != PANO_OK) return s;
+    if (!h_mask || i < 0 || i >= c->plan.n) return PANO_EINVAL;
+    if (w != c->plan.roi[i].w || h != c->plan.roi[i].h || stride < (size_t)w)
+        return fail(c, PANO_EINVAL, "mask must be ROI sized (pano_get_roi)");
+    HIP_TRY(c, hipMemcpy2D(c->mask[i], (size_t)w, h_mask, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice));
+    c->mask_set[i] = true;
+    c->weights_dirty = true;
+    return PANO_OK;
+}
+
+pano_status pano_get_mask(pano_ctx* c, int i, uint8_t* h_mask, size_t stride) {
+    pano_status s = check_compute(c);
+    if (s != PANO_OK) return s;
+    if (!h_mask || i < 0 || i >= c->plan.n) return PANO_EINVAL;
+    if (!c->mask_set[i]) return fail(c, PANO_ESTATE, "mask not set");
+    int w = c->plan.roi[i].w, h = c->plan.roi[i].h;
+    if (stride < (size_t)w) return PANO_EINVAL;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy2D(h_mask, stride, c->mask[i], (size_t)w, (size_t)w, (size_t)h, hipMemcpyDeviceToHost));
+    return PANO_OK;
+}
+
+pano_status pano_build_masks_voronoi(pano_ctx* c) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    const Plan& P = c->plan;
+    const int n = P.n, sw = P.src_w, sh = P.src_h;
+    hipStream_t s = c->own_stream;
+    // seam scale (ocvstitcher.hpp:298, :988-1017)
+    double swa = std::min(1.0, std::sqrt(1e5 / ((double)sh * sw)));
+    int ssw = (int)std::lrint(sw * swa), ssh = (int)std::lrint(sh * swa);
+    float seam_scale = static_cast<float>(c->scale * swa);
+    float swa_f = (float)swa;
+    std::vector<Rect> sroi(n);
+    std::vector<uint8_t*> smask(n, nullptr);
+    std::vector<void*> to_free;
+    auto cleanup = [&]() {
+        for (void* p : to_free) (void)hipFree(p);
+    };
+    std::vector<float> a, b;
+    for (int i = 0; i < n; i++) {
+        float K[9];
+        std::memcpy(K, c->K[i], sizeof(K));
+        K[0] *= swa_f; K[2] *= swa_f; K[4] *= swa_f; K[5] *= swa_f;
+        Projector pj;
+        pj.set(c->cfg.projector, seam_scale, K, c->R[i]);
+        sroi[i] = warpRoi(pj, ssw, ssh);
+        trigTables(pj, sroi[i], 0, 0, sroi[i].w, sroi[i].h, a, b);
+        float2 *dA = nullptr, *dB = nullptr;
+        pano_status u;
+        if ((u = upload(c, &dA, a.data(), a.size() * sizeof(float)))) { cleanup(); return u; }
+        to_free.push_back(dA);
+        if ((u = upload(c, &dB, b.data(), b.size() * sizeof(float)))) { cleanup(); return u; }
+        to_free.push_back(dB);
+        if (hipMalloc((void**)&smask[i], (size_t)sroi[i].w * sroi[i].h) != hipSuccess) { cleanup(); return fail(c, PANO_EHIP, "hipMalloc"); }
+        to_free.push_back(smask[i]);
+        WarpCam w{};
+        w.src_w = ssw; w.src_h = ssh;
+        std::memcpy(w.m, pj.k_rinv, sizeof(w.m));
+        w.colA = dA; w.rowB = dB; w.tw = sroi[i].w; w.th = sroi[i].h;
+        launch_warp_mask(w, smask[i], sroi[i].w, s);
+    }
+    // PairwiseSeamFinder::run order
+    for (int i = 0; i < n - 1; i++)
+        for (int j = i + 1; j < n; j++) {
+            int x_tl = std::max(sroi[i].x, sroi[j].x), y_tl = std::max(sroi[i].y, sroi[j].y);
+            int x_br = std::min(sroi[i].x + sroi[i].w, sroi[j].x + sroi[j].w);
+            int y_br = std::min(sroi[i].y + sroi[i].h, sroi[j].y + sroi[j].h);
+            if (!(x_tl < x_br && y_tl < y_br)) continue;
+            int* scratch = nullptr;
+            if (hipMalloc((void**)&scratch, voronoi_scratch_ints(x_br - x_tl, y_br - y_tl) * sizeof(int)) != hipSuccess) {
+                cleanup();
+                return fail(c, PANO_EHIP, "hipMalloc");
+            }
+            to_free.push_back(scratch);
+            launch_voronoi_pair(smask[i], sroi[i].w, sroi[i].h, sroi[i].x, sroi[i].y, smask[j], sroi[j].w, sroi[j].h,
+                                sroi[j].x, sroi[j].y, x_tl, y_tl, x_br - x_tl, y_br - y_tl, scratch, s);
+        }
+    // full-size: warp mask, dilate seam mask, resize, and (ocvstitcher.hpp:1085, :1097-1101)
+    for (int i = 0; i < n; i++) {
+        const Rect& r = P.roi[i];
+        uint8_t *full = nullptr, *dil = nullptr, *seam = nullptr;
+        if (hipMalloc((void**)&full, (size_t)r.w * r.h) != hipSuccess) { cleanup(); return fail(c, PANO_EHIP, "hipMalloc"); }
+        to_free.push_back(full);
+        if (hipMalloc((void**)&dil, (size_t)sroi[i].w * sroi[i].h) != hipSuccess) { cleanup(); return fail(c, PANO_EHIP, "hipMalloc"); }
+        to_free.push_back(dil);
+        if (hipMalloc((void**)&seam, (size_t)r.w * r.h) != hipSuccess) { cleanup(); return fail(c, PANO_EHIP, "hipMalloc"); }
+        to_free.push_back(seam);
+        WarpCam w = make_warp_cam(c, i, nullptr, 0, true);
+        launch_warp_mask(w, full, r.w, s);
+        launch_dilate3x3(smask[i], dil, sroi[i].w, sroi[i].h, s);
+        // INTER_LINEAR_EXACT coefficient tables (resize.cpp interpolationLinear<uchar>::getCoeffs), IEEE double
+        auto coeffs = [&](int ssize, int dsize, std::vector<int>& ofs, std::vector<int>& c1, int& mn, int& mx) {
+            double scale = 1.0 / ((double)dsize / ssize);
+            ofs.assign(dsize, 0);
+            c1.assign(dsize, 0);
+            mn = 0;
+            mx = dsize;
+            for (int v = 0; v < dsize; v++) {
+                double fval = scale * ((double)v + 0.5) - 0.5;
+                int ival = (int)std::floor(fval);
+                if (ival >= 0 && ssize > 1) {
+                    if (ival < ssize - 1) {
+                        ofs[v] = ival;
+                        c1[v] = (int)std::lrint((fval - (double)ival) * 256.0);
+                    } else {
+                        ofs[v] = ssize - 1;
+                        mx = std::min(mx, v);
+                    }
+                } else {
+                    mn = std::max(mn, v + 1);
+                }
+            }
+            if (mx < mn) mx = mn;
+        };
+        std::vector<int> xo, xc, yo, yc;
+        int mnx, mxx, mny, mxy;
+        coeffs(sroi[i].w, r.w, xo, xc, mnx, mxx);
+        coeffs(sroi[i].h, r.h, yo, yc, mny, mxy);
+        int *dxo = nullptr, *dxc = nullptr, *dyo = nullptr, *dyc = nullptr;
+        pano_status u;
+        if ((u = upload(c, &dxo, xo.data(), xo.size() * sizeof(int)))) { cleanup(); return u; }
+        to_free.push_back(dxo);
+        if ((u = upload(c, &dxc, xc.data(), xc.size() * sizeof(int)))) { cleanup(); return u; }
+        to_free.push_back(dxc);
+        if ((u = upload(c, &dyo, yo.data(), yo.size() * sizeof(int)))) { cleanup(); return u; }
+        to_free.push_back(dyo);
+        if ((u = upload(c, &dyc, yc.data(), yc.size() * sizeof(int)))) { cleanup(); return u; }
+        to_free.push_back(dyc);
+        launch_resize_linear_exact(dil, sroi[i].w, sroi[i].h, seam, r.w, r.h, dxo, dxc, dyo, dyc, mnx, mxx, mny, mxy, s);
+        launch_and(seam, full, c->mask[i], (size_t)r.w * r.h, s);
+        c->mask_set[i] = true;
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) return fail(c, PANO_EHIP, hipGetErrorString(e));
+    HIP_TRY(c, hipGetLastError());
+    c->weights_dirty = true;
+    return PANO_OK;
+}
+
+pano_status pano_set_gain_map(pano_ctx* c, int i, const float* h_gain, int gw, int gh) {
+    pano_status s = check_compute(c);
+    if (s != PANO_OK) return s;
+    if (i < 0 || i >= c->plan.n) return PANO_EINVAL;
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (!h_gain) {
+        dfree(c->gain[i]);
+        return PANO_OK;
+    }
+    if (gw < 1 || gh < 1) return PANO_EINVAL;
+    c->gain_w[i] = gw;
+    c->gain_h[i] = gh;
+    if ((s = upload(c, &c->gain[i], h_gain, (size_t)gw * gh * sizeof(float)))) return s;
+    return upload_gain_tables(c, i);
+}
+
+pano_status pano_warp(pano_ctx* c, int i, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, size_t dst_stride,
+                      void* stream) {
+    pano_status s = check_compute(c);
+    if (s != PANO_OK) return s;
+    if (!d_src || !d_dst || i < 0 || i >= c->plan.n) return PANO_EINVAL;
+    if (src_stride < (size_t)c->plan.src_w * 3 || dst_stride < (size_t)c->plan.roi[i].w * 3) return PANO_EINVAL;
+    WarpCam w = make_warp_cam(c, i, d_src, src_stride, true);
+    w.dst = d_dst;
+    w.dst_pitch = (int)dst_stride;
+    launch_warp_image(w, (hipStream_t)stream);
+    HIP_TRY(c, hipGetLastError());
+    return PANO_OK;
+}
+
+pano_status pano_warp_mask(pano_ctx* c, int i, uint8_t* d_dst, size_t dst_stride, void* stream) {
+    pano_status s = check_compute(c);
+    if (s != PANO_OK) return s;
+    if (!d_dst || i < 0 || i >= c->plan.n || dst_stride < (size_t)c->plan.roi[i].w) return PANO_EINVAL;
+    WarpCam w = make_warp_cam(c, i, nullptr, 0, true);
+    launch_warp_mask(w, d_dst, (int)dst_stride, (hipStream_t)stream);
+    HIP_TRY(c, hipGetLastError());
+    return PANO_OK;
+}
+
+pano_status pano_feed_cameras(pano_ctx* c, unsigned cam_bits, const uint8_t* const* d_frames, const size_t* strides,
+                              void* stream) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (!d_frames || !strides) return PANO_EINVAL;
+    const Plan& P = c->plan;
+    hipStream_t s = (hipStream_t)stream;
+    cam_bits &= (1u << P.n) - 1u;
+    WarpParams wp{};
+    int k = 0, mw = 0, mh = 0;
+    for (int i = 0; i < P.n; i++) {
+        if (!((cam_bits >> i) & 1u)) continue;
+        if (!d_frames[i] || strides[i] < (size_t)P.src_w * 3) return fail(c, PANO_EINVAL, "frame pointer / stride");
+        wp.cam[k++] = make_warp_cam(c, i, d_frames[i], strides[i], false);
+        mw = std::max(mw, P.tile[i].rect.w);
+        mh = std::max(mh, P.tile[i].rect.h);
+    }
+    if (k == 0) return PANO_OK;
+    if (c->profiling) {
+        if ((st = begin_slot(c)) != PANO_OK) return st;
+        if ((st = record(c, 0, s)) != PANO_OK) return st;
+    }
+    launch_warp_tiles(wp, k, mw, mh, s);
+    if (c->profiling && (st = record(c, 1, s)) != PANO_OK) return st;
+    for (int l = 0; l < P.bands; l++) launch_pyr_down(c->pyr, cam_bits, l, s);
+    if (c->profiling && (st = record(c, 2, s)) != PANO_OK) return st;
+    HIP_TRY(c, hipGetLastError());
+    return PANO_OK;
+}
+
+pano_status pano_blend(pano_ctx* c, uint8_t* d_out, size_t out_stride, void* stream) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    const Plan& P = c->plan;
+    if (!d_out || out_stride < (size_t)P.cut.w * 3) return PANO_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if ((st = ensure_weights(c, s)) != PANO_OK) return st;
+    CanvasParams cv = c->cv;
+    cv.out = d_out;
+    cv.out_stride = (int)out_stride;
+    if (P.bands < 0) {
+        const uint8_t* masks[kMaxCams];
+        int mp[kMaxCams], rx[kMaxCams], ry[kMaxCams], rw[kMaxCams], rh[kMaxCams];
+        for (int i = 0; i < P.n; i++) {
+            masks[i] = c->mask[i];
+            mp[i] = P.roi[i].w;
+            rx[i] = P.roi[i].x - P.pano.x; ry[i] = P.roi[i].y - P.pano.y;
+            rw[i] = P.roi[i].w; rh[i] = P.roi[i].h;
+        }
+        launch_no_blend(c->pyr, masks, mp, rx, ry, rw, rh, cv, s);
+    } else {
+        for (int l = P.bands; l >= 0; l--) launch_blend_level(c->pyr, cv, l, s);
+    }
+    if (c->profiling) {
+        if (c->ev_cur < 0 && (st = begin_slot(c)) != PANO_OK) return st;
+        if ((st = record(c, 3, s)) != PANO_OK) return st;
+        c->ev_cur = -1;  // frame closed
+    }
+    HIP_TRY(c, hipGetLastError());
+    return PANO_OK;
+}
+
+pano_status pano_compose(pano_ctx* c, const uint8_t* const* d_frames, const size_t* strides, uint8_t* d_out,
+                         size_t out_stride, void* stream) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    // weights first so that the profiled stages hold only per-frame work
+    if ((st = ensure_weights(c, (hipStream_t)stream)) != PANO_OK) return st;
+    if ((st = pano_feed_cameras(c, (1u << c->plan.n) - 1u, d_frames, strides, stream)) != PANO_OK) return st;
+    return pano_blend(c, d_out, out_stride, stream);
+}
+
+pano_status pano_compose_host(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides, uint8_t* h_out,
+                              size_t out_stride) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (!h_frames || !strides || !h_out) return PANO_EINVAL;
+    const Plan& P = c->plan;
+    const size_t in_pitch = align_up((size_t)P.src_w * 3, 256), out_pitch = align_up((size_t)P.cut.w * 3, 256);
+    if (!c->stage_out || c->stage_in_pitch != in_pitch || c->stage_out_pitch != out_pitch) {
+        for (int i = 0; i < P.n; i++) {
+            dfree(c->stage_in[i]);
+            HIP_TRY(c, hipMalloc((void**)&c->stage_in[i], in_pitch * P.src_h + 64));
+        }
+        dfree(c->stage_out);
+        HIP_TRY(c, hipMalloc((void**)&c->stage_out, out_pitch * P.cut.h));
+        c->stage_in_pitch = in_pitch;
+        c->stage_out_pitch = out_pitch;
+    }
+    hipStream_t s = c->own_stream;
+    const uint8_t* frames[kMaxCams];
+    size_t pitches[kMaxCams];
+    for (int i = 0; i < P.n; i++) {
+        if (!h_frames[i] || strides[i] < (size_t)P.src_w * 3) return PANO_EINVAL;
+        HIP_TRY(c, hipMemcpy2DAsync(c->stage_in[i], in_pitch, h_frames[i], strides[i], (size_t)P.src_w * 3, P.src_h,
+                                    hipMemcpyHostToDevice, s));
+        frames[i] = c->stage_in[i];
+        pitches[i] = in_pitch;
+    }
+    if ((st = pano_compose(c, frames, pitches, c->stage_out, out_pitch, s)) != PANO_OK) return st;
+    HIP_TRY(c, hipMemcpy2DAsync(h_out, out_stride, c->stage_out, out_pitch, (size_t)P.cut.w * 3, P.cut.h,
+                                hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return PANO_OK;
+}
+
+pano_status pano_get_pyramid_slots(pano_ctx* c, void** d_base, size_t* slot_bytes) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (!d_base || !slot_bytes) return PANO_EINVAL;
+    *d_base = c->pyr_base;
+    *slot_bytes = c->slot_bytes;
+    return PANO_OK;
+}
+
+pano_status pano_set_profiling(pano_ctx* c, int enabled) {
+    if (!c) return PANO_EINVAL;
+    c->profiling = enabled != 0;
+    return PANO_OK;
+}
+
+pano_status pano_get_stage_ms(pano_ctx* c, float ms[PANO_NUM_STAGES]) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (!ms || !c->profiling) return fail(c, PANO_ESTATE, "profiling is off");
+    while (c->ev_count > 0)
+        if ((st = harvest_oldest(c)) != PANO_OK) return st;
+    for (int k = 0; k < PANO_NUM_STAGES; k++) ms[k] = c->last_ms[k];
+    return PANO_OK;
+}
+
+pano_status pano_get_stage_stats(pano_ctx* c, double total_ms[PANO_NUM_STAGES], uint64_t launches[PANO_NUM_STAGES],
+                                 int reset) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (!total_ms || !launches) return PANO_EINVAL;
+    while (c->ev_count > 0)
+        if ((st = harvest_oldest(c)) != PANO_OK) return st;
+    for (int k = 0; k < PANO_NUM_STAGES; k++) {
+        total_ms[k] = c->acc_ms[k];
+        launches[k] = c->acc_n[k];
+        if (reset) {
+            c->acc_ms[k] = 0;
+            c->acc_n[k] = 0;
+        }
+    }
+    return PANO_OK;
+}
+
+pano_status pano_get_warp_bytes(const pano_ctx* c, uint64_t* src_bytes, uint64_t* dst_bytes) {
+    if (!c || !c->prepared || !src_bytes || !dst_bytes) return PANO_EINVAL;
+    uint64_t s = 0, d = 0;
+    for (int i = 0; i < c->plan.n; i++) {
+        s += (uint64_t)c->plan.src_w * c->plan.src_h * 3;
+        d += (uint64_t)c->plan.tile[i].rect.w * c->plan.tile[i].rect.h * 6;
+    }
+    *src_bytes = s;
+    *dst_bytes = d;
+    return PANO_OK;
+}
+
+pano_status pano_debug_get_level(pano_ctx* c, int i, int level, int16_t* h_dst, int* w, int* h) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (i < 0 || i >= c->plan.n || level < 0 || level >= c->levels || !w || !h) return PANO_EINVAL;
+    *w = c->plan.tile[i].rect.w >> level;
+    *h = c->plan.tile[i].rect.h >> level;
+    if (!h_dst) return PANO_OK;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy2D(h_dst, (size_t)*w * 6, c->pyr.cam[i].lvl[level], (size_t)c->lvl_pitch[i][level] * 6,
+                           (size_t)*w * 6, (size_t)*h, hipMemcpyDeviceToHost));
+    return PANO_OK;
+}
+
+pano_status pano_debug_get_weights(pano_ctx* c, int i, int level, float* h_dst, int* w, int* h) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (i < 0 || i >= c->plan.n || level < 0 || level >= c->levels || !w || !h || c->plan.bands < 0) return PANO_EINVAL;
+    *w = c->plan.tile[i].rect.w >> level;
+    *h = c->plan.tile[i].rect.h >> level;
+    if (!h_dst) return PANO_OK;
+    if ((st = ensure_weights(c, c->own_stream)) != PANO_OK) return st;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy2D(h_dst, (size_t)*w * 4, c->wgt[i][level], (size_t)c->lvl_pitch[i][level] * 4, (size_t)*w * 4,
+                           (size_t)*h, hipMemcpyDeviceToHost));
+    return PANO_OK;
+}
+
+pano_status pano_debug_get_canvas_weights(pano_ctx* c, int level, float* h_dst, int* w, int* h) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (level < 0 || level >= c->levels || !w || !h || c->plan.bands < 0) return PANO_EINVAL;
+    *w = c->plan.canvas.w >> level;
+    *h = c->plan.canvas.h >> level;
+    if (!h_dst) return PANO_OK;
+    if ((st = ensure_weights(c, c->own_stream)) != PANO_OK) return st;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(h_dst, c->wsum[level], (size_t)*w * *h * 4, hipMemcpyDeviceToHost));
+    return PANO_OK;
+}
+
+pano_status pano_debug_get_canvas(pano_ctx* c, int level, int16_t* h_dst, int* w, int* h) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    // level 0 is written straight to the 8U panorama and never materialised
+    if (level < 1 || level >= c->levels || !w || !h || c->plan.bands < 0) return PANO_EINVAL;
+    *w = c->plan.canvas.w >> level;
+    *h = c->plan.canvas.h >> level;
+    if (!h_dst) return PANO_OK;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(h_dst, c->canvas[level], (size_t)*w * *h * 6, hipMemcpyDeviceToHost));
+    return PANO_OK;
+}
+
+}  // extern "C"

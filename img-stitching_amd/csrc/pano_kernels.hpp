@@ -1,0 +1,96 @@
+// pano_kernels.hpp - launch interface between the C-ABI host code (pano_api.cpp) and the gfx950
+// kernels (pano_kernels.hip).  Plain structs passed by value as kernel arguments.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pano {
+
+constexpr int kCams = 8;
+constexpr int kLevels = 9;
+
+// one camera's slice of the fused warp launch (K1)
+struct WarpCam {
+    const uint8_t* src;   // BGR8 interleaved frame
+    int src_w, src_h;
+    int src_stride;       // bytes
+    float m[9];           // k_rinv = K * R^-1 (Projector::k_rinv)
+    const float2* colA;   // [tw] {sin(u/s), cos(u/s)} with the REFLECT border of feed() folded in
+    const float2* rowB;   // [th] {sin(pi - v/s) | 1, cos(pi - v/s) | v/s}
+    void* dst;            // int16x3 level-0 tile (pipeline) or uint8x3 image (stage warp)
+    int tw, th;           // tile width/height in pixels
+    int dst_pitch;        // pipeline: pixels per row; stage warp: bytes per row
+    // optional exposure gain (BlocksGainCompensator::apply): bilinear resize of a block map on the fly
+    const float* gain;    // [gh][gw] block gains or nullptr
+    const int2* gcol;     // [tw] {sx, sx1}   (REFLECT folded like colA)
+    const float2* gcolw;  // [tw] {1-fx, fx}
+    const int2* grow;     // [th] {sy0, sy1}
+    const float2* groww;  // [th] {1-fy, fy}
+    int gw;
+};
+struct WarpParams {
+    WarpCam cam[kCams];
+};
+
+// one camera's pyramid slot
+struct PyrCam {
+    int16_t* lvl[kLevels];     // Gaussian levels, int16x3 interleaved
+    const float* wgt[kLevels]; // weight levels f32 (level 0 included)
+    int w0, h0;                // level-0 tile size (multiples of 2^bands)
+    int pitch[kLevels];        // pixels per row of each level
+    int tx, ty;                // tile origin in the padded canvas (level 0)
+};
+struct PyrParams {
+    PyrCam cam[kCams];
+    int ncam;
+};
+
+struct CanvasParams {
+    int16_t* img[kLevels];     // collapsed canvas levels (level 0 is never materialised)
+    const float* wsum[kLevels];// summed weights per level
+    int w0, h0;                // padded canvas size
+    int bands;
+    // final output
+    uint8_t* out;
+    int out_stride;            // bytes
+    int cut_x, cut_y, cut_w, cut_h;  // in padded-canvas coordinates (pano rect origin == canvas origin)
+    int final_w, final_h;      // dst_roi_final size (unpadded)
+};
+
+// K1: fused REFLECT border + mapBackward + fixed-point bilinear remap + 8U->16S
+void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hipStream_t s);
+// stage entry: plain RotationWarper::warp to an 8UC3 image
+void launch_warp_image(const WarpCam& c, hipStream_t s);
+// RotationWarper::warp(mask255, INTER_NEAREST, BORDER_CONSTANT)
+void launch_warp_mask(const WarpCam& c, uint8_t* dst, int dst_stride, hipStream_t s);
+
+// K2: one pyrDown level (16S x3) for the selected cameras: level `l` -> level `l+1`
+void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s);
+// K3: one blend level for the whole canvas (Laplacian, weight, accumulate, normalise, collapse);
+// level 0 writes the cut 8U panorama
+void launch_blend_level(const PyrParams& p, const CanvasParams& c, int l, hipStream_t s);
+// Blender::NO path
+void launch_no_blend(const PyrParams& p, const uint8_t* const* masks, const int* mask_pitch,
+                     const int* roi_x, const int* roi_y, const int* roi_w, const int* roi_h,
+                     const CanvasParams& c, hipStream_t s);
+
+// weights (run when masks change)
+void launch_mask_to_weight(const uint8_t* mask, int mw, int mh, int mpitch, int left, int top,
+                           float* w0, int tw, int th, int pitch, hipStream_t s);
+void launch_pyr_down_f32(const float* src, int sw, int sh, int spitch, float* dst, int dpitch, hipStream_t s);
+void launch_sum_weights(const PyrParams& p, int l, float* wsum, int cw, int ch, hipStream_t s);
+
+// mask preparation (Voronoi)
+void launch_dilate3x3(const uint8_t* src, uint8_t* dst, int w, int h, hipStream_t s);
+void launch_resize_linear_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh,
+                                const int* xofs, const int* xc1, const int* yofs, const int* yc1,
+                                int minx, int maxx, int miny, int maxy, hipStream_t s);
+void launch_and(const uint8_t* a, const uint8_t* b, uint8_t* dst, size_t n, hipStream_t s);
+// one VoronoiSeamFinder::findInPair on device masks
+void launch_voronoi_pair(uint8_t* mask1, int w1, int h1, int tlx1, int tly1,
+                         uint8_t* mask2, int w2, int h2, int tlx2, int tly2,
+                         int rx, int ry, int rw, int rh, int* scratch, hipStream_t s);
+size_t voronoi_scratch_ints(int rw, int rh);
+
+}  // namespace pano

@@ -1,0 +1,168 @@
+/*
+ * pano.h - C-ABI of libpano_hip.so: the MI355X (gfx950) implementation of the per-frame
+ * panorama composition path of LeRoii/Img-Stitching.
+ *
+ * Drop-in boundary.  The reference's path is the header-only C++ class `ocvStitcher`
+ * (reference include/ocvstitcher.hpp:254-1306) whose arithmetic lives behind five OpenCV
+ * entry points: RotationWarper::warp / warpRoi, Blender::prepare / feed / blend.  Each entry
+ * point below names the reference interface (file:line under the reference tree) it replaces.
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions, every call returns a pano_status (0 == RET_OK of
+ *     reference include/stitcherglobal.h:13-14; PANO_ERR == RET_ERR == -1).
+ *   - frames are 8-bit BGR interleaved (cv::Mat CV_8UC3), `stride` in bytes.
+ *   - "d_" pointers are device (HBM) pointers, "h_" pointers are host pointers.
+ *   - a ctx is single-caller; distinct ctxs share nothing (no globals, own buffers), so the
+ *     reference's two-stitchers-on-two-threads pattern (src/master.cpp:314-318) needs no lock.
+ *   - there is NO CPU fallback: compute entry points return PANO_ENODEVICE on a plan-only
+ *     ctx (config.device < 0) and PANO_EHIP if the GPU runtime fails.
+ */
+#ifndef PANO_H
+#define PANO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PANO_MAX_CAMS 8
+#define PANO_MAX_BANDS 8
+
+typedef struct pano_ctx pano_ctx;
+
+typedef enum pano_status {
+    PANO_OK = 0,          /* RET_OK  (stitcherglobal.h:13) */
+    PANO_ERR = -1,        /* RET_ERR (stitcherglobal.h:14) */
+    PANO_EINVAL = -2,     /* bad argument */
+    PANO_ESTATE = -3,     /* call order (e.g. compose before prepare / masks) */
+    PANO_EHIP = -4,       /* HIP runtime error, see pano_last_error() */
+    PANO_ENODEVICE = -5,  /* compute call on a plan-only ctx */
+    PANO_EWRAP = -6,      /* a camera's ROI straddles the +-pi seam of the projection (reference README.md:27-29) */
+    PANO_ENOMEM = -7
+} pano_status;
+
+enum { PANO_SPHERICAL = 0, PANO_CYLINDRICAL = 1 };   /* cv::SphericalWarper / cv::CylindricalWarper */
+enum { PANO_BANDS_NO_BLEND = -1,                      /* Blender::NO (ocvstitcher.hpp:1190-1191) */
+       PANO_BANDS_FROM_STRENGTH = -2 };               /* band rule of ocvstitcher.hpp:1188-1195 */
+
+/* Mirrors stStitcherCfg (reference include/stitcherglobal.h:68-81) plus what ocvStitcher::init(yaml)
+ * reads for the compose path (ocvstitcher.hpp:276-289): size, num_images, blendStrength, cut. */
+typedef struct pano_config {
+    int num_images;            /* stStitcherCfg.num_images, 1..PANO_MAX_CAMS */
+    int width, height;         /* stStitcherCfg.width/height = yaml outPutWidth/outPutHeight */
+    int projector;             /* PANO_SPHERICAL (reference default, ocvstitcher.hpp:1000) | PANO_CYLINDRICAL */
+    float warped_image_scale;  /* ocvStitcher::warped_image_scale (last value of the 18N+1 list) */
+    float blend_strength;      /* stStitcherCfg.blendStrength (yaml stitcherBlenderStrength) */
+    int num_bands;             /* >=0 explicit MultiBandBlender::setNumBands; or PANO_BANDS_* */
+    int cut[4];                /* m_cutParams x,y,w,h (cameras.yaml `cut`); w==0 -> whole panorama */
+    int device;                /* HIP device ordinal; <0 = plan-only ctx (host geometry, no GPU) */
+} pano_config;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+/* ocvStitcher::ocvStitcher() + init(yaml) (ocvstitcher.hpp:257, :262-358) */
+pano_status pano_create(const pano_config* cfg, pano_ctx** out);
+void pano_destroy(pano_ctx* ctx);
+const char* pano_last_error(const pano_ctx* ctx);
+const char* pano_version(void);
+
+/* ---- camera parameters ------------------------------------------------------------------ */
+/* camK[i] / cameraR[i], row-major f32 - useDefaultCamParams (ocvstitcher.hpp:423-450),
+ * initCamParams (:452-520) */
+pano_status pano_set_camera(pano_ctx* ctx, int i, const float K[9], const float R[9]);
+/* parse the reference's `18*N+1` comma-separated list (defaultCamParams, ocvstitcher.hpp:423-450;
+ * cameras.yaml `cams:`), sets all N cameras and warped_image_scale */
+pano_status pano_set_cameras_from_list(pano_ctx* ctx, const char* comma_separated_floats);
+/* read the LAST record of a cameraparaout_<id>.txt log (initCamParams, ocvstitcher.hpp:452-520;
+ * old 7-line shared-K format of 2222/cameraparaout_*.txt also accepted) */
+pano_status pano_load_camera_file(pano_ctx* ctx, const char* path);
+
+/* ---- geometry: RotationWarper::warpRoi x N, resultRoi, band rule, Blender::prepare --------
+ * (initSeam compose half, ocvstitcher.hpp:1054-1063, :1107-1121; per-frame :1186-1198).
+ * Allocates every device buffer the ctx will ever use. */
+pano_status pano_prepare(pano_ctx* ctx);
+/* m_corners[i] / m_sizes[i] (ocvstitcher.hpp:1059-1060) */
+pano_status pano_get_roi(const pano_ctx* ctx, int i, int xywh[4]);
+/* resultRoi(m_corners, m_sizes) -> dst_sz (ocvstitcher.hpp:1110); xywh in warp coordinates */
+pano_status pano_get_pano_rect(const pano_ctx* ctx, int xywh[4]);
+/* MultiBandBlender::numBands() after prepare (cropped as blenders.cpp prepare does); -1 = Blender::NO */
+pano_status pano_get_num_bands(const pano_ctx* ctx, int* num_bands);
+/* bordered feed() tile of camera i in padded-canvas coordinates + copyMakeBorder widths
+ * (MultiBandBlender::feed tl_new/br_new, top/bottom/left/right) */
+pano_status pano_get_feed_tile(const pano_ctx* ctx, int i, int xywh[4], int tblr[4]);
+/* m_cutParams (ocvstitcher.hpp:1210) */
+pano_status pano_set_cut(pano_ctx* ctx, const int xywh[4]);
+/* size of the image process() returns (cut applied) */
+pano_status pano_get_output_size(const pano_ctx* ctx, int* w, int* h);
+
+/* ---- blend masks: m_blenderMask[i] (ocvstitcher.hpp:1101, :1257) --------------------------- */
+/* caller-supplied mask of camera i, ROI sized (pano_get_roi), host pointer */
+pano_status pano_set_mask(pano_ctx* ctx, int i, const uint8_t* h_mask, int w, int h, size_t stride);
+/* mask half of initSeam / updateMask (ocvstitcher.hpp:988-1101, :1218-1261) with the reference's
+ * Voronoi seam option (src/stitching_detailed.cpp:728-729) instead of graph cut: seam-scale NEAREST
+ * mask warp, VoronoiSeamFinder, dilate 3x3, resize INTER_LINEAR_EXACT, AND - all on the GPU */
+pano_status pano_build_masks_voronoi(pano_ctx* ctx);
+pano_status pano_get_mask(pano_ctx* ctx, int i, uint8_t* h_mask, size_t stride);
+
+/* ---- exposure: BlocksGainCompensator::apply (src/stitching_detailed.cpp:841) ---------------- */
+/* block gain map of camera i (f32, gw x gh), bilinearly resized to the ROI like apply() does;
+ * NULL removes it */
+pano_status pano_set_gain_map(pano_ctx* ctx, int i, const float* h_gain, int gw, int gh);
+
+/* ---- per-frame path ---------------------------------------------------------------------- */
+/* RotationWarper::warp(img, K, R, INTER_LINEAR, BORDER_REFLECT, dst) (ocvstitcher.hpp:1171):
+ * writes the ROI-sized 8UC3 warped image of camera i.  Stage-level entry (parity tests, debugging);
+ * pano_compose does not materialise this image. */
+pano_status pano_warp(pano_ctx* ctx, int i, const uint8_t* d_src, size_t src_stride,
+                      uint8_t* d_dst, size_t dst_stride, void* hip_stream);
+/* RotationWarper::warp(mask255, K, R, INTER_NEAREST, BORDER_CONSTANT, dst) (ocvstitcher.hpp:1085) */
+pano_status pano_warp_mask(pano_ctx* ctx, int i, uint8_t* d_dst, size_t dst_stride, void* hip_stream);
+
+/* ocvStitcher::process(imgs, ret) (ocvstitcher.hpp:1141-1216) with device-resident frames:
+ * N x (warp -> 16S -> feed) -> blend -> 8U -> cut.  Asynchronous on hip_stream. */
+pano_status pano_compose(pano_ctx* ctx, const uint8_t* const* d_frames, const size_t* strides,
+                         uint8_t* d_out, size_t out_stride, void* hip_stream);
+/* the same with host cv::Mat-style buffers in and out (H2D, compose, D2H, synchronous): the exact
+ * shape of process(vector<Mat>&, Mat&) */
+pano_status pano_compose_host(pano_ctx* ctx, const uint8_t* const* h_frames, const size_t* strides,
+                              uint8_t* h_out, size_t out_stride);
+
+/* ---- camera-sharded (multi-GPU) form of the same path -------------------------------------- */
+/* warp + Gaussian pyramid of the cameras selected by cam_bits (bit i = camera i) into the ctx's
+ * pyramid slots; d_frames entries of unselected cameras are ignored */
+pano_status pano_feed_cameras(pano_ctx* ctx, unsigned cam_bits, const uint8_t* const* d_frames,
+                              const size_t* strides, void* hip_stream);
+/* all pyramid slots are one allocation, slot i at base + i*slot_bytes (equal sized so that one
+ * RCCL gather / all-gather lands every rank's slots in place) */
+pano_status pano_get_pyramid_slots(pano_ctx* ctx, void** d_base, size_t* slot_bytes);
+/* Blender::blend + 8U + cut over whatever the pyramid slots hold */
+pano_status pano_blend(pano_ctx* ctx, uint8_t* d_out, size_t out_stride, void* hip_stream);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+enum { PANO_STAGE_WARP = 0, PANO_STAGE_PYRAMID = 1, PANO_STAGE_BLEND = 2, PANO_NUM_STAGES = 3 };
+/* when enabled, hipEvents bracket each stage on the launch stream */
+pano_status pano_set_profiling(pano_ctx* ctx, int enabled);
+/* ms of each stage of the LAST compose (synchronises on its events) */
+pano_status pano_get_stage_ms(pano_ctx* ctx, float ms[PANO_NUM_STAGES]);
+/* totals since the last reset: the events live in a ring and are harvested lazily, so a timed loop
+ * never waits for the GPU; launches[k] = number of stage-k intervals summed into total_ms[k] */
+pano_status pano_get_stage_stats(pano_ctx* ctx, double total_ms[PANO_NUM_STAGES],
+                                 uint64_t launches[PANO_NUM_STAGES], int reset);
+/* algorithmic bytes of the warp kernel per compose: sum_cams (W*H*3 + Wt*Ht*6) and its launch shape */
+pano_status pano_get_warp_bytes(const pano_ctx* ctx, uint64_t* src_bytes, uint64_t* dst_bytes);
+
+/* ---- stage inspection (parity tests) ------------------------------------------------------- */
+/* Gaussian level `level` of camera i's bordered tile, int16 x3 interleaved, tight rows */
+pano_status pano_debug_get_level(pano_ctx* ctx, int i, int level, int16_t* h_dst, int* w, int* h);
+/* f32 weight level of camera i (pyrDown chain of mask/255 with constant border) */
+pano_status pano_debug_get_weights(pano_ctx* ctx, int i, int level, float* h_dst, int* w, int* h);
+/* canvas: summed weights / collapsed image of a level */
+pano_status pano_debug_get_canvas_weights(pano_ctx* ctx, int level, float* h_dst, int* w, int* h);
+pano_status pano_debug_get_canvas(pano_ctx* ctx, int level, int16_t* h_dst, int* w, int* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANO_H */

@@ -1,0 +1,49 @@
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pano():
+    """the product package (directory name has a hyphen, so import by string)"""
+    return importlib.import_module("img-stitching_amd")
+
+
+@pytest.fixture(scope="session")
+def po():
+    """the CPU oracle (test infrastructure)"""
+    import pano_oracle
+    pano_oracle.build()
+    return pano_oracle
+
+
+def load_png_bgr(path):
+    from PIL import Image
+    return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+
+
+@pytest.fixture(scope="session")
+def c1():
+    """config 1: 4 x 480x270 frames of 2222/1..4.png + last record of 2222/cameraparaout_1.txt"""
+    d = json.load(open(os.path.join(GOLDEN, "c1_cams.json")))
+    frames = [load_png_bgr(os.path.join(GOLDEN, f"c1_cam{i}.png")) for i in range(4)]
+    return {"frames": frames, "K": [d["K"]] * 4, "R": d["R"], "scale": d["scale"], "w": 480, "h": 270, "n": 4}
+
+
+@pytest.fixture(scope="session")
+def rig_r():
+    """reference rig R: cfg/cameras.yaml 4cam-black/960, stitcher 0 and 1 (2 cams each) + cut"""
+    return json.load(open(os.path.join(GOLDEN, "r_cams.json")))

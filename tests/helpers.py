@@ -1,0 +1,35 @@
+"""shared synthetic inputs for the tests and bench.py (no reference files needed at run time)"""
+import math
+
+import numpy as np
+
+
+def synth_frame(w, h, seed):
+    """deterministic BGR8 frame: PCG64 noise low-passed 3x3, mixed with smooth ramps and hard edges so that
+    interpolation, pyramid and seam arithmetic all see structure"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8).astype(np.float32)
+    p = np.pad(img, ((1, 1), (1, 1), (0, 0)), mode="edge")
+    lp = sum(p[dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)) / 9.0
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    ramp = 110.0 + 70.0 * np.sin(xx / w * 9.0 + seed)[..., None] + 60.0 * np.cos(yy / h * 5.0 + np.arange(3))
+    checker = (((xx // 37).astype(np.int32) + (yy // 29).astype(np.int32)) % 2 * 60.0)[..., None]
+    return np.clip(0.4 * lp + 0.6 * ramp + checker - 30.0, 0, 255).astype(np.uint8)
+
+
+def ry(deg):
+    t = math.radians(deg)
+    c, s = math.cos(t), math.sin(t)
+    return [c, 0.0, s, 0.0, 1.0, 0.0, -s, 0.0, c]
+
+
+def c2_group(w=1920, h=1080, f=1002.416):
+    """config 2, one group: 4 cameras at yaw +67.5, +22.5, -22.5, -67.5 degrees"""
+    K = [f, 0.0, w / 2.0, 0.0, f, h / 2.0, 0.0, 0.0, 1.0]
+    return {"K": [K] * 4, "R": [ry(a) for a in (67.5, 22.5, -22.5, -67.5)], "scale": f, "w": w, "h": h, "n": 4}
+
+
+def c4_rig(w=3840, h=2160, f=3534.0):
+    """config 4: 4 x 4K, cylindrical, same yaws"""
+    d = c2_group(w, h, f)
+    return d

@@ -1,0 +1,128 @@
+"""CPU tests of the product's boundary: the C-ABI library loads, exports every symbol include/pano.h
+declares, and its host-side geometry (plan-only contexts: no GPU, no compute) matches the oracle.
+Compute entry points must refuse to run without a device - there is no CPU fallback."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import c2_group, c4_rig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib(pano):
+    pano.build()
+    return pano.load_library()
+
+
+def test_exports_match_header(pano, lib):
+    hdr = open(os.path.join(ROOT, "include", "pano.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(pano_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == sorted(pano.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.pano_version()
+
+
+def make_plan(pano, d, kind, **kw):
+    ctx = pano.Context(d["n"], d["w"], d["h"], scale=d["scale"], projector=kind, device=-1, **kw)
+    for i in range(d["n"]):
+        ctx.set_camera(i, d["K"][i], d["R"][i])
+    ctx.prepare()
+    return ctx
+
+
+@pytest.mark.parametrize("name,kind,bands", [("c1", 0, 2), ("c1", 0, 4), ("c1", 0, 0), ("c1", 1, 3), ("c2", 0, 5), ("c4", 1, 7)])
+def test_plan_matches_oracle(pano, po, c1, name, kind, bands):
+    d = {"c1": c1, "c2": c2_group(), "c4": c4_rig()}[name]
+    ctx = make_plan(pano, d, kind, num_bands=bands)
+    rois = [po.warp_roi(po.projector(kind, d["scale"], d["K"][i], d["R"][i]), d["w"], d["h"]) for i in range(d["n"])]
+    assert [ctx.roi(i) for i in range(d["n"])] == rois
+    b = po.Blender(bands)
+    b.prepare([r[:2] for r in rois], [r[2:] for r in rois])
+    assert ctx.pano_rect() == b.dst_roi_final() and ctx.num_bands() == b.num_bands()
+    for i in range(d["n"]):
+        # feed() geometry only (a 1-row dummy image is enough to exercise the tile box arithmetic)
+        img = np.zeros((rois[i][3], rois[i][2], 3), np.int16)
+        b.feed(img, np.zeros((rois[i][3], rois[i][2]), np.uint8), rois[i][:2])
+        assert ctx.feed_tile(i) == b.last_tile()
+    assert ctx.output_size() == b.dst_roi_final()[2:]
+    src, dst = ctx.warp_bytes()
+    assert src == d["n"] * d["w"] * d["h"] * 3
+    assert dst == sum(ctx.feed_tile(i)[0][2] * ctx.feed_tile(i)[0][3] * 6 for i in range(d["n"]))
+
+
+def test_band_rule_and_cut(pano, po, c1, rig_r):
+    for s in (1.0, 3.0, 5.0):
+        ctx = make_plan(pano, c1, 0, num_bands=pano.BANDS_FROM_STRENGTH, blend_strength=s)
+        assert ctx.num_bands() == po.bands_from_strength(1333, 257, s)
+    ctx = make_plan(pano, c1, 0, num_bands=pano.BANDS_FROM_STRENGTH, blend_strength=0.01)
+    assert ctx.num_bands() == -1      # Blender::NO
+    st = rig_r["stitchers"][0]
+    ctx = pano.Context(2, 960, 540, num_bands=pano.BANDS_FROM_STRENGTH, blend_strength=1.0, cut=st["cut"], device=-1)
+    ctx.set_cameras_from_list(",".join(repr(v) for v in st["cams"]))
+    ctx.prepare()
+    assert ctx.pano_rect() == (-721, 497, 1452, 523) and ctx.num_bands() == 3
+    assert ctx.output_size() == (1430, 250)
+    with pytest.raises(pano.PanoError):
+        ctx.set_cut((0, 0, 2000, 10))
+
+
+def test_camera_file_loader(pano, c1, tmp_path):
+    # old 7-line shared-K record (2222/cameraparaout_1.txt) preceded by an older record that must be skipped
+    K = ",".join(repr(v) for v in c1["K"][0]) + ","
+    rec = ["2021-01-01-00-00-00:", "1,0,0,0,1,0,0,0,1,"] + ["1,0,0,0,1,0,0,0,1,"] * 4 + ["100"]
+    rec += ["2021-11-17-10-25-21:", K] + [",".join(repr(v) for v in r) + "," for r in c1["R"]] + [repr(c1["scale"])]
+    p = tmp_path / "cameraparaout_1.txt"
+    p.write_text("\n".join(rec) + "\n")
+    ctx = pano.Context(4, 480, 270, num_bands=2, device=-1)
+    ctx.load_camera_file(str(p))
+    ctx.prepare()
+    assert ctx.pano_rect() == (-1121, 475, 1333, 257)
+    # new format written by saveCameraParams: N lines of 18 values + scale
+    rec = ["2022-10-10-16-25-01:"] + [K + ",".join(repr(v) for v in r) + "," for r in c1["R"]] + [repr(c1["scale"])]
+    p.write_text("\n".join(rec) + "\n")
+    ctx = pano.Context(4, 480, 270, num_bands=2, device=-1)
+    ctx.load_camera_file(str(p))
+    ctx.prepare()
+    assert ctx.pano_rect() == (-1121, 475, 1333, 257)
+    with pytest.raises(pano.PanoError):
+        pano.Context(4, 480, 270, device=-1).load_camera_file(str(tmp_path / "missing.txt"))
+
+
+def test_errors_and_no_cpu_fallback(pano, c1):
+    with pytest.raises(pano.PanoError):
+        pano.Context(0, 480, 270, device=-1)
+    with pytest.raises(pano.PanoError):
+        pano.Context(9, 480, 270, device=-1)
+    ctx = pano.Context(4, 480, 270, scale=c1["scale"], num_bands=2, device=-1)
+    with pytest.raises(pano.PanoError):   # cameras missing
+        ctx.prepare()
+    with pytest.raises(pano.PanoError):   # bad index
+        ctx.set_camera(7, c1["K"][0], c1["R"][0])
+    with pytest.raises(pano.PanoError):   # list length
+        ctx.set_cameras_from_list("1,2,3")
+    ctx = make_plan(pano, c1, 0, num_bands=2)
+    # every compute entry refuses on a plan-only context: PANO_ENODEVICE, never a host computation
+    for fn in (lambda: ctx.compose_host(c1["frames"]), lambda: ctx.build_masks_voronoi(),
+               lambda: ctx.set_mask(0, np.zeros((254, 422), np.uint8)), lambda: ctx.blend(0, 0),
+               lambda: ctx.warp(0, 0, 0, 0, 0), lambda: ctx.pyramid_slots(), lambda: ctx.debug_level(0, 0)):
+        with pytest.raises(pano.PanoError) as e:
+            fn()
+        assert e.value.status == -5
+
+
+def test_full_ring_is_rejected(pano):
+    # a camera looking backwards straddles the +-pi seam (reference README.md:27-29): PANO_EWRAP
+    from helpers import ry
+    K = [1002.416, 0, 960, 0, 1002.416, 540, 0, 0, 1]
+    ctx = pano.Context(1, 1920, 1080, scale=1002.416, num_bands=2, device=-1)
+    ctx.set_camera(0, K, ry(180.0))
+    with pytest.raises(pano.PanoError) as e:
+        ctx.prepare()
+    assert e.value.status == -6

@@ -1,0 +1,224 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C-ABI against the CPU
+oracle on the same inputs.  Everything on this path is integer / fixed-point or exactly-ordered f32,
+so the bar is BIT-EXACT (tolerance 0), stage by stage and end to end."""
+import numpy as np
+import pytest
+
+from helpers import c2_group, c4_rig, synth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def make_ctx(pano, d, kind=0, **kw):
+    ctx = pano.Context(d["n"], d["w"], d["h"], scale=d["scale"], projector=kind, device=0, **kw)
+    for i in range(d["n"]):
+        ctx.set_camera(i, d["K"][i], d["R"][i])
+    ctx.prepare()
+    return ctx
+
+
+def oracle_masks(po, d, kind=0):
+    return po.prepare_masks_voronoi(kind, d["w"], d["h"], d["K"], d["R"], d["scale"])
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_warp_stage_bit_exact(pano, po, torch, c1, kind):
+    """RotationWarper::warp (INTER_LINEAR, BORDER_REFLECT) and the NEAREST/CONSTANT mask warp"""
+    ctx = make_ctx(pano, c1, kind, num_bands=2)
+    for i in range(4):
+        p = po.projector(kind, c1["scale"], c1["K"][i], c1["R"][i])
+        corner, want = po.warp(p, c1["frames"][i])
+        r = ctx.roi(i)
+        assert r[:2] == corner and want.shape == (r[3], r[2], 3)
+        src = torch.from_numpy(c1["frames"][i]).cuda()
+        dst = torch.zeros((r[3], r[2], 3), dtype=torch.uint8, device="cuda")
+        ctx.warp(i, src.data_ptr(), 480 * 3, dst.data_ptr(), r[2] * 3, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), want)
+        _, wantm = po.warp(p, np.full((270, 480), 255, np.uint8), po.INTER_NEAREST, po.BORDER_CONSTANT)
+        dm = torch.zeros((r[3], r[2]), dtype=torch.uint8, device="cuda")
+        ctx.warp_mask(i, dm.data_ptr(), r[2], torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(dm.cpu().numpy(), wantm)
+
+
+def test_voronoi_masks_bit_exact(pano, po, c1, rig_r):
+    ctx = make_ctx(pano, c1, 0, num_bands=2)
+    ctx.build_masks_voronoi()
+    want = oracle_masks(po, c1)
+    for i in range(4):
+        assert np.array_equal(ctx.get_mask(i), want[i])
+    st = rig_r["stitchers"][1]
+    v = st["cams"]
+    d = {"n": 2, "w": 960, "h": 540, "scale": v[-1], "K": [v[0:9], v[18:27]], "R": [v[9:18], v[27:36]]}
+    ctx = make_ctx(pano, d, 0, num_bands=3)
+    ctx.build_masks_voronoi()
+    want = oracle_masks(po, d)
+    for i in range(2):
+        assert np.array_equal(ctx.get_mask(i), want[i])
+
+
+@pytest.mark.parametrize("bands", [0, 2, 4])
+def test_stages_and_compose_c1_bit_exact(pano, po, c1, bands):
+    """config 1 end to end + every intermediate the oracle exposes"""
+    masks = oracle_masks(po, c1)
+    ctx = make_ctx(pano, c1, 0, num_bands=bands)
+    for i in range(4):
+        ctx.set_mask(i, masks[i])
+    got = ctx.compose_host(c1["frames"])
+    want, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, bands)
+    assert got.shape == want.shape == (257, 1333, 3)
+    assert np.array_equal(got, want)
+    # per-camera Gaussian levels == pyrDown chain of the REFLECT-bordered warped image; weights likewise
+    rois = [ctx.roi(i) for i in range(4)]
+    b = po.Blender(bands)
+    b.prepare([r[:2] for r in rois], [r[2:] for r in rois])
+    for i in range(4):
+        p = po.projector(0, c1["scale"], c1["K"][i], c1["R"][i])
+        warped = po.warp(p, c1["frames"][i])[1].astype(np.int16)
+        (tx, ty, tw, th), (top, bottom, left, right) = ctx.feed_tile(i)
+        ys = np.abs(np.arange(-top, warped.shape[0] + bottom))
+        # BORDER_REFLECT index map
+        def refl(idx, n):
+            q = np.mod(idx, 2 * n)
+            return np.where(q < n, q, 2 * n - 1 - q)
+        g = warped[refl(np.arange(-top, warped.shape[0] + bottom), warped.shape[0])][:, refl(np.arange(-left, warped.shape[1] + right), warped.shape[1])]
+        wgt = np.zeros((th, tw), np.float32)
+        wgt[top:top + warped.shape[0], left:left + warped.shape[1]] = masks[i].astype(np.float32) * np.float32(1.0 / 255.0)
+        for l in range(bands + 1):
+            assert np.array_equal(ctx.debug_level(i, l), g), (i, l)
+            assert np.array_equal(ctx.debug_weights(i, l), wgt), (i, l)
+            if l < bands:
+                g = po.pyr_down_16s(g)
+                wgt = po.pyr_down_32f(wgt)
+        b.feed(warped, masks[i], rois[i][:2])
+    for l in range(bands + 1):
+        assert np.array_equal(ctx.debug_canvas_weights(l), b.level_weights(l))
+    # idempotence: a second frame through the same context gives the same panorama
+    assert np.array_equal(ctx.compose_host(c1["frames"]), want)
+
+
+def test_no_blend_and_cut_and_cylindrical(pano, po, c1, rig_r):
+    masks = oracle_masks(po, c1)
+    ctx = make_ctx(pano, c1, 0, num_bands=pano.BANDS_NO_BLEND)
+    for i in range(4):
+        ctx.set_mask(i, masks[i])
+    want, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, -1)
+    assert np.array_equal(ctx.compose_host(c1["frames"]), want)
+    # cut (m_cutParams) on rig R stitcher 0 with the band rule at strength 1 -> 3 bands
+    st = rig_r["stitchers"][0]
+    v = st["cams"]
+    d = {"n": 2, "w": 960, "h": 540, "scale": v[-1], "K": [v[0:9], v[18:27]], "R": [v[9:18], v[27:36]]}
+    frames = [synth_frame(960, 540, 11 + i) for i in range(2)]
+    m = oracle_masks(po, d)
+    ctx = make_ctx(pano, d, 0, num_bands=pano.BANDS_FROM_STRENGTH, blend_strength=1.0, cut=st["cut"])
+    assert ctx.num_bands() == 3
+    for i in range(2):
+        ctx.set_mask(i, m[i])
+    want, _ = po.compose(frames, d["K"], d["R"], d["scale"], m, 3, cut=st["cut"])
+    got = ctx.compose_host(frames)
+    assert got.shape == (250, 1430, 3) and np.array_equal(got, want)
+    # cylindrical projector
+    mc = oracle_masks(po, c1, 1)
+    ctx = make_ctx(pano, c1, 1, num_bands=3)
+    for i in range(4):
+        ctx.set_mask(i, mc[i])
+    want, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], mc, 3, kind=1)
+    assert np.array_equal(ctx.compose_host(c1["frames"]), want)
+
+
+def test_ragged_masks_and_extreme_frames(pano, po, c1):
+    """edge cases: empty mask for one camera, soft (non 0/255) masks, all-black and all-white frames"""
+    rng = np.random.default_rng(5)
+    ctx = make_ctx(pano, c1, 0, num_bands=3)
+    rois = [ctx.roi(i) for i in range(4)]
+    masks = [rng.integers(0, 256, size=(r[3], r[2]), dtype=np.uint8) for r in rois]
+    masks[1][:] = 0
+    masks[2][:, : rois[2][2] // 2] = 255
+    for i in range(4):
+        ctx.set_mask(i, masks[i])
+    frames = [np.zeros((270, 480, 3), np.uint8), np.full((270, 480, 3), 255, np.uint8), c1["frames"][2],
+              rng.integers(0, 256, size=(270, 480, 3), dtype=np.uint8)]
+    want, _ = po.compose(frames, c1["K"], c1["R"], c1["scale"], masks, 3)
+    assert np.array_equal(ctx.compose_host(frames), want)
+
+
+def test_exposure_gain_apply(pano, po, c1):
+    """BlocksGainCompensator::apply between warp and feed (stitching_detailed.cpp:841)"""
+    rng = np.random.default_rng(7)
+    masks = oracle_masks(po, c1)
+    ctx = make_ctx(pano, c1, 0, num_bands=2)
+    gains, full = [], []
+    for i in range(4):
+        r = ctx.roi(i)
+        g = (0.8 + 0.45 * rng.random(((r[3] + 31) // 32, (r[2] + 31) // 32))).astype(np.float32)
+        gains.append(g)
+        full.append(po.resize_linear_32f(g, r[2], r[3]))
+        ctx.set_mask(i, masks[i])
+        ctx.set_gain_map(i, g)
+    want, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 2, gain_maps=full)
+    assert np.array_equal(ctx.compose_host(c1["frames"]), want)
+    ctx.set_gain_map(0, None)
+
+
+def test_device_entry_and_sharded_feed(pano, po, torch, c1):
+    """pano_compose on device pointers == pano_feed_cameras in two shards + pano_blend (the multi-GPU split)"""
+    masks = oracle_masks(po, c1)
+    ctx = make_ctx(pano, c1, 0, num_bands=4)
+    for i in range(4):
+        ctx.set_mask(i, masks[i])
+    want, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 4)
+    s = torch.cuda.current_stream().cuda_stream
+    d = [torch.from_numpy(f).cuda() for f in c1["frames"]]
+    out = torch.zeros((257, 1333, 3), dtype=torch.uint8, device="cuda")
+    ctx.compose([t.data_ptr() for t in d], [480 * 3] * 4, out.data_ptr(), 1333 * 3, s)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    base, slot = ctx.pyramid_slots()
+    assert base and slot % 4096 == 0
+    out.zero_()
+    ctx.feed_cameras(0b0101, [t.data_ptr() for t in d], [480 * 3] * 4, s)
+    ctx.feed_cameras(0b1010, [t.data_ptr() for t in d], [480 * 3] * 4, s)
+    ctx.blend(out.data_ptr(), 1333 * 3, s)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_c2_full_size_bit_exact(pano, po):
+    """config 2 (one group of the 8x1080p rig: 4 x 1920x1080, 5 bands) against the oracle at full size"""
+    d = c2_group()
+    frames = [synth_frame(1920, 1080, 42 + i) for i in range(4)]
+    ctx = make_ctx(pano, d, 0, num_bands=5)
+    ctx.build_masks_voronoi()
+    masks = [ctx.get_mask(i) for i in range(4)]
+    want_masks = oracle_masks(po, d)
+    for i in range(4):
+        assert np.array_equal(masks[i], want_masks[i])
+    po.set_threads(8)
+    want, _ = po.compose(frames, d["K"], d["R"], d["scale"], masks, 5)
+    po.set_threads(1)
+    got = ctx.compose_host(frames)
+    assert got.shape == (991, 3893, 3)
+    assert np.array_equal(got, want)
+
+
+def test_c4_cylindrical_7_bands_properties(pano, po):
+    """config 4 shape (4 x 4K, cylindrical, 7 bands, gains): size-independent properties at full size -
+    determinism, cut == crop of the full panorama - plus an oracle comparison on a band of rows"""
+    d = c4_rig()
+    frames = [synth_frame(3840, 2160, 7 + i) for i in range(4)]
+    ctx = make_ctx(pano, d, 1, num_bands=7)
+    ctx.build_masks_voronoi()
+    full = ctx.compose_host(frames)
+    assert full.shape[1] == ctx.pano_rect()[2] and full.shape[0] == ctx.pano_rect()[3]
+    assert np.array_equal(full, ctx.compose_host(frames))
+    ctx.set_cut((1000, 300, 6000, 900))
+    assert np.array_equal(ctx.compose_host(frames), full[300:1200, 1000:7000])
+    assert full[:, :, :].max() > 0

@@ -1,0 +1,196 @@
+"""CPU tests of the oracle itself (test infrastructure): the C restatement against the independent NumPy
+restatement, against the ROI integers pinned in SURVEY.md Appendix C, and against hand-computed
+known answers of the pyramid / resize / distance primitives.  PARITY UNPINNED: the reference holds no
+expected outputs, so these are the only pins that exist."""
+import numpy as np
+import pytest
+
+from helpers import c2_group, synth_frame
+
+
+def test_roi_pins_c1(po, c1):
+    # SURVEY.md Appendix C, config 1
+    want = [(-210, 475, 422, 254), (-496, 478, 422, 254), (-816, 476, 423, 254), (-1121, 476, 424, 254)]
+    got = [po.warp_roi(po.projector(po.SPHERICAL, c1["scale"], c1["K"][i], c1["R"][i]), 480, 270) for i in range(4)]
+    assert got == want
+    assert po.result_roi([r[:2] for r in got], [r[2:] for r in got]) == (-1121, 475, 1333, 257)
+    # band rule: strength 1 -> 2, 3 -> 4, 5 -> 4 (Appendix C)
+    assert [po.bands_from_strength(1333, 257, s) for s in (1, 3, 5)] == [2, 4, 4]
+    assert po.bands_from_strength(100, 100, 0.5) == -1  # blend_width < 1 -> Blender::NO
+
+
+def test_roi_pins_c2_and_rig(po, rig_r):
+    g = c2_group()
+    got = [po.warp_roi(po.projector(po.SPHERICAL, g["scale"], g["K"][i], g["R"][i]), 1920, 1080) for i in range(4)]
+    assert got == [(415, 1079, 1532, 991), (-371, 1079, 1530, 991), (-1159, 1079, 1531, 991), (-1946, 1079, 1532, 991)]
+    for st, want_rois, want_pano in ((0, [(-721, 525, 773, 495), (-59, 497, 790, 496)], (-721, 497, 1452, 523)),
+                                     (1, [(-733, 547, 755, 485), (-39, 523, 790, 508)], (-733, 523, 1484, 509))):
+        v = rig_r["stitchers"][st]["cams"]
+        rois = [po.warp_roi(po.projector(po.SPHERICAL, v[-1], v[18 * i:18 * i + 9], v[18 * i + 9:18 * i + 18]), 960, 540)
+                for i in range(2)]
+        assert rois == want_rois
+        assert po.result_roi([r[:2] for r in rois], [r[2:] for r in rois]) == want_pano
+        assert po.bands_from_strength(want_pano[2], want_pano[3], 1.0) == 3
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_projector_and_maps_vs_numpy(po, c1, kind):
+    import np_oracle as npo
+    for i in (0, 2):
+        pc = po.projector(kind, c1["scale"], c1["K"][i], c1["R"][i])
+        pn = npo.Projector(kind, c1["scale"], c1["K"][i], c1["R"][i])
+        assert np.array_equal(np.array(pc.k_rinv[:], np.float32), pn.k_rinv.ravel())
+        assert np.array_equal(np.array(pc.r_kinv[:], np.float32), pn.r_kinv.ravel())
+        assert po.warp_roi(pc, 480, 270) == pn.roi(480, 270)
+        xm, ym = po.build_maps(pc, 480, 270)
+        X, Y = pn.maps(480, 270)
+        assert np.array_equal(xm, X) and np.array_equal(ym, Y)   # separable tables == per-pixel sinf/cosf
+
+
+def test_warp_vs_numpy(po, c1):
+    import np_oracle as npo
+    for i in (1, 3):
+        pc = po.projector(0, c1["scale"], c1["K"][i], c1["R"][i])
+        corner, warped = po.warp(pc, c1["frames"][i])
+        X, Y = npo.Projector(0, c1["scale"], c1["K"][i], c1["R"][i]).maps(480, 270)
+        assert np.array_equal(warped, npo.remap_linear_reflect(c1["frames"][i], X, Y))
+        assert corner == po.warp_roi(pc, 480, 270)[:2]
+
+
+def test_remap_known_answers(po):
+    src = np.arange(5 * 4 * 3, dtype=np.uint8).reshape(4, 5, 3) * 3
+    # exact pixel centres reproduce the source; (-1,-1) hits REFLECT -> pixel (0,0); half-way is the mean
+    xm = np.array([[0.0, 4.0, -1.0, 1.5, 2.0]], np.float32)
+    ym = np.array([[0.0, 3.0, -1.0, 0.0, 1.5]], np.float32)
+    out = po.remap(src, xm, ym, po.INTER_LINEAR, po.BORDER_REFLECT)
+    s = src.astype(int)
+    assert np.array_equal(out[0, 0], src[0, 0]) and np.array_equal(out[0, 1], src[3, 4])
+    assert np.array_equal(out[0, 2], src[0, 0])
+    assert np.array_equal(out[0, 3], (s[0, 1] + s[0, 2] + 1) // 2)
+    assert np.array_equal(out[0, 4], (s[1, 2] + s[2, 2] + 1) // 2)
+    # 1/32 quantisation: 1.49 -> cvRound(47.68)=48 -> 1.5 exactly
+    out2 = po.remap(src, np.array([[1.49]], np.float32), np.array([[0.0]], np.float32), po.INTER_LINEAR, po.BORDER_REFLECT)
+    assert np.array_equal(out2[0, 0], out[0, 3])
+    # nearest / constant: outside -> 0, ties round half to even
+    m = np.full((4, 5), 255, np.uint8)
+    o = po.remap(m, np.array([[-0.5, -0.51, 4.5, 4.49]], np.float32), np.zeros((1, 4), np.float32), po.INTER_NEAREST,
+                 po.BORDER_CONSTANT)
+    assert o.tolist() == [[255, 0, 255, 255]]
+
+
+def test_pyramids_known_answers_and_numpy(po):
+    import np_oracle as npo
+    # constant image stays constant through pyrDown / pyrUp (weights sum to 256 / 64)
+    a = np.full((8, 12, 3), 77, np.int16)
+    assert (po.pyr_down_16s(a) == 77).all() and (po.pyr_up_16s(a) == 77).all()
+    # impulse: pyrDown of a centred delta*256 gives the 5-tap products /256
+    d = np.zeros((9, 9), np.int16); d[4, 4] = 256
+    pd = po.pyr_down_16s(d)
+    assert pd.shape == (5, 5) and pd[2, 2] == 36 and pd[1, 2] == 6 and pd[1, 1] == 1 and pd[0, 0] == 0
+    # pyrUp edges: left reflect-101 (6 s0 + 2 s1), right replicate (s[n-2] + 7 s[n-1], 8 s[n-1])
+    r = np.array([[8, 16, 32]], np.int16)
+    up = po.pyr_up_16s(r)
+    hor = [6 * 8 + 2 * 16, 4 * (8 + 16), 8 + 6 * 16 + 32, 4 * (16 + 32), 16 + 7 * 32, 8 * 32]
+    assert up[0].tolist() == [(8 * h + 32) >> 6 for h in hor]
+    rng = np.random.default_rng(3)
+    for shape in ((16, 24, 3), (7, 9, 3), (2, 2, 3), (33, 17, 1)):
+        x = rng.integers(-3000, 3000, size=shape).astype(np.int16)
+        xin = x[..., 0] if shape[2] == 1 else x
+        assert np.array_equal(po.pyr_down_16s(xin), npo.pyr_down_16s(xin))
+        assert np.array_equal(po.pyr_up_16s(xin), npo.pyr_up_16s(xin))
+    w = rng.random((20, 36)).astype(np.float32)
+    assert np.array_equal(po.pyr_down_32f(w), npo.pyr_down_32f(w))
+
+
+def test_blender_vs_numpy(po, c1):
+    import np_oracle as npo
+    rois, warped = [], []
+    for i in range(4):
+        p = po.projector(0, c1["scale"], c1["K"][i], c1["R"][i])
+        rois.append(po.warp_roi(p, 480, 270))
+        warped.append(po.warp(p, c1["frames"][i])[1])
+    masks = po.prepare_masks_voronoi(0, 480, 270, c1["K"], c1["R"], c1["scale"])
+    for nb in (0, 2, 4):
+        bc = po.Blender(nb); bn = npo.MultiBand(nb)
+        bc.prepare([r[:2] for r in rois], [r[2:] for r in rois]); bn.prepare([r[:2] for r in rois], [r[2:] for r in rois])
+        assert bc.dst_roi() == bn.roi and bc.dst_roi_final() == bn.final and bc.num_bands() == bn.nb
+        for i in range(4):
+            bc.feed(warped[i].astype(np.int16), masks[i], rois[i][:2])
+            bn.feed(warped[i].astype(np.int16), masks[i], rois[i][:2])
+            assert bc.last_tile() == bn.last_tile
+        for l in range(nb + 1):
+            assert np.array_equal(bc.level_laplace(l), bn.lap[l].astype(np.int16))
+            assert np.array_equal(bc.level_weights(l), bn.wgt[l])
+        rc, mc = bc.blend(); rn, mn = bn.blend()
+        assert np.array_equal(rc, rn) and np.array_equal(mc, mn)
+
+
+def test_single_camera_full_mask_blend_is_warp(po, c1):
+    """property: one camera with an all-255 mask blends to its own warped image within 1 LSB
+    per band of truncation"""
+    p = po.projector(0, c1["scale"], c1["K"][0], c1["R"][0])
+    roi = po.warp_roi(p, 480, 270)
+    _, warped = po.warp(p, c1["frames"][0])
+    for nb in (0, 3):
+        b = po.Blender(nb)
+        b.prepare([roi[:2]], [roi[2:]])
+        b.feed(warped.astype(np.int16), np.full((roi[3], roi[2]), 255, np.uint8), roi[:2])
+        out, m = b.blend()
+        assert (m == 255).all()
+        assert np.abs(out.astype(int) - warped.astype(int)).max() <= 2 * nb + 2
+
+
+def test_no_blend_path(po):
+    b = po.Blender(-1)
+    b.prepare([(0, 0), (3, 0)], [(4, 2), (4, 2)])
+    a = np.full((2, 4, 3), 10, np.int16); c = np.full((2, 4, 3), 20, np.int16)
+    b.feed(a, np.array([[255, 255, 255, 0]] * 2, np.uint8), (0, 0))
+    b.feed(c, np.array([[0, 255, 255, 255]] * 2, np.uint8), (3, 0))
+    out, m = b.blend()
+    assert out[0, :, 0].tolist() == [10, 10, 10, 0, 20, 20, 20] and m[0].tolist() == [255, 255, 255, 0, 255, 255, 255]
+
+
+def test_mask_primitives(po):
+    m = np.zeros((5, 6), np.uint8); m[2, 3] = 200
+    d = po.dilate3x3(m)
+    assert d[1:4, 2:5].min() == 200 and d.sum() == 200 * 9
+    # INTER_LINEAR_EXACT: identity at equal size, 2x upscale of a step keeps 0/255 ends and exact 1/4-3/4 mixes
+    a = np.array([[0, 255]], np.uint8)
+    assert np.array_equal(po.resize_linear_exact(a, 2, 1), a)
+    up = po.resize_linear_exact(a, 4, 1)
+    assert up.tolist() == [[0, 64, 191, 255]]
+    # L1 distance: city-block to the nearest zero
+    z = np.full((5, 7), 255, np.uint8); z[2, 1] = 0
+    dist = po.distance_l1(z)
+    yy, xx = np.mgrid[0:5, 0:7]
+    assert np.array_equal(dist, (np.abs(yy - 2) + np.abs(xx - 1)).astype(np.float32))
+
+
+def test_voronoi_partitions_overlap(po, c1):
+    masks = po.prepare_masks_voronoi(0, 480, 270, c1["K"], c1["R"], c1["scale"])
+    rois = [po.warp_roi(po.projector(0, c1["scale"], c1["K"][i], c1["R"][i]), 480, 270) for i in range(4)]
+    full = po.result_roi([r[:2] for r in rois], [r[2:] for r in rois])
+    cover = np.zeros((full[3], full[2]), np.int32)
+    for m, r in zip(masks, rois):
+        assert m.shape == (r[3], r[2])
+        cover[r[1] - full[1]:r[1] - full[1] + r[3], r[0] - full[0]:r[0] - full[0] + r[2]] += (m == 255)
+    # seams are dilated by one seam-scale pixel, so full-weight double cover is a thin band only
+    assert (cover >= 1).mean() > 0.9 and (cover >= 2).mean() < 0.05
+
+
+def test_gain_apply(po):
+    g = po.resize_linear_32f(np.array([[1.0, 2.0]], np.float32), 4, 1)
+    assert g.tolist() == [[1.0, 1.25, 1.75, 2.0]]
+
+
+def test_compose_cut_and_threads(po, c1):
+    masks = po.prepare_masks_voronoi(0, 480, 270, c1["K"], c1["R"], c1["scale"])
+    full, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 2)
+    cut, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 2, cut=(10, 20, 1000, 200))
+    assert np.array_equal(cut, full[20:220, 10:1010])
+    po.set_threads(4)
+    par, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 2)
+    po.set_threads(1)
+    assert np.array_equal(par, full)
+    with pytest.raises(ValueError):
+        po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 2, cut=(0, 0, 2000, 100))
