@@ -12,7 +12,7 @@ def synth_frame(w, h, seed):
     p = np.pad(img, ((1, 1), (1, 1), (0, 0)), mode="edge")
     lp = sum(p[dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)) / 9.0
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-    ramp = 110.0 + 70.0 * np.sin(xx / w * 9.0 + seed)[..., None] + 60.0 * np.cos(yy / h * 5.0 + np.arange(3))
+    ramp = 110.0 + 70.0 * np.sin(xx / w * 9.0 + seed)[..., None] + 60.0 * np.cos((yy / h * 5.0)[..., None] + np.arange(3, dtype=np.float32))
     checker = (((xx // 37).astype(np.int32) + (yy // 29).astype(np.int32)) % 2 * 60.0)[..., None]
     return np.clip(0.4 * lp + 0.6 * ramp + checker - 30.0, 0, 255).astype(np.uint8)
 
