@@ -16,7 +16,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpano_hip.so")
+# PANO_LIB selects another build of the same C-ABI (the diagnostic library used by tools/); default = product
+LIB_PATH = os.environ.get("PANO_LIB") or os.path.join(_HERE, "libpano_hip.so")
 
 SPHERICAL, CYLINDRICAL = 0, 1
 BANDS_NO_BLEND, BANDS_FROM_STRENGTH = -1, -2

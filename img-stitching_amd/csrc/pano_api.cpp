@@ -57,7 +57,10 @@ struct pano_ctx {
     size_t slot_bytes = 0;
     size_t lvl_off[kMaxCams][kMaxLevels] = {};
     int lvl_pitch[kMaxCams][kMaxLevels] = {};
+    int lvl_plane[kMaxCams][kMaxLevels] = {};
+    int wpitch[kMaxCams][kMaxLevels] = {};
     float* wgt[kMaxCams][kMaxLevels] = {};
+    uint8_t* mask0[kMaxCams] = {};  // level-0 tile-sized mask with the CONSTANT border of feed()
     float* wsum[kMaxLevels] = {};
     int16_t* canvas[kMaxLevels] = {};
 
@@ -124,7 +127,7 @@ void dfree(T*& p) {
 void free_device(pano_ctx* c) {
     for (int i = 0; i < kMaxCams; i++) {
         dfree(c->colA[i]); dfree(c->rowB[i]); dfree(c->colA_roi[i]); dfree(c->rowB_roi[i]);
-        dfree(c->mask[i]); dfree(c->gain[i]);
+        dfree(c->mask[i]); dfree(c->gain[i]); dfree(c->mask0[i]);
         dfree(c->gcol[i]); dfree(c->grow[i]); dfree(c->gcol_roi[i]); dfree(c->grow_roi[i]);
         dfree(c->gcolw[i]); dfree(c->groww[i]); dfree(c->gcolw_roi[i]); dfree(c->groww_roi[i]);
         dfree(c->stage_in[i]);
@@ -161,6 +164,7 @@ WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t strid
         w.tw = c->plan.tile[i].rect.w; w.th = c->plan.tile[i].rect.h;
         w.dst = c->pyr_base + (size_t)i * c->slot_bytes + c->lvl_off[i][0];
         w.dst_pitch = c->lvl_pitch[i][0];
+        w.dst_plane = c->lvl_plane[i][0];
         w.gcol = c->gcol[i]; w.gcolw = c->gcolw[i]; w.grow = c->grow[i]; w.groww = c->groww[i];
     }
     w.gain = c->gain[i];
@@ -234,17 +238,17 @@ pano_status ensure_weights(pano_ctx* c, hipStream_t s) {
     const Plan& P = c->plan;
     for (int i = 0; i < P.n; i++)
         if (!c->mask_set[i]) return fail(c, PANO_ESTATE, "blend masks not set (pano_set_mask / pano_build_masks_voronoi)");
-    if (P.bands >= 0) {
-        for (int i = 0; i < P.n; i++) {
-            const FeedTile& t = P.tile[i];
-            launch_mask_to_weight(c->mask[i], P.roi[i].w, P.roi[i].h, P.roi[i].w, t.left, t.top, c->wgt[i][0], t.rect.w,
-                                  t.rect.h, c->lvl_pitch[i][0], s);
-            for (int l = 0; l < P.bands; l++)
-                launch_pyr_down_f32(c->wgt[i][l], t.rect.w >> l, t.rect.h >> l, c->lvl_pitch[i][l], c->wgt[i][l + 1],
-                                    c->lvl_pitch[i][l + 1], s);
-        }
-        for (int l = 0; l <= P.bands; l++) launch_sum_weights(c->pyr, l, c->wsum[l], P.canvas.w >> l, P.canvas.h >> l, s);
+    for (int i = 0; i < P.n; i++) {
+        const FeedTile& t = P.tile[i];
+        launch_mask_to_weight(c->mask[i], P.roi[i].w, P.roi[i].h, P.roi[i].w, t.left, t.top, c->wgt[i][0], c->wpitch[i][0],
+                              c->mask0[i], c->lvl_pitch[i][0], t.rect.w, t.rect.h, s);
+        for (int l = 0; l < P.bands; l++)
+            launch_pyr_down_f32(c->wgt[i][l], t.rect.w >> l, t.rect.h >> l, c->wpitch[i][l], c->wgt[i][l + 1],
+                                c->wpitch[i][l + 1], s);
     }
+    // the summed canvas weights are not read by the blend (it re-adds the same f32 terms in the same
+    // order); they are kept for stage inspection
+    for (int l = 0; l <= P.bands; l++) launch_sum_weights(c->pyr, l, c->wsum[l], P.canvas.w >> l, P.canvas.h >> l, s);
     HIP_TRY(c, hipGetLastError());
     c->weights_dirty = false;
     return PANO_OK;
@@ -461,37 +465,46 @@ pano_status pano_prepare(pano_ctx* c) {
     for (int i = 0; i < n; i++) {
         size_t off = 0;
         for (int l = 0; l < c->levels; l++) {
+            // planar u8: B, G, R planes, rows padded to 16 bytes, planes to 256 bytes
             int w = P.tile[i].rect.w >> l, h = P.tile[i].rect.h >> l;
-            c->lvl_pitch[i][l] = (int)align_up((size_t)w, 8);
+            c->lvl_pitch[i][l] = (int)align_up((size_t)w, 16);
+            c->lvl_plane[i][l] = (int)align_up((size_t)c->lvl_pitch[i][l] * h, 256);
+            c->wpitch[i][l] = (int)align_up((size_t)w, 4);
             c->lvl_off[i][l] = off;
-            off += align_up((size_t)c->lvl_pitch[i][l] * h * 6, 256);
+            off += (size_t)c->lvl_plane[i][l] * 3;
         }
         slot = std::max(slot, off);
     }
+    c->cv = CanvasParams{};
     c->slot_bytes = align_up(slot, 4096);
-    HIP_TRY(c, hipMalloc((void**)&c->pyr_base, c->slot_bytes * n));
+    HIP_TRY(c, hipMalloc((void**)&c->pyr_base, c->slot_bytes * n + 256));  // + slack: edge lanes read up to 4 bytes past a row
     HIP_TRY(c, hipMemset(c->pyr_base, 0, c->slot_bytes * n));
     std::vector<float> a, b;
     for (int i = 0; i < n; i++) {
         const FeedTile& t = P.tile[i];
         pano_status s;
         trigTables(P.proj[i], P.roi[i], t.left, t.top, t.rect.w, t.rect.h, a, b);
+        while ((a.size() / 2) % 4) {  // K1 reads the column table four entries at a time
+            a.push_back(a[a.size() - 2]);
+            a.push_back(a[a.size() - 2]);
+        }
         if ((s = upload(c, &c->colA[i], a.data(), a.size() * sizeof(float)))) return s;
         if ((s = upload(c, &c->rowB[i], b.data(), b.size() * sizeof(float)))) return s;
         trigTables(P.proj[i], P.roi[i], 0, 0, P.roi[i].w, P.roi[i].h, a, b);
         if ((s = upload(c, &c->colA_roi[i], a.data(), a.size() * sizeof(float)))) return s;
         if ((s = upload(c, &c->rowB_roi[i], b.data(), b.size() * sizeof(float)))) return s;
         HIP_TRY(c, hipMalloc((void**)&c->mask[i], (size_t)P.roi[i].w * P.roi[i].h));
-        if (P.bands >= 0)
-            for (int l = 0; l < c->levels; l++)
-                HIP_TRY(c, hipMalloc((void**)&c->wgt[i][l], (size_t)c->lvl_pitch[i][l] * (t.rect.h >> l) * sizeof(float)));
+        HIP_TRY(c, hipMalloc((void**)&c->mask0[i], (size_t)c->lvl_pitch[i][0] * t.rect.h + 256));
+        for (int l = 0; l < c->levels; l++)
+            HIP_TRY(c, hipMalloc((void**)&c->wgt[i][l], ((size_t)c->wpitch[i][l] * (t.rect.h >> l) + 64) * sizeof(float)));
     }
-    if (P.bands >= 0)
-        for (int l = 0; l < c->levels; l++) {
-            size_t px = (size_t)(P.canvas.w >> l) * (P.canvas.h >> l);
-            HIP_TRY(c, hipMalloc((void**)&c->wsum[l], px * sizeof(float)));
-            if (l > 0) HIP_TRY(c, hipMalloc((void**)&c->canvas[l], px * 6));
-        }
+    for (int l = 0; l < c->levels; l++) {
+        int cw = P.canvas.w >> l, ch = P.canvas.h >> l;
+        c->cv.cpitch[l] = (int)align_up((size_t)cw, 8);
+        c->cv.cplane[l] = c->cv.cpitch[l] * ch;
+        HIP_TRY(c, hipMalloc((void**)&c->wsum[l], (size_t)cw * ch * sizeof(float)));
+        if (l > 0) HIP_TRY(c, hipMalloc((void**)&c->canvas[l], (size_t)c->cv.cplane[l] * 3 * sizeof(int16_t) + 256));
+    }
     // kernel parameter blocks
     c->pyr = PyrParams{};
     c->pyr.ncam = n;
@@ -499,19 +512,30 @@ pano_status pano_prepare(pano_ctx* c) {
         PyrCam& pc = c->pyr.cam[i];
         pc.w0 = P.tile[i].rect.w; pc.h0 = P.tile[i].rect.h;
         pc.tx = P.tile[i].rect.x; pc.ty = P.tile[i].rect.y;
+        pc.mask0 = c->mask0[i];
         for (int l = 0; l < c->levels; l++) {
-            pc.lvl[l] = (int16_t*)(c->pyr_base + (size_t)i * c->slot_bytes + c->lvl_off[i][l]);
+            pc.lvl[l] = (uint8_t*)(c->pyr_base + (size_t)i * c->slot_bytes + c->lvl_off[i][l]);
             pc.wgt[l] = c->wgt[i][l];
             pc.pitch[l] = c->lvl_pitch[i][l];
+            pc.plane[l] = c->lvl_plane[i][l];
+            pc.wpitch[l] = c->wpitch[i][l];
         }
     }
-    c->cv = CanvasParams{};
     for (int l = 0; l < c->levels; l++) {
         c->cv.img[l] = c->canvas[l];
-        c->cv.wsum[l] = c->wsum[l];
+        // the vector blend kernel needs every tile box of the level on a 4 x 2 grid
+        // ... and only pays on big levels: small ones are latency bound and want one pixel per thread
+        bool fast = P.bands >= 0 && ((P.canvas.w >> l) % 4 == 0) && ((P.canvas.h >> l) % 2 == 0) &&
+                    (size_t)(P.canvas.w >> l) * (P.canvas.h >> l) >= 600000;
+        for (int i = 0; i < n && fast; i++) {
+            const Rect& r = P.tile[i].rect;
+            fast = ((r.x >> l) % 4 == 0) && ((r.y >> l) % 2 == 0) && ((r.w >> l) % 4 == 0) && ((r.h >> l) % 2 == 0) &&
+                   ((r.w >> l) << l) == r.w && ((r.x >> l) << l) == r.x;
+        }
+        c->cv.fast[l] = fast ? 1 : 0;
     }
     c->cv.w0 = P.canvas.w; c->cv.h0 = P.canvas.h;
-    c->cv.bands = P.bands;
+    c->cv.bands = P.bands < 0 ? 0 : P.bands;
     c->cv.cut_x = P.cut.x; c->cv.cut_y = P.cut.y; c->cv.cut_w = P.cut.w; c->cv.cut_h = P.cut.h;
     c->cv.final_w = P.pano.w; c->cv.final_h = P.pano.h;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -793,15 +817,7 @@ pano_status pano_blend(pano_ctx* c, uint8_t* d_out, size_t out_stride, void* str
     cv.out = d_out;
     cv.out_stride = (int)out_stride;
     if (P.bands < 0) {
-        const uint8_t* masks[kMaxCams];
-        int mp[kMaxCams], rx[kMaxCams], ry[kMaxCams], rw[kMaxCams], rh[kMaxCams];
-        for (int i = 0; i < P.n; i++) {
-            masks[i] = c->mask[i];
-            mp[i] = P.roi[i].w;
-            rx[i] = P.roi[i].x - P.pano.x; ry[i] = P.roi[i].y - P.pano.y;
-            rw[i] = P.roi[i].w; rh[i] = P.roi[i].h;
-        }
-        launch_no_blend(c->pyr, masks, mp, rx, ry, rw, rh, cv, s);
+        launch_no_blend(c->pyr, cv, s);
     } else {
         for (int l = P.bands; l >= 0; l--) launch_blend_level(c->pyr, cv, l, s);
     }
@@ -906,7 +922,7 @@ pano_status pano_get_warp_bytes(const pano_ctx* c, uint64_t* src_bytes, uint64_t
     uint64_t s = 0, d = 0;
     for (int i = 0; i < c->plan.n; i++) {
         s += (uint64_t)c->plan.src_w * c->plan.src_h * 3;
-        d += (uint64_t)c->plan.tile[i].rect.w * c->plan.tile[i].rect.h * 6;
+        d += (uint64_t)c->plan.tile[i].rect.w * c->plan.tile[i].rect.h * 3;  // planar u8 tile, written once
     }
     *src_bytes = s;
     *dst_bytes = d;
@@ -921,8 +937,12 @@ pano_status pano_debug_get_level(pano_ctx* c, int i, int level, int16_t* h_dst, 
     *h = c->plan.tile[i].rect.h >> level;
     if (!h_dst) return PANO_OK;
     HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy2D(h_dst, (size_t)*w * 6, c->pyr.cam[i].lvl[level], (size_t)c->lvl_pitch[i][level] * 6,
-                           (size_t)*w * 6, (size_t)*h, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> tmp((size_t)*w * *h);
+    for (int pl = 0; pl < 3; pl++) {  // planar u8 on the device -> CV_16SC3 for the caller
+        HIP_TRY(c, hipMemcpy2D(tmp.data(), (size_t)*w, c->pyr.cam[i].lvl[level] + (size_t)pl * c->lvl_plane[i][level],
+                               (size_t)c->lvl_pitch[i][level], (size_t)*w, (size_t)*h, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < tmp.size(); k++) h_dst[k * 3 + pl] = tmp[k];
+    }
     return PANO_OK;
 }
 
@@ -935,7 +955,7 @@ pano_status pano_debug_get_weights(pano_ctx* c, int i, int level, float* h_dst, 
     if (!h_dst) return PANO_OK;
     if ((st = ensure_weights(c, c->own_stream)) != PANO_OK) return st;
     HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy2D(h_dst, (size_t)*w * 4, c->wgt[i][level], (size_t)c->lvl_pitch[i][level] * 4, (size_t)*w * 4,
+    HIP_TRY(c, hipMemcpy2D(h_dst, (size_t)*w * 4, c->wgt[i][level], (size_t)c->wpitch[i][level] * 4, (size_t)*w * 4,
                            (size_t)*h, hipMemcpyDeviceToHost));
     return PANO_OK;
 }
@@ -962,7 +982,12 @@ pano_status pano_debug_get_canvas(pano_ctx* c, int level, int16_t* h_dst, int* w
     *h = c->plan.canvas.h >> level;
     if (!h_dst) return PANO_OK;
     HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy(h_dst, c->canvas[level], (size_t)*w * *h * 6, hipMemcpyDeviceToHost));
+    std::vector<int16_t> tmp((size_t)*w * *h);
+    for (int pl = 0; pl < 3; pl++) {
+        HIP_TRY(c, hipMemcpy2D(tmp.data(), (size_t)*w * 2, c->canvas[level] + (size_t)pl * c->cv.cplane[level],
+                               (size_t)c->cv.cpitch[level] * 2, (size_t)*w * 2, (size_t)*h, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < tmp.size(); k++) h_dst[k * 3 + pl] = tmp[k];
+    }
     return PANO_OK;
 }
 

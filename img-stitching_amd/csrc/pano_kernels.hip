@@ -15,6 +15,7 @@
 #include "pano_kernels.hpp"
 
 #include <limits.h>
+#include <stdlib.h>
 
 namespace pano {
 
@@ -30,23 +31,25 @@ __device__ __forceinline__ int cv_round_dev(float v) {
 __device__ __forceinline__ int sat16i(int v) { return min(max(v, -32768), 32767); }
 __device__ __forceinline__ int sat8i(int v) { return min(max(v, 0), 255); }
 
-// cv::borderInterpolate BORDER_REFLECT, closed form (period 2n)
+// cv::borderInterpolate BORDER_REFLECT.  One fold covers -n <= p < 2n (every tap the warp can ask for
+// near a frame); the closed form (period 2n) with its integer division is kept for anything farther out.
 __device__ __forceinline__ int reflect_idx(int p, int n) {
     if ((unsigned)p < (unsigned)n) return p;
+    int q = p < 0 ? -p - 1 : 2 * n - 1 - p;
+    if ((unsigned)q < (unsigned)n) return q;
     if (n == 1) return 0;
     int period = 2 * n;
-    int q = p % period;
+    q = p % period;
     if (q < 0) q += period;
     return q < n ? q : period - 1 - q;
 }
-// BORDER_REFLECT_101, closed form (period 2n-2)
+// BORDER_REFLECT_101 for the pyramid stencils: p is never farther than 2 outside [0, n)
 __device__ __forceinline__ int reflect101_idx(int p, int n) {
     if ((unsigned)p < (unsigned)n) return p;
     if (n == 1) return 0;
-    int period = 2 * n - 2;
-    int q = p % period;
-    if (q < 0) q += period;
-    return q < n ? q : period - q;
+    p = p < 0 ? -p : 2 * n - 2 - p;
+    p = p < 0 ? -p : p;                 // n == 2
+    return min(p, n - 1);
 }
 
 // Spherical/CylindricalProjector::mapBackward from the separable factors, then the 1/32-pixel
@@ -68,18 +71,33 @@ __device__ __forceinline__ void map_backward(const float* __restrict__ m, float2
 
 // remapBilinear<FixedPtCast<int,uchar,15>>: sum(p*w)+16384 >> 15 with w = (32-a|a)(32-b|b)*32
 // == ((32-b)*(p00*(32-a)+p01*a) + b*(p10*(32-a)+p11*a) + 512) >> 10, exact in integers.
+template <int ABL = 0>
 __device__ __forceinline__ void sample_bilinear_reflect(const uint8_t* __restrict__ src, int sw, int sh, int stride,
                                                         float fx, float fy, int out[3]) {
     int isx = cv_round_dev(fx * 32.f), isy = cv_round_dev(fy * 32.f);
     int a = isx & 31, b = isy & 31;
     int ix = sat16i(isx >> 5), iy = sat16i(isy >> 5);
+    if (ABL == 1) {  // diagnostic: no tap loads
+        out[0] = (ix + a) & 255; out[1] = (iy + b) & 255; out[2] = (ix ^ iy) & 255;
+        return;
+    }
+    if (ABL == 2) {  // diagnostic: every pixel takes the interior path
+        ix = min(max(ix, 0), sw - 3);
+        iy = min(max(iy, 0), sh - 2);
+    }
     int wa0 = 32 - a, wb0 = 32 - b;
-    if (ix >= 0 && ix <= sw - 3 && iy >= 0 && iy <= sh - 2) {
-        // interior: the two taps of a row are 6 consecutive bytes; one unaligned 8-byte load per row
-        const uint8_t* p = src + (size_t)iy * stride + 3 * ix;
+    if (ix >= 0 && ix <= sw - 3) {
+        // the two taps of a row are 6 consecutive bytes: one unaligned 8-byte load per row (ix <= sw-3 keeps
+        // the 2 spare bytes inside the row); rows reflect independently
+        int y0 = iy, y1 = iy + 1;
+        if (iy < 0 || iy > sh - 2) {
+            y0 = reflect_idx(iy, sh);
+            y1 = reflect_idx(iy + 1, sh);
+        }
+        const uint8_t* p = src + 3 * ix;
         uint2 t, u;
-        __builtin_memcpy(&t, p, 8);
-        __builtin_memcpy(&u, p + stride, 8);
+        __builtin_memcpy(&t, p + (size_t)y0 * stride, 8);
+        __builtin_memcpy(&u, p + (size_t)y1 * stride, 8);
         int t0 = t.x & 0xff, t1 = (t.x >> 8) & 0xff, t2 = (t.x >> 16) & 0xff;
         int t3 = t.x >> 24, t4 = t.y & 0xff, t5 = (t.y >> 8) & 0xff;
         int u0 = u.x & 0xff, u1 = (u.x >> 8) & 0xff, u2 = (u.x >> 16) & 0xff;
@@ -117,46 +135,66 @@ __device__ __forceinline__ void apply_gain(const WarpCam& c, int x, int y, int v
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: fused warp of every camera's bordered feed() tile.  grid = (ceil(tw/128), ceil(th/4), ncam),
-// block = (64,4): one wave per tile row segment, 2 adjacent pixels per lane -> each lane stores
-// 12 contiguous bytes (3 dwords), a wave stores 768 contiguous bytes.
+// K1: fused warp of every camera's bordered feed() tile.  grid = (ceil(tw/256), ceil(th/4), ncam),
+// block = (64,4): one wave per tile-row segment, 4 adjacent pixels per lane.  Output is planar u8
+// (B, G, R planes): each lane stores one dword per plane, a wave stores 3 x 256 contiguous bytes.
+// Four independent tap fetches per lane are in flight together (latency hiding by ILP).
 // ------------------------------------------------------------------------------------------------
+template <int ABL>
 __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
     const WarpCam& c = P.cam[blockIdx.z];
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 2;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x0 >= c.tw || y >= c.th) return;
     float m[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) m[i] = c.m[i];
     const float2 B = c.rowB[y];
-    int v[2][3];
+    // colA is padded to a multiple of 4 entries: two 16-byte loads
+    const float4 a01 = *reinterpret_cast<const float4*>(c.colA + x0);
+    const float4 a23 = *reinterpret_cast<const float4*>(c.colA + x0 + 2);
+    const float2 A[4] = {make_float2(a01.x, a01.y), make_float2(a01.z, a01.w), make_float2(a23.x, a23.y),
+                         make_float2(a23.z, a23.w)};
+    int v[4][3];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        int x = min(x0 + j, c.tw - 1);
+    for (int j = 0; j < 4; j++) {
         float fx, fy;
-        map_backward(m, c.colA[x], B, fx, fy);
-        sample_bilinear_reflect(c.src, c.src_w, c.src_h, c.src_stride, fx, fy, v[j]);
-        if (c.gain) apply_gain(c, x, y, v[j]);
+        if (ABL == 3) {  // diagnostic: no projection arithmetic
+            fx = (float)(x0 + j) * 0.9f + A[j].x;
+            fy = (float)y * 0.9f + B.x;
+        } else {
+            map_backward(m, A[j], B, fx, fy);
+        }
+        sample_bilinear_reflect<ABL>(c.src, c.src_w, c.src_h, c.src_stride, fx, fy, v[j]);
     }
-    int16_t* row = (int16_t*)c.dst + ((size_t)y * c.dst_pitch + x0) * 3;
-    if (x0 + 1 < c.tw) {
-        uint3 pk;
-        pk.x = (unsigned)v[0][0] | ((unsigned)v[0][1] << 16);
-        pk.y = (unsigned)v[0][2] | ((unsigned)v[1][0] << 16);
-        pk.z = (unsigned)v[1][1] | ((unsigned)v[1][2] << 16);
-        *reinterpret_cast<uint3*>(row) = pk;
-    } else {
-        row[0] = (int16_t)v[0][0];
-        row[1] = (int16_t)v[0][1];
-        row[2] = (int16_t)v[0][2];
+    if (c.gain) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) apply_gain(c, min(x0 + j, c.tw - 1), y, v[j]);
+    }
+    uint8_t* d = (uint8_t*)c.dst + (size_t)y * c.dst_pitch + x0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        unsigned pk = (unsigned)v[0][ch] | ((unsigned)v[1][ch] << 8) | ((unsigned)v[2][ch] << 16) | ((unsigned)v[3][ch] << 24);
+        if (ABL == 4 && pk != 0x12345678u) continue;  // diagnostic: no stores
+        *reinterpret_cast<unsigned*>(d + (size_t)ch * c.dst_plane) = pk;  // rows are padded to 16 bytes
     }
 }
 
 void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hipStream_t s) {
     dim3 block(64, 4, 1);
-    dim3 grid((max_tw + 127) / 128, (max_th + 3) / 4, ncam);
-    hipLaunchKernelGGL(warp_tiles_kernel, grid, block, 0, s, p);
+    dim3 grid((max_tw + 255) / 256, (max_th + 3) / 4, ncam);
+#ifdef PANO_DIAG
+    // diagnostic build only (libpano_hip_diag.so): ablation variants for profiling, never shipped
+    static const int abl = getenv("PANO_WARP_ABL") ? atoi(getenv("PANO_WARP_ABL")) : 0;
+    switch (abl) {
+        case 1: hipLaunchKernelGGL(warp_tiles_kernel<1>, grid, block, 0, s, p); return;
+        case 2: hipLaunchKernelGGL(warp_tiles_kernel<2>, grid, block, 0, s, p); return;
+        case 3: hipLaunchKernelGGL(warp_tiles_kernel<3>, grid, block, 0, s, p); return;
+        case 4: hipLaunchKernelGGL(warp_tiles_kernel<4>, grid, block, 0, s, p); return;
+        default: break;
+    }
+#endif
+    hipLaunchKernelGGL(warp_tiles_kernel<0>, grid, block, 0, s, p);
 }
 
 // stage entry: RotationWarper::warp to an 8UC3 image (no border, byte pitch)
@@ -196,36 +234,90 @@ void launch_warp_mask(const WarpCam& c, uint8_t* dst, int dst_stride, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: pyrDown CV_16S x3, REFLECT_101, (v+128)>>8.  One thread per output pixel.
+// K2: pyrDown (cv::pyrDown CV_16S semantics: 5x5 [1 4 6 4 1]^2, REFLECT_101, (v+128)>>8) on planar u8.
+// One thread = 4 x 2 output pixels of one plane: 7 input rows x one 16-byte load, the horizontal 5-tap as
+// v_dot4_u32_u8 on byte windows, the vertical pass in registers.  grid.z = camera * 3 + plane.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pyr_down_hrow(const uint4 q, int h[4]) {
+    // q = 16 bytes starting at column 8t-4; the four outputs are centred on columns 8t, 8t+2, 8t+4, 8t+6
+    const unsigned w0 = __builtin_amdgcn_alignbyte(q.y, q.x, 2);  // bytes 2..5
+    const unsigned w2 = __builtin_amdgcn_alignbyte(q.z, q.y, 2);  // bytes 6..9
+    const unsigned K = 0x04060401u;                               // taps 1,4,6,4 (little endian) + the 5th tap
+    h[0] = (int)__builtin_amdgcn_udot4(w0, K, (q.y >> 16) & 0xffu, false);
+    h[1] = (int)__builtin_amdgcn_udot4(q.y, K, q.z & 0xffu, false);
+    h[2] = (int)__builtin_amdgcn_udot4(w2, K, (q.z >> 16) & 0xffu, false);
+    h[3] = (int)__builtin_amdgcn_udot4(q.z, K, q.w & 0xffu, false);
+}
 __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam_bits, int l) {
-    if (!((cam_bits >> blockIdx.z) & 1u)) return;
-    const PyrCam& c = P.cam[blockIdx.z];
+    const int ci = blockIdx.z / 3, pl = blockIdx.z - ci * 3;
+    if (!((cam_bits >> ci) & 1u)) return;
+    const PyrCam& c = P.cam[ci];
     const int sw = c.w0 >> l, sh = c.h0 >> l;
     const int dw = sw >> 1, dh = sh >> 1;
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= dw || y >= dh) return;
-    const int16_t* __restrict__ src = c.lvl[l];
-    const int sp = c.pitch[l] * 3;
-    int xs[5];
+    const int t = blockIdx.x * 64 + threadIdx.x;      // group of 4 output columns
+    const int y0 = (blockIdx.y * 4 + threadIdx.y) * 2;  // pair of output rows
+    if (t * 4 >= dw || y0 >= dh) return;
+    const uint8_t* __restrict__ src = c.lvl[l] + (size_t)pl * c.plane[l];
+    const int sp = c.pitch[l];
+    // Every lane does seven 16-byte loads (columns 8t-4 .. 8t+11; lane 0 loads columns 0..15 and shifts).
+    // REFLECT_101 at the two row ends touches at most three bytes, patched in registers:
+    //   left  (t == 0): columns -2, -1 are columns 2, 1
+    //   right (8t+8 == sw, the last group): column sw is column sw-2
+    int acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
+    const int off = t == 0 ? 0 : 8 * t - 4;
+    uint4 q[7];
 #pragma unroll
-    for (int k = 0; k < 5; k++) xs[k] = reflect101_idx(2 * x + k - 2, sw) * 3;
-    int acc[3] = {0, 0, 0};
+    for (int r = 0; r < 7; r++)
+        q[r] = *reinterpret_cast<const uint4*>(src + (size_t)reflect101_idx(2 * y0 - 2 + r, sh) * sp + off);
+    if (t == 0) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int16_t* r = src + (size_t)reflect101_idx(2 * y + k - 2, sh) * sp;
-        const int wy = (k == 2) ? 6 : ((k == 1 || k == 3) ? 4 : 1);
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            int h = r[xs[2] + ch] * 6 + (r[xs[1] + ch] + r[xs[3] + ch]) * 4 + r[xs[0] + ch] + r[xs[4] + ch];
-            acc[ch] += h * wy;
+        for (int r = 0; r < 7; r++) {
+            const unsigned a = q[r].x;
+            q[r].w = q[r].z;
+            q[r].z = q[r].y;
+            q[r].y = a;
+            // byte2 = column -2 = column 2 (column 0 when the row has only two), byte3 = column -1 = column 1
+            q[r].x = (sw > 2 ? (a & 0x00ff0000u) : ((a & 0xffu) << 16)) | ((a & 0x0000ff00u) << 16);
         }
     }
-    int16_t* d = c.lvl[l + 1] + ((size_t)y * c.pitch[l + 1] + x) * 3;
-    d[0] = (int16_t)sat16i((acc[0] + 128) >> 8);
-    d[1] = (int16_t)sat16i((acc[1] + 128) >> 8);
-    d[2] = (int16_t)sat16i((acc[2] + 128) >> 8);
+    const int ksw = sw - (8 * t - 4);  // byte position of column sw in the 16-byte window
+    if (ksw <= 12) {
+        // ksw is even (sw and 8t-4 are even) and >= 6: the source byte ksw-2 sits in the same or the previous dword
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            unsigned d[4] = {q[r].x, q[r].y, q[r].z, q[r].w};
+            const int ks = ksw - 2;
+            unsigned v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((ks >> 2) == j) v = (d[j] >> (8 * (ks & 3))) & 0xffu;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((ksw >> 2) == j) d[j] = (d[j] & ~(0xffu << (8 * (ksw & 3)))) | (v << (8 * (ksw & 3)));
+            q[r] = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        int h[4];
+        pyr_down_hrow(q[r], h);
+        const int wa = r == 0 ? 1 : (r == 1 ? 4 : (r == 2 ? 6 : (r == 3 ? 4 : (r == 4 ? 1 : 0))));
+        const int wb = r == 2 ? 1 : (r == 3 ? 4 : (r == 4 ? 6 : (r == 5 ? 4 : (r == 6 ? 1 : 0))));
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            acc0[j] += h[j] * wa;
+            acc1[j] += h[j] * wb;
+        }
+    }
+    uint8_t* d = c.lvl[l + 1] + (size_t)pl * c.plane[l + 1] + (size_t)y0 * c.pitch[l + 1] + 4 * t;
+    unsigned p0 = 0, p1 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        p0 |= (unsigned)min((acc0[j] + 128) >> 8, 255) << (8 * j);
+        p1 |= (unsigned)min((acc1[j] + 128) >> 8, 255) << (8 * j);
+    }
+    *reinterpret_cast<unsigned*>(d) = p0;  // rows are padded to 16 bytes
+    if (y0 + 1 < dh) *reinterpret_cast<unsigned*>(d + c.pitch[l + 1]) = p1;
 }
 
 void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s) {
@@ -236,17 +328,17 @@ void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s
             mh = max(mh, p.cam[i].h0 >> (l + 1));
         }
     if (mw == 0 || mh == 0) return;
-    dim3 block(64, 4, 1), grid((mw + 63) / 64, (mh + 3) / 4, p.ncam);
+    dim3 block(64, 4, 1), grid((mw + 255) / 256, (mh + 7) / 8, p.ncam * 3);
     hipLaunchKernelGGL(pyr_down_kernel, grid, block, 0, s, p, cam_bits, l);
 }
 
 // ------------------------------------------------------------------------------------------------
-// pyrUp CV_16S x3 sampled at one destination pixel (X, Y) of an exactly-2x image:
+// pyrUp (cv::pyrUp CV_16S semantics) sampled at one destination pixel (X, Y) of an exactly-2x plane:
 // even: s[x-1] + 6 s[x] + s[x+1], odd: 4 (s[x] + s[x+1]); left/top reflect-101, right/bottom
-// replicate; (v + 32) >> 6, saturate.
+// replicate; (v + 32) >> 6, saturate.  T = uint8_t (camera Gaussian planes) or int16_t (canvas planes).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pyr_up_px(const int16_t* __restrict__ S, int n, int m, int pitch, int X, int Y,
-                                          int out[3]) {
+template <typename T>
+__device__ __forceinline__ int pyr_up_px(const T* __restrict__ S, int n, int m, int pitch, int X, int Y) {
     const int x = X >> 1, y = Y >> 1;
     int xi[3], wx[3], yi[3], wy[3];
     if (!(X & 1)) {
@@ -263,29 +355,30 @@ __device__ __forceinline__ void pyr_up_px(const int16_t* __restrict__ S, int n, 
         yi[0] = y; yi[1] = min(y + 1, m - 1); yi[2] = y;
         wy[0] = 4; wy[1] = 4; wy[2] = 0;
     }
-    int acc[3] = {0, 0, 0};
+    int acc = 0;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-        const int16_t* r = S + (size_t)yi[j] * pitch * 3;
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            int h = r[xi[0] * 3 + ch] * wx[0] + r[xi[1] * 3 + ch] * wx[1] + r[xi[2] * 3 + ch] * wx[2];
-            acc[ch] += h * wy[j];
-        }
+        const T* r = S + (size_t)yi[j] * pitch;
+        acc += ((int)r[xi[0]] * wx[0] + (int)r[xi[1]] * wx[1] + (int)r[xi[2]] * wx[2]) * wy[j];
     }
-    out[0] = sat16i((acc[0] + 32) >> 6);
-    out[1] = sat16i((acc[1] + 32) >> 6);
-    out[2] = sat16i((acc[2] + 32) >> 6);
+    return sat16i((acc + 32) >> 6);
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: one level of the blend, one thread per canvas pixel.
+// K3 (generic form, any alignment): one level of the blend, one thread per canvas pixel.
 //   acc  = sum over cameras in feed order of (short)(lap * w)          (wrapping short add)
 //   lap  = sat16(G_l - pyrUp(G_{l+1}))  (top level: G_l)
+//   W    = sum over cameras in feed order of w                          (dst_band_weights)
 //   norm = (short)(acc / (W + 1e-5f))
 //   out  = sat16(norm + pyrUp(out_{l+1}))                                (top level: norm)
 // level 0 applies dst_mask (W0 > eps), convertTo(CV_8U) and the cut, and writes the panorama.
+// Cameras whose weight is exactly 0 at the pixel add (short)(lap*0) = 0 and +0.f: they are skipped.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cam_weight(const PyrCam& c, int l, int x, int y) {
+    if (l == 0) return (float)c.mask0[(size_t)y * c.pitch[0] + x] * (float)(1. / 255.);
+    return c.wgt[l][(size_t)y * c.wpitch[l] + x];
+}
+
 __global__ __launch_bounds__(256) void blend_level_kernel(PyrParams P, CanvasParams C, int l) {
     const int cw = C.w0 >> l, ch = C.h0 >> l;
     int X = blockIdx.x * 64 + threadIdx.x;
@@ -297,42 +390,57 @@ __global__ __launch_bounds__(256) void blend_level_kernel(PyrParams P, CanvasPar
     } else if (X >= cw || Y >= ch) {
         return;
     }
+    // phase A: every load that does not depend on another load - all cameras' weights and the coarser
+    // canvas level - is issued together (these levels are latency bound, not bandwidth bound)
+    float wv[kCams];
+#pragma unroll
+    for (int i = 0; i < kCams; i++) {
+        wv[i] = 0.f;
+        if (i < P.ncam) {
+            const PyrCam& c = P.cam[i];
+            const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
+            if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l)) wv[i] = cam_weight(c, l, x, y);
+        }
+    }
+    int cup[3] = {0, 0, 0};
+    if (l < C.bands) {
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            cup[k] = pyr_up_px<int16_t>(C.img[l + 1] + (size_t)k * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X, Y);
+    }
+    // phase B: cameras with a non-zero weight (one in the interior, two or three on a seam)
     int acc[3] = {0, 0, 0};
-    for (int i = 0; i < P.ncam; i++) {
+    float W = 0.f;
+#pragma unroll
+    for (int i = 0; i < kCams; i++) {
+        const float w = wv[i];
+        if (w == 0.f) continue;
         const PyrCam& c = P.cam[i];
         const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
         const int tw = c.w0 >> l, th = c.h0 >> l;
-        if ((unsigned)x >= (unsigned)tw || (unsigned)y >= (unsigned)th) continue;
-        const float w = c.wgt[l][(size_t)y * c.pitch[l] + x];
-        if (w == 0.f) continue;  // (short)(lap * 0) == 0
-        const int16_t* g = c.lvl[l] + ((size_t)y * c.pitch[l] + x) * 3;
-        int lap[3] = {g[0], g[1], g[2]};
-        if (l < C.bands) {
-            int up[3];
-            pyr_up_px(c.lvl[l + 1], tw >> 1, th >> 1, c.pitch[l + 1], x, y, up);
-            lap[0] = sat16i(lap[0] - up[0]);
-            lap[1] = sat16i(lap[1] - up[1]);
-            lap[2] = sat16i(lap[2] - up[2]);
-        }
+        W += w;
 #pragma unroll
-        for (int k = 0; k < 3; k++) acc[k] = (int16_t)(acc[k] + (int16_t)(int)((float)lap[k] * w));
+        for (int k = 0; k < 3; k++) {
+            const uint8_t* g = c.lvl[l] + (size_t)k * c.plane[l];
+            int lap = g[(size_t)y * c.pitch[l] + x];
+            if (l < C.bands)
+                lap = sat16i(lap - pyr_up_px<uint8_t>(c.lvl[l + 1] + (size_t)k * c.plane[l + 1], tw >> 1, th >> 1,
+                                                      c.pitch[l + 1], x, y));
+            acc[k] = (int16_t)(acc[k] + (int16_t)(int)((float)lap * w));
+        }
     }
-    const float W = C.wsum[l][(size_t)Y * cw + X];
     const float den = W + 1e-5f;
     int v[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) v[k] = (int16_t)(int)((float)acc[k] / den);
-    if (l < C.bands) {
-        int up[3];
-        pyr_up_px(C.img[l + 1], cw >> 1, ch >> 1, cw >> 1, X, Y, up);
-#pragma unroll
-        for (int k = 0; k < 3; k++) v[k] = sat16i(v[k] + up[k]);
+    for (int k = 0; k < 3; k++) {
+        // W == 1.0f: (short)(n / 1.00001f) == n - sign(n), see the vector kernel
+        if (W == 1.0f) v[k] = acc[k] - (acc[k] > 0) + (acc[k] < 0);
+        else v[k] = (int16_t)(int)((float)acc[k] / den);
+        if (l < C.bands) v[k] = sat16i(v[k] + cup[k]);
     }
     if (l > 0) {
-        int16_t* d = C.img[l] + ((size_t)Y * cw + X) * 3;
-        d[0] = (int16_t)v[0];
-        d[1] = (int16_t)v[1];
-        d[2] = (int16_t)v[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) C.img[l][(size_t)k * C.cplane[l] + (size_t)Y * C.cpitch[l] + X] = (int16_t)v[k];
     } else {
         const bool on = W > 1e-5f;
         uint8_t* d = C.out + (size_t)(Y - C.cut_y) * C.out_stride + 3 * (X - C.cut_x);
@@ -342,19 +450,283 @@ __global__ __launch_bounds__(256) void blend_level_kernel(PyrParams P, CanvasPar
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3 (vector form): one thread = 4 x 2 canvas pixels (X0 multiple of 4, Y0 even).  Used for levels where
+// every tile origin/size is a multiple of 4 x 2 at that level (C.fast[l]), i.e. all but the two coarsest.
+// Per camera and plane: 2 dword loads of G_l, 3 unaligned dword loads of G_{l+1} (the 4 x 3 coarse
+// neighbourhood serves all eight pyrUp samples).  Same arithmetic as the generic form.
+// ------------------------------------------------------------------------------------------------
+// horizontally upsample 4 coarse samples p[0..3] (columns x-1 .. x+2) to fine X0..X0+3 (X0 = 2x)
+__device__ __forceinline__ void up_h4(const int p[4], int o[4]) {
+    o[0] = p[0] + 6 * p[1] + p[2];
+    o[1] = 4 * (p[1] + p[2]);
+    o[2] = p[1] + 6 * p[2] + p[3];
+    o[3] = 4 * (p[2] + p[3]);
+}
+// the 4 x 3 coarse neighbourhood of a 4 x 2 fine block: rows y-1, y, y+1 (y = Y0/2), columns x-1 .. x+2
+template <typename T>
+__device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int m, int pitch, int x, int y,
+                                            int p[3][4]) {
+    const bool interior = x >= 1 && x + 2 <= n - 1;
+    int yi[3] = {y > 0 ? y - 1 : (m > 1 ? 1 : 0), y, min(y + 1, m - 1)};
+    if (interior) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const T* q = S + (size_t)yi[r] * pitch + (x - 1);
+            if (sizeof(T) == 1) {
+                unsigned d;
+                __builtin_memcpy(&d, q, 4);
+                p[r][0] = d & 0xff; p[r][1] = (d >> 8) & 0xff; p[r][2] = (d >> 16) & 0xff; p[r][3] = d >> 24;
+            } else {
+                uint2 d;
+                __builtin_memcpy(&d, q, 8);
+                p[r][0] = (int16_t)(d.x & 0xffff); p[r][1] = (int16_t)(d.x >> 16);
+                p[r][2] = (int16_t)(d.y & 0xffff); p[r][3] = (int16_t)(d.y >> 16);
+            }
+        }
+    } else {
+        int xi[4] = {x > 0 ? x - 1 : (n > 1 ? 1 : 0), x, min(x + 1, n - 1), min(x + 2, n - 1)};
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const T* q = S + (size_t)yi[r] * pitch;
+#pragma unroll
+            for (int k = 0; k < 4; k++) p[r][k] = (int)q[xi[k]];
+        }
+    }
+}
+// pyrUp of a 4 x 2 block: up[0][..] = fine row Y0 (even), up[1][..] = fine row Y0+1 (odd)
+__device__ __forceinline__ void up_block(const int p[3][4], int up[2][4]) {
+    int h[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; r++) up_h4(p[r], h[r]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        up[0][k] = sat16i((h[0][k] + 6 * h[1][k] + h[2][k] + 32) >> 6);
+        up[1][k] = sat16i((4 * (h[1][k] + h[2][k]) + 32) >> 6);
+    }
+}
+
+template <bool L0>
+__global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, CanvasParams C, int lvl) {
+    const int l = L0 ? 0 : lvl;
+    const int cw = C.w0 >> l, ch = C.h0 >> l;
+    // level 0 covers only the block-aligned hull of the cut rectangle
+    const int bx0 = L0 ? (C.cut_x & ~3) : 0, by0 = L0 ? (C.cut_y & ~1) : 0;
+    const int X0 = bx0 + (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int Y0 = by0 + (blockIdx.y * 4 + threadIdx.y) * 2;
+    if (L0) {
+        if (X0 >= C.cut_x + C.cut_w || Y0 >= C.cut_y + C.cut_h) return;
+    } else if (X0 >= cw || Y0 >= ch) {
+        return;
+    }
+    // phase A: which cameras carry weight on this 4 x 2 block.  All weight loads are issued together.
+    // Level 0 keeps the mask bytes (2 dwords per camera); coarser levels only keep the verdict and
+    // re-read the (cached) f32 weights in phase B, which costs no extra round trip.
+    unsigned mk[kCams][2];
+    unsigned live = 0;
+#pragma unroll
+    for (int i = 0; i < kCams; i++) {
+        mk[i][0] = mk[i][1] = 0;
+        if (i < P.ncam) {
+            const PyrCam& c = P.cam[i];
+            const int x = X0 - (c.tx >> l), y = Y0 - (c.ty >> l);
+            if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l)) {  // blocks never straddle a tile edge
+                if (L0) {
+                    mk[i][0] = *reinterpret_cast<const unsigned*>(c.mask0 + (size_t)y * c.pitch[0] + x);
+                    mk[i][1] = *reinterpret_cast<const unsigned*>(c.mask0 + (size_t)(y + 1) * c.pitch[0] + x);
+                } else {
+                    const float4 f0 = *reinterpret_cast<const float4*>(c.wgt[l] + (size_t)y * c.wpitch[l] + x);
+                    const float4 f1 = *reinterpret_cast<const float4*>(c.wgt[l] + (size_t)(y + 1) * c.wpitch[l] + x);
+                    mk[i][0] = (f0.x != 0.f) | (f0.y != 0.f) | (f0.z != 0.f) | (f0.w != 0.f) | (f1.x != 0.f) |
+                               (f1.y != 0.f) | (f1.z != 0.f) | (f1.w != 0.f);
+                }
+            }
+        }
+        if (mk[i][0] | mk[i][1]) live |= 1u << i;
+    }
+    // the coarser canvas level: early on the latency-bound small levels, late (fewer live registers) on level 0
+    int cp[3][3][4];
+    if (!L0 && l < C.bands) {
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+            load_coarse<int16_t>(C.img[l + 1] + (size_t)pl * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
+                                 Y0 >> 1, cp[pl]);
+    }
+    int acc[3][2][4];
+    float W[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            W[r][k] = 0.f;
+            acc[0][r][k] = acc[1][r][k] = acc[2][r][k] = 0;
+        }
+    // phase B: cameras with weight, in feed order
+#pragma unroll
+    for (int i = 0; i < kCams; i++) {
+        if (!((live >> i) & 1u)) continue;
+        const PyrCam& c = P.cam[i];
+        const int x = X0 - (c.tx >> l), y = Y0 - (c.ty >> l);
+        const int tw = c.w0 >> l, th = c.h0 >> l;
+        float w[2][4];
+        if (L0) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) w[r][k] = (float)((mk[i][r] >> (8 * k)) & 0xffu) * (float)(1. / 255.);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const float4 f = *reinterpret_cast<const float4*>(c.wgt[l] + (size_t)(y + r) * c.wpitch[l] + x);
+                w[r][0] = f.x; w[r][1] = f.y; w[r][2] = f.z; w[r][3] = f.w;
+            }
+        }
+        // away from the seams the weight is exactly 1.0f on the whole block: no float path
+        bool unit = true;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) unit &= w[r][k] == 1.0f;
+        // issue every load of this camera before using any
+        unsigned g0[3], g1[3];
+        int p[3][3][4];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const uint8_t* g = c.lvl[l] + (size_t)pl * c.plane[l] + (size_t)y * c.pitch[l] + x;
+            g0[pl] = *reinterpret_cast<const unsigned*>(g);
+            g1[pl] = *reinterpret_cast<const unsigned*>(g + c.pitch[l]);
+            if (l < C.bands)
+                load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)pl * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1], x >> 1,
+                                     y >> 1, p[pl]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) W[r][k] += w[r][k];  // + 0.f is exact
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            int up[2][4];
+            if (l < C.bands) {
+                up_block(p[pl], up);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) up[0][k] = up[1][k] = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int l0 = sat16i((int)((g0[pl] >> (8 * k)) & 0xffu) - up[0][k]);
+                const int l1 = sat16i((int)((g1[pl] >> (8 * k)) & 0xffu) - up[1][k]);
+                if (unit) {  // (short)(lap * 1.0f) == lap
+                    acc[pl][0][k] = (int16_t)(acc[pl][0][k] + l0);
+                    acc[pl][1][k] = (int16_t)(acc[pl][1][k] + l1);
+                } else {
+                    acc[pl][0][k] = (int16_t)(acc[pl][0][k] + (int16_t)(int)((float)l0 * w[0][k]));
+                    acc[pl][1][k] = (int16_t)(acc[pl][1][k] + (int16_t)(int)((float)l1 * w[1][k]));
+                }
+            }
+        }
+    }
+    if (L0 && l < C.bands) {
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+            load_coarse<int16_t>(C.img[l + 1] + (size_t)pl * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
+                                 Y0 >> 1, cp[pl]);
+    }
+    // (short)(n / (1.0f + 1e-5f)) == n - sign(n) for every int16 n: the quotient lies strictly between
+    // |n|-1 and |n| (|n| * 1e-5 < 1, and far more than an ulp of n), and the cast truncates toward zero.
+    // So where the summed weight is exactly 1.0f (everywhere but the seams) no division is needed.
+    bool unitW = true;
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) unitW &= W[r][k] == 1.0f;
+    int v[3][2][4];
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) {
+        int up[2][4];
+        if (l < C.bands) {
+            up_block(cp[pl], up);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) up[0][k] = up[1][k] = 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int a = acc[pl][r][k];
+                int nrm;
+                if (unitW) nrm = a - (a > 0) + (a < 0);
+                else nrm = (int16_t)(int)((float)a / (W[r][k] + 1e-5f));
+                v[pl][r][k] = l < C.bands ? sat16i(nrm + up[r][k]) : nrm;
+            }
+    }
+    if (!L0) {
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                uint2 pk;
+                pk.x = ((unsigned)v[pl][r][0] & 0xffffu) | ((unsigned)v[pl][r][1] << 16);
+                pk.y = ((unsigned)v[pl][r][2] & 0xffffu) | ((unsigned)v[pl][r][3] << 16);
+                *reinterpret_cast<uint2*>(C.img[l] + (size_t)pl * C.cplane[l] + (size_t)(Y0 + r) * C.cpitch[l] + X0) = pk;
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int Y = Y0 + r;
+            if (Y < C.cut_y || Y >= C.cut_y + C.cut_h) continue;
+            unsigned b[12];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool on = W[r][k] > 1e-5f;
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) b[3 * k + pl] = on ? (unsigned)sat8i(v[pl][r][k]) : 0u;
+            }
+            uint8_t* d = C.out + (size_t)(Y - C.cut_y) * C.out_stride + 3 * (X0 - C.cut_x);
+            const bool whole = X0 >= C.cut_x && X0 + 4 <= C.cut_x + C.cut_w;
+            if (whole && (((size_t)d) & 3) == 0) {
+                uint3 pk;
+                pk.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                pk.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                pk.z = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+                *reinterpret_cast<uint3*>(d) = pk;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (X0 + k >= C.cut_x && X0 + k < C.cut_x + C.cut_w) {
+                        d[3 * k] = (uint8_t)b[3 * k];
+                        d[3 * k + 1] = (uint8_t)b[3 * k + 1];
+                        d[3 * k + 2] = (uint8_t)b[3 * k + 2];
+                    }
+            }
+        }
+    }
+}
+
 void launch_blend_level(const PyrParams& p, const CanvasParams& c, int l, hipStream_t s) {
+    if (c.fast[l]) {
+        int w, h;
+        if (l == 0) {
+            w = c.cut_x + c.cut_w - (c.cut_x & ~3);
+            h = c.cut_y + c.cut_h - (c.cut_y & ~1);
+        } else {
+            w = c.w0 >> l;
+            h = c.h0 >> l;
+        }
+        dim3 block(64, 4, 1), grid((w + 255) / 256, (h + 7) / 8, 1);
+        if (l == 0) hipLaunchKernelGGL(blend_level_vec_kernel<true>, grid, block, 0, s, p, c, l);
+        else hipLaunchKernelGGL(blend_level_vec_kernel<false>, grid, block, 0, s, p, c, l);
+        return;
+    }
     int w = l == 0 ? c.cut_w : (c.w0 >> l), h = l == 0 ? c.cut_h : (c.h0 >> l);
     dim3 block(64, 4, 1), grid((w + 63) / 64, (h + 3) / 4, 1);
     hipLaunchKernelGGL(blend_level_kernel, grid, block, 0, s, p, c, l);
 }
 
-// Blender::NO: Blender::feed masked copy in feed order, Blender::blend zeroing, convertTo(8U), cut
-struct NoBlendArgs {
-    const uint8_t* mask[kCams];
-    int mpitch[kCams];
-    int rx[kCams], ry[kCams], rw[kCams], rh[kCams];
-};
-__global__ __launch_bounds__(256) void no_blend_kernel(PyrParams P, NoBlendArgs A, CanvasParams C) {
+// Blender::NO: Blender::feed masked copy in feed order, Blender::blend zeroing, convertTo(8U), cut.
+// The level-0 tile is the ROI itself (no border) and mask0 the blend mask.
+__global__ __launch_bounds__(256) void no_blend_kernel(PyrParams P, CanvasParams C) {
     int X = blockIdx.x * 64 + threadIdx.x;
     int Y = blockIdx.y * 4 + threadIdx.y;
     if (X >= C.cut_w || Y >= C.cut_h) return;
@@ -362,26 +734,21 @@ __global__ __launch_bounds__(256) void no_blend_kernel(PyrParams P, NoBlendArgs 
     Y += C.cut_y;
     int v[3] = {0, 0, 0};
     for (int i = 0; i < P.ncam; i++) {
-        const int x = X - A.rx[i], y = Y - A.ry[i];
-        if ((unsigned)x >= (unsigned)A.rw[i] || (unsigned)y >= (unsigned)A.rh[i]) continue;
-        if (!A.mask[i][(size_t)y * A.mpitch[i] + x]) continue;
-        const int16_t* g = P.cam[i].lvl[0] + ((size_t)y * P.cam[i].pitch[0] + x) * 3;
-        v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
+        const PyrCam& c = P.cam[i];
+        const int x = X - c.tx, y = Y - c.ty;
+        if ((unsigned)x >= (unsigned)c.w0 || (unsigned)y >= (unsigned)c.h0) continue;
+        if (!c.mask0[(size_t)y * c.pitch[0] + x]) continue;
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = c.lvl[0][(size_t)k * c.plane[0] + (size_t)y * c.pitch[0] + x];
     }
     uint8_t* d = C.out + (size_t)(Y - C.cut_y) * C.out_stride + 3 * (X - C.cut_x);
-    d[0] = (uint8_t)sat8i(v[0]);
-    d[1] = (uint8_t)sat8i(v[1]);
-    d[2] = (uint8_t)sat8i(v[2]);
+    d[0] = (uint8_t)v[0];
+    d[1] = (uint8_t)v[1];
+    d[2] = (uint8_t)v[2];
 }
-void launch_no_blend(const PyrParams& p, const uint8_t* const* masks, const int* mask_pitch, const int* roi_x,
-                     const int* roi_y, const int* roi_w, const int* roi_h, const CanvasParams& c, hipStream_t s) {
-    NoBlendArgs a;
-    for (int i = 0; i < p.ncam; i++) {
-        a.mask[i] = masks[i]; a.mpitch[i] = mask_pitch[i];
-        a.rx[i] = roi_x[i]; a.ry[i] = roi_y[i]; a.rw[i] = roi_w[i]; a.rh[i] = roi_h[i];
-    }
+void launch_no_blend(const PyrParams& p, const CanvasParams& c, hipStream_t s) {
     dim3 block(64, 4, 1), grid((c.cut_w + 63) / 64, (c.cut_h + 3) / 4, 1);
-    hipLaunchKernelGGL(no_blend_kernel, grid, block, 0, s, p, a, c);
+    hipLaunchKernelGGL(no_blend_kernel, grid, block, 0, s, p, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -389,19 +756,21 @@ void launch_no_blend(const PyrParams& p, const uint8_t* const* masks, const int*
 // canvas sum in feed order
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_to_weight_kernel(const uint8_t* mask, int mw, int mh, int mpitch, int left,
-                                                             int top, float* w0, int tw, int th, int pitch) {
+                                                             int top, float* w0, int wpitch, uint8_t* m0, int mpitch0,
+                                                             int tw, int th) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= tw || y >= th) return;
     const int sx = x - left, sy = y - top;
-    float v = 0.f;
-    if ((unsigned)sx < (unsigned)mw && (unsigned)sy < (unsigned)mh)
-        v = (float)mask[(size_t)sy * mpitch + sx] * (float)(1. / 255.);
-    w0[(size_t)y * pitch + x] = v;
+    uint8_t mv = 0;
+    if ((unsigned)sx < (unsigned)mw && (unsigned)sy < (unsigned)mh) mv = mask[(size_t)sy * mpitch + sx];
+    m0[(size_t)y * mpitch0 + x] = mv;
+    w0[(size_t)y * wpitch + x] = (float)mv * (float)(1. / 255.);
 }
-void launch_mask_to_weight(const uint8_t* mask, int mw, int mh, int mpitch, int left, int top, float* w0, int tw,
-                           int th, int pitch, hipStream_t s) {
+void launch_mask_to_weight(const uint8_t* mask, int mw, int mh, int mpitch, int left, int top, float* w0, int wpitch,
+                           uint8_t* m0, int mpitch0, int tw, int th, hipStream_t s) {
     dim3 block(64, 4, 1), grid((tw + 63) / 64, (th + 3) / 4, 1);
-    hipLaunchKernelGGL(mask_to_weight_kernel, grid, block, 0, s, mask, mw, mh, mpitch, left, top, w0, tw, th, pitch);
+    hipLaunchKernelGGL(mask_to_weight_kernel, grid, block, 0, s, mask, mw, mh, mpitch, left, top, w0, wpitch, m0, mpitch0,
+                       tw, th);
 }
 
 __global__ __launch_bounds__(256) void pyr_down_f32_kernel(const float* __restrict__ src, int sw, int sh, int spitch,
@@ -434,7 +803,7 @@ __global__ __launch_bounds__(256) void sum_weights_kernel(PyrParams P, int l, fl
         const PyrCam& c = P.cam[i];
         const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
         if ((unsigned)x >= (unsigned)(c.w0 >> l) || (unsigned)y >= (unsigned)(c.h0 >> l)) continue;
-        W += c.wgt[l][(size_t)y * c.pitch[l] + x];
+        W += c.wgt[l][(size_t)y * c.wpitch[l] + x];
     }
     wsum[(size_t)Y * cw + X] = W;
 }

@@ -18,9 +18,10 @@ struct WarpCam {
     float m[9];           // k_rinv = K * R^-1 (Projector::k_rinv)
     const float2* colA;   // [tw] {sin(u/s), cos(u/s)} with the REFLECT border of feed() folded in
     const float2* rowB;   // [th] {sin(pi - v/s) | 1, cos(pi - v/s) | v/s}
-    void* dst;            // int16x3 level-0 tile (pipeline) or uint8x3 image (stage warp)
+    void* dst;            // pipeline: plane B of the level-0 tile (planar u8); stage warp: uint8x3 image
     int tw, th;           // tile width/height in pixels
-    int dst_pitch;        // pipeline: pixels per row; stage warp: bytes per row
+    int dst_pitch;        // bytes per row
+    int dst_plane;        // pipeline: bytes between the B, G, R planes
     // optional exposure gain (BlocksGainCompensator::apply): bilinear resize of a block map on the fly
     const float* gain;    // [gh][gw] block gains or nullptr
     const int2* gcol;     // [tw] {sx, sx1}   (REFLECT folded like colA)
@@ -33,12 +34,17 @@ struct WarpParams {
     WarpCam cam[kCams];
 };
 
-// one camera's pyramid slot
+// one camera's pyramid slot.  Every Gaussian level of an 8-bit image stays in [0,255], so the levels are
+// stored as PLANAR uint8 (B plane, G plane, R plane): half the bytes of OpenCV's CV_16SC3 and
+// dword-vectorisable stencils; the widening to int16 happens in registers where the Laplacian is formed.
 struct PyrCam {
-    int16_t* lvl[kLevels];     // Gaussian levels, int16x3 interleaved
-    const float* wgt[kLevels]; // weight levels f32 (level 0 included)
+    uint8_t* lvl[kLevels];     // plane B of each Gaussian level; plane c at + c * plane[l]
+    int pitch[kLevels];        // bytes per row (multiple of 16)
+    int plane[kLevels];        // bytes per plane
+    const uint8_t* mask0;      // level-0 weight source: blend mask with the CONSTANT 0 border of feed(), tile sized, pitch[0]
+    const float* wgt[kLevels]; // f32 weight levels (level 0 = mask0 * (1/255.f), kept for the pyrDown chain)
+    int wpitch[kLevels];       // floats per row
     int w0, h0;                // level-0 tile size (multiples of 2^bands)
-    int pitch[kLevels];        // pixels per row of each level
     int tx, ty;                // tile origin in the padded canvas (level 0)
 };
 struct PyrParams {
@@ -47,8 +53,10 @@ struct PyrParams {
 };
 
 struct CanvasParams {
-    int16_t* img[kLevels];     // collapsed canvas levels (level 0 is never materialised)
-    const float* wsum[kLevels];// summed weights per level
+    int16_t* img[kLevels];     // collapsed canvas levels, planar int16 (level 0 is never materialised)
+    int cpitch[kLevels];       // int16 elements per row
+    int cplane[kLevels];       // int16 elements per plane
+    int fast[kLevels];         // 1: every tile origin / size of this level is 4x2 aligned -> vector kernel
     int w0, h0;                // padded canvas size
     int bands;
     // final output
@@ -71,13 +79,11 @@ void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s
 // level 0 writes the cut 8U panorama
 void launch_blend_level(const PyrParams& p, const CanvasParams& c, int l, hipStream_t s);
 // Blender::NO path
-void launch_no_blend(const PyrParams& p, const uint8_t* const* masks, const int* mask_pitch,
-                     const int* roi_x, const int* roi_y, const int* roi_w, const int* roi_h,
-                     const CanvasParams& c, hipStream_t s);
+void launch_no_blend(const PyrParams& p, const CanvasParams& c, hipStream_t s);
 
 // weights (run when masks change)
 void launch_mask_to_weight(const uint8_t* mask, int mw, int mh, int mpitch, int left, int top,
-                           float* w0, int tw, int th, int pitch, hipStream_t s);
+                           float* w0, int wpitch, uint8_t* m0, int mpitch0, int tw, int th, hipStream_t s);
 void launch_pyr_down_f32(const float* src, int sw, int sh, int spitch, float* dst, int dpitch, hipStream_t s);
 void launch_sum_weights(const PyrParams& p, int l, float* wsum, int cw, int ch, hipStream_t s);
 

@@ -150,7 +150,9 @@ pano_status pano_get_stage_ms(pano_ctx* ctx, float ms[PANO_NUM_STAGES]);
  * never waits for the GPU; launches[k] = number of stage-k intervals summed into total_ms[k] */
 pano_status pano_get_stage_stats(pano_ctx* ctx, double total_ms[PANO_NUM_STAGES],
                                  uint64_t launches[PANO_NUM_STAGES], int reset);
-/* algorithmic bytes of the warp kernel per compose: sum_cams (W*H*3 + Wt*Ht*6) and its launch shape */
+/* algorithmic bytes of the warp kernel per compose: sum_cams (W*H*3 read once + Wt*Ht*3 written once:
+ * the bordered level-0 tile is stored as planar u8, the 8U->16S widening of ocvstitcher.hpp:1180 happens
+ * in registers downstream) */
 pano_status pano_get_warp_bytes(const pano_ctx* ctx, uint64_t* src_bytes, uint64_t* dst_bytes);
 
 /* ---- stage inspection (parity tests) ------------------------------------------------------- */

@@ -54,7 +54,7 @@ def test_plan_matches_oracle(pano, po, c1, name, kind, bands):
     assert ctx.output_size() == b.dst_roi_final()[2:]
     src, dst = ctx.warp_bytes()
     assert src == d["n"] * d["w"] * d["h"] * 3
-    assert dst == sum(ctx.feed_tile(i)[0][2] * ctx.feed_tile(i)[0][3] * 6 for i in range(d["n"]))
+    assert dst == sum(ctx.feed_tile(i)[0][2] * ctx.feed_tile(i)[0][3] * 3 for i in range(d["n"]))
 
 
 def test_band_rule_and_cut(pano, po, c1, rig_r):
