@@ -174,7 +174,7 @@ def main():
                     traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"kernel": "warp_tiles_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+            roofline = {"kernel": "warp_tiles_lut_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                         "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": NG}

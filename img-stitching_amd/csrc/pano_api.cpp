@@ -61,6 +61,9 @@ struct pano_ctx {
     int wpitch[kMaxCams][kMaxLevels] = {};
     float* wgt[kMaxCams][kMaxLevels] = {};
     uint8_t* mask0[kMaxCams] = {};  // level-0 tile-sized mask with the CONSTANT border of feed()
+    uint32_t* lut[kMaxCams] = {};   // static remap tables of K1 (frames <= 2048 x 2048)
+    int lut_pitch[kMaxCams] = {};
+    bool use_lut = true;
     float* wsum[kMaxLevels] = {};
     int16_t* canvas[kMaxLevels] = {};
 
@@ -127,7 +130,7 @@ void dfree(T*& p) {
 void free_device(pano_ctx* c) {
     for (int i = 0; i < kMaxCams; i++) {
         dfree(c->colA[i]); dfree(c->rowB[i]); dfree(c->colA_roi[i]); dfree(c->rowB_roi[i]);
-        dfree(c->mask[i]); dfree(c->gain[i]); dfree(c->mask0[i]);
+        dfree(c->mask[i]); dfree(c->gain[i]); dfree(c->mask0[i]); dfree(c->lut[i]);
         dfree(c->gcol[i]); dfree(c->grow[i]); dfree(c->gcol_roi[i]); dfree(c->grow_roi[i]);
         dfree(c->gcolw[i]); dfree(c->groww[i]); dfree(c->gcolw_roi[i]); dfree(c->groww_roi[i]);
         dfree(c->stage_in[i]);
@@ -165,6 +168,8 @@ WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t strid
         w.dst = c->pyr_base + (size_t)i * c->slot_bytes + c->lvl_off[i][0];
         w.dst_pitch = c->lvl_pitch[i][0];
         w.dst_plane = c->lvl_plane[i][0];
+        w.lut = c->use_lut ? c->lut[i] : nullptr;
+        w.lut_pitch = c->lut_pitch[i];
         w.gcol = c->gcol[i]; w.gcolw = c->gcolw[i]; w.grow = c->grow[i]; w.groww = c->groww[i];
     }
     w.gain = c->gain[i];
@@ -504,6 +509,19 @@ pano_status pano_prepare(pano_ctx* c) {
         c->cv.cplane[l] = c->cv.cpitch[l] * ch;
         HIP_TRY(c, hipMalloc((void**)&c->wsum[l], (size_t)cw * ch * sizeof(float)));
         if (l > 0) HIP_TRY(c, hipMalloc((void**)&c->canvas[l], (size_t)c->cv.cplane[l] * 3 * sizeof(int16_t) + 256));
+    }
+    // static remap tables of the warp (K1): the projection of every tile pixel is fixed from here on.
+    // PANO_WARP_ON_THE_FLY=1 keeps the projecting kernel (also what frames beyond 2048 x 2048 use).
+    c->use_lut = P.src_w <= 2048 && P.src_h <= 2048 && !(getenv("PANO_WARP_ON_THE_FLY") && atoi(getenv("PANO_WARP_ON_THE_FLY")));
+    if (c->use_lut) {
+        for (int i = 0; i < n; i++) {
+            const FeedTile& t = P.tile[i];
+            c->lut_pitch[i] = (int)align_up((size_t)t.rect.w, 8);
+            HIP_TRY(c, hipMalloc((void**)&c->lut[i], (size_t)c->lut_pitch[i] * t.rect.h * sizeof(uint32_t)));
+            WarpCam w = make_warp_cam(c, i, nullptr, (size_t)P.src_w * 3, false);
+            launch_build_warp_lut(w, c->lut[i], c->lut_pitch[i], nullptr);
+        }
+        HIP_TRY(c, hipDeviceSynchronize());
     }
     // kernel parameter blocks
     c->pyr = PyrParams{};

@@ -26,7 +26,7 @@ namespace pano {
 __device__ __forceinline__ int cv_round_dev(float v) {
     // cvRound: round-half-even; x86 "integer indefinite" on overflow / NaN
     int r = __float2int_rn(v);
-    return (v >= -2147483648.f && v < 2147483648.f) ? r : INT_MIN;
+    return __builtin_fabsf(v) < 2147483648.f ? r : INT_MIN;  // NaN compares false
 }
 __device__ __forceinline__ int sat16i(int v) { return min(max(v, -32768), 32767); }
 __device__ __forceinline__ int sat8i(int v) { return min(max(v, 0), 255); }
@@ -77,14 +77,7 @@ __device__ __forceinline__ void sample_bilinear_reflect(const uint8_t* __restric
     int isx = cv_round_dev(fx * 32.f), isy = cv_round_dev(fy * 32.f);
     int a = isx & 31, b = isy & 31;
     int ix = sat16i(isx >> 5), iy = sat16i(isy >> 5);
-    if (ABL == 1) {  // diagnostic: no tap loads
-        out[0] = (ix + a) & 255; out[1] = (iy + b) & 255; out[2] = (ix ^ iy) & 255;
-        return;
-    }
-    if (ABL == 2) {  // diagnostic: every pixel takes the interior path
-        ix = min(max(ix, 0), sw - 3);
-        iy = min(max(iy, 0), sh - 2);
-    }
+
     int wa0 = 32 - a, wb0 = 32 - b;
     if (ix >= 0 && ix <= sw - 3) {
         // the two taps of a row are 6 consecutive bytes: one unaligned 8-byte load per row (ix <= sw-3 keeps
@@ -140,6 +133,66 @@ __device__ __forceinline__ void apply_gain(const WarpCam& c, int x, int y, int v
 // (B, G, R planes): each lane stores one dword per plane, a wave stores 3 x 256 contiguous bytes.
 // Four independent tap fetches per lane are in flight together (latency hiding by ILP).
 // ------------------------------------------------------------------------------------------------
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+
+// The 6 tap bytes B0 G0 R0 B1 G1 R1 at byte offset o of the frame, returned in the low 6 bytes of a uint2.
+// An unaligned 8-byte load costs the texture-address unit roughly twice an aligned one (measured: the
+// table-form K1 runs 30 us with unaligned taps, 22 us aligned), so fetch the enclosing 4-byte-aligned
+// 12 bytes (global_load_dwordx3) and realign in registers (2 x v_alignbyte_b32).
+__device__ __forceinline__ uint2 load_taps6(const uint8_t* __restrict__ src, unsigned lo, unsigned o) {
+    const unsigned k = (o + lo) & 3u;
+    const uint3 d = *reinterpret_cast<const uint3*>(src + (o - k));
+    return make_uint2(__builtin_amdgcn_alignbyte(d.y, d.x, k), __builtin_amdgcn_alignbyte(d.z, d.y, k));
+}
+
+// x / z and y / z, correctly rounded (IEEE-754 round-to-nearest-even), for a shared denominator.
+// This is the AMDGPU f32 division expansion (v_rcp + Newton refinement + two residual corrections) with
+// the reciprocal refinement shared by both quotients and without the exponent pre-scaling, which is a
+// no-op when 2^-40 <= z <= 2^40 (checked by the caller; anything else takes the generic path).
+__device__ __forceinline__ void div2_shared(float x, float y, float z, float& qx, float& qy) {
+    float r = __builtin_amdgcn_rcpf(z);
+    const float e = __builtin_fmaf(-z, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = x * r;
+    float rem = __builtin_fmaf(-z, q, x);
+    q = __builtin_fmaf(rem, r, q);
+    rem = __builtin_fmaf(-z, q, x);
+    qx = __builtin_fmaf(rem, r, q);
+    q = y * r;
+    rem = __builtin_fmaf(-z, q, y);
+    q = __builtin_fmaf(rem, r, q);
+    rem = __builtin_fmaf(-z, q, y);
+    qy = __builtin_fmaf(rem, r, q);
+}
+
+// one interior pixel: two unaligned 8-byte tap loads already issued (t = row iy, u = row iy+1, each holding
+// the 6 bytes B0 G0 R0 B1 G1 R1); bilinear in packed 16-bit lanes:
+//   h = p_left * (32-a) + p_right * a   for the top (low half) and bottom (high half) rows at once
+//   out = (h_top * (32-b) + h_bot * b + 512) >> 10          (v_dot2_u32_u16)
+__device__ __forceinline__ void bilinear_packed(uint2 t, uint2 u, int a, int b, int out[3]) {
+    const unsigned wa0 = (unsigned)(32 - a) * 0x00010001u, wa1 = (unsigned)a * 0x00010001u;
+    const us2_t W0 = __builtin_bit_cast(us2_t, wa0), W1 = __builtin_bit_cast(us2_t, wa1);
+    const us2_t WB = __builtin_bit_cast(us2_t, (unsigned)(32 - b) | ((unsigned)b << 16));
+    // v_perm_b32: bytes 0-3 come from the 2nd operand, 4-7 from the 1st, 0x0c = zero
+    const unsigned l0 = __builtin_amdgcn_perm(u.x, t.x, 0x0c040c00u), r0 = __builtin_amdgcn_perm(u.x, t.x, 0x0c070c03u);
+    const unsigned l1 = __builtin_amdgcn_perm(u.x, t.x, 0x0c050c01u), r1 = __builtin_amdgcn_perm(u.y, t.y, 0x0c040c00u);
+    const unsigned l2 = __builtin_amdgcn_perm(u.x, t.x, 0x0c060c02u), r2 = __builtin_amdgcn_perm(u.y, t.y, 0x0c050c01u);
+    const us2_t h0 = __builtin_bit_cast(us2_t, l0) * W0 + __builtin_bit_cast(us2_t, r0) * W1;
+    const us2_t h1 = __builtin_bit_cast(us2_t, l1) * W0 + __builtin_bit_cast(us2_t, r1) * W1;
+    const us2_t h2 = __builtin_bit_cast(us2_t, l2) * W0 + __builtin_bit_cast(us2_t, r2) * W1;
+    out[0] = (int)(__builtin_amdgcn_udot2(h0, WB, 512u, false) >> 10);
+    out[1] = (int)(__builtin_amdgcn_udot2(h1, WB, 512u, false) >> 10);
+    out[2] = (int)(__builtin_amdgcn_udot2(h2, WB, 512u, false) >> 10);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: fused warp of every camera's bordered feed() tile.  grid = (ceil(tw/256), ceil(th/4), ncam),
+// block = (64,4): one wave per tile-row segment, 4 adjacent pixels per lane.  Output is planar u8
+// (B, G, R planes): each lane stores one dword per plane, a wave stores 3 x 256 contiguous bytes.
+// The common case - all four pixels project inside the frame - is straight-line code: four maps, eight
+// tap loads in flight together, packed bilinear.  Anything else (reflected taps, z <= 0, extreme
+// exponents) takes the per-pixel generic path.
+// ------------------------------------------------------------------------------------------------
 template <int ABL>
 __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
     const WarpCam& c = P.cam[blockIdx.z];
@@ -155,17 +208,74 @@ __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
     const float4 a23 = *reinterpret_cast<const float4*>(c.colA + x0 + 2);
     const float2 A[4] = {make_float2(a01.x, a01.y), make_float2(a01.z, a01.w), make_float2(a23.x, a23.y),
                          make_float2(a23.z, a23.w)};
-    int v[4][3];
+    const int sw = c.src_w, sh = c.src_h, stride = c.src_stride;
+    const unsigned src_lo = (unsigned)(size_t)c.src & 3u;
+    // mapBackward, in OpenCV's evaluation order: (m0*x_ + m1*y_) + m2*z_ ; the m1*y_ products are per row
+    const float y_ = B.y, t1x = m[1] * y_, t1y = m[4] * y_, t1z = m[7] * y_;
+    float X[4], Y[4], Z[4];
+    bool fast = true;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        float fx, fy;
-        if (ABL == 3) {  // diagnostic: no projection arithmetic
-            fx = (float)(x0 + j) * 0.9f + A[j].x;
-            fy = (float)y * 0.9f + B.x;
-        } else {
-            map_backward(m, A[j], B, fx, fy);
+        const float x_ = B.x * A[j].x, z_ = B.x * A[j].y;
+        X[j] = (m[0] * x_ + t1x) + m[2] * z_;
+        Y[j] = (m[3] * x_ + t1y) + m[5] * z_;
+        Z[j] = (m[6] * x_ + t1z) + m[8] * z_;
+        fast &= Z[j] >= 0x1p-40f && Z[j] <= 0x1p40f;
+    }
+    int ix[4], iy[4], fa[4], fb[4];
+    if (ABL != 3) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float qx, qy;
+            div2_shared(X[j], Y[j], Z[j], qx, qy);
+            const int isx = cv_round_dev(qx * 32.f), isy = cv_round_dev(qy * 32.f);
+            fa[j] = isx & 31; fb[j] = isy & 31;
+            ix[j] = isx >> 5; iy[j] = isy >> 5;  // |value| < 2^26: the saturate_cast<short> is decided by the range test below
+            // the 12-byte aligned fetch of row iy+1 must end inside the frame: ix <= sw-4
+            fast &= ix[j] >= 0 && ix[j] <= sw - 4 && iy[j] >= 0 && iy[j] <= sh - 2;
         }
-        sample_bilinear_reflect<ABL>(c.src, c.src_w, c.src_h, c.src_stride, fx, fy, v[j]);
+    } else {  // diagnostic: no projection arithmetic
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            ix[j] = min((x0 + j) * 9 / 10, sw - 4); iy[j] = min(y * 9 / 10, sh - 2);
+            fa[j] = (x0 + j) & 31; fb[j] = y & 31;
+        }
+        fast = true;
+    }
+    if (ABL == 2) {  // diagnostic: every pixel takes the interior path
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            ix[j] = min(max(ix[j], 0), sw - 4);
+            iy[j] = min(max(iy[j], 0), sh - 2);
+        }
+        fast = true;
+    }
+    int v[4][3];
+    if (fast) {
+        uint2 t[4], u[4];
+        if (ABL != 1) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned o = (unsigned)(iy[j] * stride + 3 * ix[j]);
+                t[j] = load_taps6(c.src, src_lo, o);
+                u[j] = load_taps6(c.src, src_lo, o + stride);
+            }
+        } else {  // diagnostic: no tap loads
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                t[j] = make_uint2(ix[j] * 0x01010101u, iy[j]);
+                u[j] = make_uint2(iy[j] * 0x01010101u, ix[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) bilinear_packed(t[j], u[j], fa[j], fb[j], v[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float fx, fy;
+            map_backward(m, A[j], B, fx, fy);
+            sample_bilinear_reflect<0>(c.src, sw, sh, stride, fx, fy, v[j]);
+        }
     }
     if (c.gain) {
 #pragma unroll
@@ -177,6 +287,133 @@ __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
         unsigned pk = (unsigned)v[0][ch] | ((unsigned)v[1][ch] << 8) | ((unsigned)v[2][ch] << 16) | ((unsigned)v[3][ch] << 24);
         if (ABL == 4 && pk != 0x12345678u) continue;  // diagnostic: no stores
         *reinterpret_cast<unsigned*>(d + (size_t)ch * c.dst_plane) = pk;  // rows are padded to 16 bytes
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1, table form.  K, R and the tile geometry are fixed after pano_prepare, so everything in front of the
+// tap fetch - mapBackward, the 1/32-pixel quantisation of cv::remap, saturate_cast<short> and the
+// BORDER_REFLECT resolution of both taps on both axes - is a per-pixel constant.  It is folded into one
+// dword per tile pixel, with the same arithmetic as the on-the-fly kernel:
+//   bits  0..15  xs * 32 + a'     bits 16..31  ys * 32 + b'
+// (xs, ys) = the smaller reflected tap index, a'/b' = weight of tap xs+1 / row ys+1 in 1/32:
+//   taps increasing (x1 == x0 + 1): a' = a;  mirrored (x1 == x0 - 1): a' = 32 - a;  same pixel: a' = 0;
+//   a' == 32 is stored as (xs + 1, 0), which weighs the same pixel.
+// 0xffffffff marks the few pixels this cannot express (a tap fetch that would run past the end of the
+// frame); they are projected on the fly.  Needs frame sides <= 2048 (16 bits per axis).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool lut_axis(int i0, int n, int frac, int& base, int& w1) {
+    const int r0 = reflect_idx(i0, n), r1 = reflect_idx(i0 + 1, n);
+    if (r1 == r0 + 1) { base = r0; w1 = frac; }
+    else if (r1 == r0 - 1) { base = r1; w1 = 32 - frac; }
+    else if (r1 == r0) { base = r0; w1 = 0; }
+    else return false;
+    if (w1 == 32) { base += 1; w1 = 0; }
+    return true;
+}
+__global__ __launch_bounds__(256) void build_warp_lut_kernel(WarpCam c, uint32_t* lut, int lut_pitch) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= lut_pitch || y >= c.th) return;
+    uint32_t code = 0xffffffffu;
+    if (x < c.tw) {
+        float fx, fy;
+        map_backward(c.m, c.colA[x], c.rowB[y], fx, fy);
+        const int isx = cv_round_dev(fx * 32.f), isy = cv_round_dev(fy * 32.f);
+        const int ix = sat16i(isx >> 5), iy = sat16i(isy >> 5);
+        int xs, a1, ys, b1;
+        if (lut_axis(ix, c.src_w, isx & 31, xs, a1) && lut_axis(iy, c.src_h, isy & 31, ys, b1)) {
+            // the fetch reads the aligned 12 bytes around column xs of rows ys and min(ys+1, sh-1): it may spill
+            // into the next row (harmless) but not past the end of the frame
+            const bool last_row = ys + 1 >= c.src_h - 1;
+            const bool ok = xs <= c.src_w - 1 && ys <= c.src_h - 1 && !(last_row && xs > c.src_w - 4);
+            if (ok) code = (uint32_t)(xs * 32 + a1) | ((uint32_t)(ys * 32 + b1) << 16);
+        }
+    }
+    lut[(size_t)y * lut_pitch + x] = code;
+}
+void launch_build_warp_lut(const WarpCam& c, uint32_t* lut, int lut_pitch, hipStream_t s) {
+    dim3 block(64, 4, 1), grid((lut_pitch + 63) / 64, (c.th + 3) / 4, 1);
+    hipLaunchKernelGGL(build_warp_lut_kernel, grid, block, 0, s, c, lut, lut_pitch);
+}
+
+// NPX = pixels per lane (4 or 8): more pixels per lane = more independent fetches in flight per wave
+template <int ABL, int NPX>
+__global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
+    const WarpCam& c = P.cam[blockIdx.z];
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * NPX;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= c.tw || y >= c.th) return;
+    unsigned code[NPX];
+    if (NPX >= 4) {
+#pragma unroll
+        for (int g = 0; g < NPX / 4; g++) {
+            // the table rows are padded to a multiple of 8 entries
+            const uint4 mm = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0 + 4 * g);
+            code[4 * g] = mm.x; code[4 * g + 1] = mm.y; code[4 * g + 2] = mm.z; code[4 * g + 3] = mm.w;
+        }
+    } else if (NPX == 2) {
+        const uint2 mm = *reinterpret_cast<const uint2*>(c.lut + (size_t)y * c.lut_pitch + x0);
+        code[0] = mm.x; code[NPX - 1] = mm.y;
+    } else {
+        code[0] = c.lut[(size_t)y * c.lut_pitch + x0];
+    }
+    const int sh1 = c.src_h - 1, stride = c.src_stride;
+    const unsigned src_lo = (unsigned)(size_t)c.src & 3u;
+    int v[NPX][3];
+    {
+        uint2 t[NPX], u[NPX];
+        int fa[NPX], fb[NPX];
+        bool marked = false;
+#pragma unroll
+        for (int j = 0; j < NPX; j++) {
+            const bool mk = code[j] == 0xffffffffu;
+            const unsigned m = mk ? 0u : code[j];  // a marked pixel fetches (0,0) and is recomputed below
+            marked |= mk;
+            const unsigned mx = m & 0xffffu, my = m >> 16;
+            fa[j] = mx & 31; fb[j] = my & 31;
+            const int xs = mx >> 5, ys = min((int)(my >> 5), sh1), ys1 = min(ys + 1, sh1);
+            if (ABL == 1) {  // diagnostic: no tap loads
+                t[j] = make_uint2(xs * 0x01010101u, ys);
+                u[j] = make_uint2(ys * 0x01010101u, xs);
+            } else {
+                t[j] = load_taps6(c.src, src_lo, (unsigned)(ys * stride) + 3 * xs);
+                u[j] = load_taps6(c.src, src_lo, (unsigned)(ys1 * stride) + 3 * xs);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPX; j++) bilinear_packed(t[j], u[j], fa[j], fb[j], v[j]);
+        if (marked && ABL == 0) {
+            // rare: the bottom-right corner of the frame; project these pixels on the fly
+#pragma unroll
+            for (int j = 0; j < NPX; j++)
+                if (code[j] == 0xffffffffu) {
+                    float fx, fy;
+                    map_backward(c.m, c.colA[min(x0 + j, c.tw - 1)], c.rowB[y], fx, fy);
+                    sample_bilinear_reflect<0>(c.src, c.src_w, c.src_h, stride, fx, fy, v[j]);
+                }
+        }
+    }
+    if (c.gain) {
+#pragma unroll
+        for (int j = 0; j < NPX; j++) apply_gain(c, min(x0 + j, c.tw - 1), y, v[j]);
+    }
+    uint8_t* d = (uint8_t*)c.dst + (size_t)y * c.dst_pitch + x0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        unsigned pk[(NPX + 3) / 4];
+#pragma unroll
+        for (int g = 0; g < (NPX + 3) / 4; g++) {
+            pk[g] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (4 * g + k < NPX) pk[g] |= (unsigned)v[4 * g + k][ch] << (8 * k);
+        }
+        if (ABL == 4 && pk[0] != 0x12345678u) continue;  // diagnostic: no stores
+        // rows are padded to 16 bytes
+        if (NPX == 8) *reinterpret_cast<uint2*>(d + (size_t)ch * c.dst_plane) = make_uint2(pk[0], pk[(NPX + 3) / 4 - 1]);
+        else if (NPX == 4) *reinterpret_cast<unsigned*>(d + (size_t)ch * c.dst_plane) = pk[0];
+        else if (NPX == 2) *reinterpret_cast<unsigned short*>(d + (size_t)ch * c.dst_plane) = (unsigned short)pk[0];
+        else d[(size_t)ch * c.dst_plane] = (uint8_t)pk[0];
     }
 }
 
@@ -194,7 +431,36 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
         default: break;
     }
 #endif
-    hipLaunchKernelGGL(warp_tiles_kernel<0>, grid, block, 0, s, p);
+    // the table form needs every camera of the launch to carry a table (frames <= 2048 x 2048)
+    bool all_lut = true;
+    for (int i = 0; i < ncam; i++) all_lut &= p.cam[i].lut != nullptr;
+    if (all_lut) {
+        int npx = 4;
+#ifdef PANO_DIAG
+        static const int labl = getenv("PANO_LUT_ABL") ? atoi(getenv("PANO_LUT_ABL")) : 0;
+        if (getenv("PANO_LUT_NPX")) npx = atoi(getenv("PANO_LUT_NPX"));
+        dim3 g8((max_tw + 511) / 512, (max_th + 3) / 4, ncam);
+        if (labl == 1 && npx == 4) { hipLaunchKernelGGL((warp_tiles_lut_kernel<1, 4>), grid, block, 0, s, p); return; }
+        if (labl == 4 && npx == 4) { hipLaunchKernelGGL((warp_tiles_lut_kernel<4, 4>), grid, block, 0, s, p); return; }
+        if (labl == 1 && npx == 8) { hipLaunchKernelGGL((warp_tiles_lut_kernel<1, 8>), g8, block, 0, s, p); return; }
+        if (labl == 4 && npx == 8) { hipLaunchKernelGGL((warp_tiles_lut_kernel<4, 8>), g8, block, 0, s, p); return; }
+#endif
+        if (npx == 8) {
+            dim3 grid8((max_tw + 511) / 512, (max_th + 3) / 4, ncam);
+            hipLaunchKernelGGL((warp_tiles_lut_kernel<0, 8>), grid8, block, 0, s, p);
+#ifdef PANO_DIAG
+        } else if (npx == 2) {
+            dim3 grid2((max_tw + 127) / 128, (max_th + 3) / 4, ncam);
+            hipLaunchKernelGGL((warp_tiles_lut_kernel<0, 2>), grid2, block, 0, s, p);
+        } else if (npx == 1) {
+            dim3 grid1((max_tw + 63) / 64, (max_th + 3) / 4, ncam);
+            hipLaunchKernelGGL((warp_tiles_lut_kernel<0, 1>), grid1, block, 0, s, p);
+#endif
+        } else {
+            hipLaunchKernelGGL((warp_tiles_lut_kernel<0, 4>), grid, block, 0, s, p);
+        }
+    }
+    else hipLaunchKernelGGL(warp_tiles_kernel<0>, grid, block, 0, s, p);
 }
 
 // stage entry: RotationWarper::warp to an 8UC3 image (no border, byte pitch)

@@ -23,6 +23,9 @@ struct WarpCam {
     int dst_pitch;        // bytes per row
     int dst_plane;        // pipeline: bytes between the B, G, R planes
     // optional exposure gain (BlocksGainCompensator::apply): bilinear resize of a block map on the fly
+    // static remap table (frames up to 2048 x 2048): one dword per tile pixel, see build_warp_lut_kernel
+    const uint32_t* lut;  // nullptr -> project on the fly
+    int lut_pitch;        // dwords per row (multiple of 4)
     const float* gain;    // [gh][gw] block gains or nullptr
     const int2* gcol;     // [tw] {sx, sx1}   (REFLECT folded like colA)
     const float2* gcolw;  // [tw] {1-fx, fx}
@@ -68,6 +71,8 @@ struct CanvasParams {
 
 // K1: fused REFLECT border + mapBackward + fixed-point bilinear remap + 8U->16S
 void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hipStream_t s);
+// builds the static remap table of one camera tile (run once per pano_prepare)
+void launch_build_warp_lut(const WarpCam& c, uint32_t* lut, int lut_pitch, hipStream_t s);
 // stage entry: plain RotationWarper::warp to an 8UC3 image
 void launch_warp_image(const WarpCam& c, hipStream_t s);
 // RotationWarper::warp(mask255, INTER_NEAREST, BORDER_CONSTANT)

@@ -105,6 +105,19 @@ def test_stages_and_compose_c1_bit_exact(pano, po, c1, bands):
     assert np.array_equal(ctx.compose_host(c1["frames"]), want)
 
 
+def test_on_the_fly_warp_kernel(pano, po, c1, monkeypatch):
+    """frames up to 2048 x 2048 use the static remap table; PANO_WARP_ON_THE_FLY=1 selects the projecting
+    kernel that larger frames use - both must give the oracle's bits"""
+    masks = oracle_masks(po, c1)
+    want, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 3)
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PANO_WARP_ON_THE_FLY", flag)
+        ctx = make_ctx(pano, c1, 0, num_bands=3)
+        for i in range(4):
+            ctx.set_mask(i, masks[i])
+        assert np.array_equal(ctx.compose_host(c1["frames"]), want)
+
+
 def test_no_blend_and_cut_and_cylindrical(pano, po, c1, rig_r):
     masks = oracle_masks(po, c1)
     ctx = make_ctx(pano, c1, 0, num_bands=pano.BANDS_NO_BLEND)

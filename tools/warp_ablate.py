@@ -33,7 +33,7 @@ def child():
         ctx.feed_cameras(0xF, ptrs, [g["w"] * 3] * 4, st)
     torch.cuda.synchronize()
     ms, n = ctx.stage_stats(True)
-    print(json.dumps({"abl": os.environ.get("PANO_WARP_ABL", "0"), "warp_us": round(ms[0] / n[0] * 1e3, 2),
+    print(json.dumps({"abl": os.environ.get("PANO_LUT_ABL", os.environ.get("PANO_WARP_ABL", "0")), "warp_us": round(ms[0] / n[0] * 1e3, 2),
                       "pyr_us": round(ms[1] / n[1] * 1e3, 2)}))
 
 
@@ -41,8 +41,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
     else:
-        names = {0: "full", 1: "no tap loads", 2: "all interior path", 3: "no projection math", 4: "no stores"}
-        for abl in range(5):
-            env = dict(os.environ, PANO_WARP_ABL=str(abl), PANO_LIB=os.path.join(ROOT, "img-stitching_amd", "libpano_hip_diag.so"))
+        names = {0: "full", 1: "no tap loads", 4: "no stores"}
+        var = "PANO_LUT_ABL" if not os.environ.get("PANO_WARP_ON_THE_FLY") else "PANO_WARP_ABL"
+        for abl in (0, 1, 4):
+            env = dict(os.environ, PANO_LIB=os.path.join(ROOT, "img-stitching_amd", "libpano_hip_diag.so"))
+            env[var] = str(abl)
             out = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
             print(names[abl], out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:], flush=True)
