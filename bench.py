@@ -80,11 +80,10 @@ def main():
     strides = [W * 3] * NC
     stream = torch.cuda.current_stream().cuda_stream
 
-    # camera sharding (world > 1)
-    per_rank = (NG * NC) // world if world > 1 else NG * NC
-    if world > 1 and (NG * NC) % world:
-        raise SystemExit("gpus must divide 8")
-    my_cams = list(range(rank * per_rank, (rank + 1) * per_rank))
+    # camera sharding (world > 1): host logic in img-stitching_amd/sharding.py (also exercised on gloo/CPU)
+    sh = importlib.import_module("img-stitching_amd.sharding")
+    plans = sh.group_plan(NG * NC, NC, world, rank)
+    per_rank = (NG * NC) // world
     slot_views = []
     for ctx in ctxs:
         base, slot = ctx.pyramid_slots()
@@ -95,38 +94,18 @@ def main():
             ctxs[grp].compose(fptr[grp], strides, outs[grp].data_ptr(), ow * 3, stream)
 
     def step_sharded():
-        for grp in range(NG):
-            cams = [c - grp * NC for c in my_cams if c // NC == grp]
-            bits = sum(1 << c for c in cams)
-            if bits:
-                ctxs[grp].feed_cameras(bits, fptr[grp], strides, stream)
+        for grp, plan in enumerate(plans):
+            if plan["bits"]:
+                ctxs[grp].feed_cameras(plan["bits"], fptr[grp], strides, stream)
             buf, slot = slot_views[grp]
-            ranks_in_group = [r for r in range(world) if (r * per_rank) // NC == grp]
-            if per_rank >= NC:
-                # this rank (if it owns the group) holds every camera of it; only the panorama moves later
-                pass
-            else:
-                # each rank of the group contributes per_rank consecutive slots; root receives them in place
-                for r in ranks_in_group:
-                    lo = (r * per_rank - grp * NC) * slot
-                    view = buf[lo:lo + per_rank * slot]
-                    if r == 0:
-                        continue
-                    if rank == r:
-                        dist.send(view, dst=0)
-                    elif rank == 0:
-                        dist.recv(view, src=r)
-            if per_rank >= NC:
-                owner = ranks_in_group[0]
-                if rank == owner:
-                    ctxs[grp].blend(outs[grp].data_ptr(), ow * 3, stream)
-                if owner != 0:
-                    if rank == owner:
-                        dist.send(outs[grp], dst=0)
-                    elif rank == 0:
-                        dist.recv(outs[grp], src=owner)
-            elif rank == 0:
+            sh.exchange_slots(dist, rank, buf, slot, plan["moves"])   # RCCL p2p on the current stream
+            if plan["blend_here"]:
                 ctxs[grp].blend(outs[grp].data_ptr(), ow * 3, stream)
+            if plan["pano_from"] != 0:
+                if rank == plan["pano_from"]:
+                    dist.send(outs[grp], dst=0)
+                elif rank == 0:
+                    dist.recv(outs[grp], src=plan["pano_from"])
 
     step = step_single if world == 1 else step_sharded
 

@@ -1,0 +1,109 @@
+// replay.cpp - the reference's replay/master main loop (src/replay.cpp:192-404, src/master.cpp:258-326)
+// on top of pano::Stitcher: two stitchers (upper / lower camera group), one thread each per frame, the two
+// half-panoramas stacked with a black divider.  No OpenCV: frames are binary PPM (P6) files or synthetic.
+//
+//   g++ -O2 -std=c++17 examples/replay.cpp -o replay -Limg-stitching_amd -lpano_hip -Wl,-rpath,$PWD/img-stitching_amd -lpthread
+//   ./replay <stitcher-cfg.yaml> [--plan] [--frames N] [up0.ppm up1.ppm ... down0.ppm ...]
+//
+// --plan: geometry only (no GPU): prints the panorama size of both stitchers and exits.
+#include <chrono>
+#include <cstdio>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../img-stitching_amd/csrc/stitcher.hpp"
+
+static bool read_ppm(const std::string& path, pano::Mat& m) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    int w = 0, h = 0, mx = 0;
+    if (fscanf(f, "P6 %d %d %d", &w, &h, &mx) != 3 || mx != 255) { fclose(f); return false; }
+    fgetc(f);
+    m.create(h, w);
+    std::vector<uint8_t> rgb((size_t)w * h * 3);
+    size_t n = fread(rgb.data(), 1, rgb.size(), f);
+    fclose(f);
+    if (n != rgb.size()) return false;
+    for (size_t i = 0; i < (size_t)w * h; i++) {  // RGB file -> BGR like cv::imread
+        m.data[i * 3] = rgb[i * 3 + 2]; m.data[i * 3 + 1] = rgb[i * 3 + 1]; m.data[i * 3 + 2] = rgb[i * 3];
+    }
+    return true;
+}
+static void write_ppm(const std::string& path, const pano::Mat& m) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return;
+    fprintf(f, "P6\n%d %d\n255\n", m.cols, m.rows);
+    std::vector<uint8_t> row((size_t)m.cols * 3);
+    for (int y = 0; y < m.rows; y++) {
+        const uint8_t* s = m.data + (size_t)y * m.step;
+        for (int x = 0; x < m.cols; x++) { row[x * 3] = s[x * 3 + 2]; row[x * 3 + 1] = s[x * 3 + 1]; row[x * 3 + 2] = s[x * 3]; }
+        fwrite(row.data(), 1, row.size(), f);
+    }
+    fclose(f);
+}
+static void synthetic(pano::Mat& m, int w, int h, int seed) {
+    m.create(h, w);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            uint8_t* p = m.data + (size_t)y * m.step + x * 3;
+            p[0] = (uint8_t)(x * 255 / w); p[1] = (uint8_t)(y * 255 / h); p[2] = (uint8_t)((((x >> 5) + (y >> 5) + seed) & 1) * 200);
+        }
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: replay <stitcher-cfg.yaml> [--plan] [--frames N] [ppm files]\n"); return 2; }
+    std::string cfg = argv[1];
+    bool plan = false;
+    int nframes = 3;
+    std::vector<std::string> files;
+    for (int i = 2; i < argc; i++) {
+        std::string a = argv[i];
+        if (a == "--plan") plan = true;
+        else if (a == "--frames" && i + 1 < argc) nframes = atoi(argv[++i]);
+        else files.push_back(a);
+    }
+    pano::Stitcher st[2];
+    for (int s = 0; s < 2; s++) {
+        if (plan) st[s].device = -1;
+        if (st[s].init(cfg, s) != pano::RET_OK) { fprintf(stderr, "stitcher %d init failed\n", s); return 1; }
+    }
+    const int n = st[0].config().num_images, W = st[0].config().width, H = st[0].config().height;
+    std::vector<pano::Mat> imgs[2];
+    for (int s = 0; s < 2; s++)
+        for (int i = 0; i < n; i++) {
+            pano::Mat m;
+            size_t k = (size_t)s * n + i;
+            if (k >= files.size() || !read_ppm(files[k], m) || m.cols != W || m.rows != H) synthetic(m, W, H, (int)k);
+            imgs[s].push_back(m);
+        }
+    for (int s = 0; s < 2; s++)
+        if (st[s].calibration(imgs[s]) != pano::RET_OK) { fprintf(stderr, "stitcher %d calibration failed: %s\n", s, st[s].lastError()); return 1; }
+    for (int s = 0; s < 2; s++) {
+        int w = 0, h = 0, nb = 0, r[4];
+        pano_get_output_size(st[s].handle(), &w, &h);
+        pano_get_num_bands(st[s].handle(), &nb);
+        pano_get_pano_rect(st[s].handle(), r);
+        printf("stitcher %d: pano %dx%d at (%d,%d), output %dx%d, bands %d\n", s, r[2], r[3], r[0], r[1], w, h, nb);
+    }
+    if (plan) return 0;
+    pano::Mat out[2];
+    for (int f = 0; f < nframes; f++) {
+        auto t0 = std::chrono::steady_clock::now();
+        std::thread t1(&pano::Stitcher::process, &st[0], std::ref(imgs[0]), std::ref(out[0]));  // master.cpp:314-318
+        std::thread t2(&pano::Stitcher::process, &st[1], std::ref(imgs[1]), std::ref(out[1]));
+        t1.join();
+        t2.join();
+        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        printf("frame %d: stitching takes %.3f ms\n", f, ms);
+    }
+    // vconcat with a black divider (master.cpp:321-326), widths cropped to the narrower half
+    int w = std::min(out[0].cols, out[1].cols);
+    pano::Mat fin(out[0].rows + out[1].rows, w);
+    for (int y = 0; y < out[0].rows; y++) memcpy(fin.data + (size_t)y * fin.step, out[0].data + (size_t)y * out[0].step, (size_t)w * 3);
+    for (int y = 0; y < out[1].rows; y++) memcpy(fin.data + (size_t)(y + out[0].rows) * fin.step, out[1].data + (size_t)y * out[1].step, (size_t)w * 3);
+    for (int y = out[0].rows - 1; y <= out[0].rows + 1 && y < fin.rows; y++) memset(fin.data + (size_t)y * fin.step, 0, (size_t)w * 3);
+    write_ppm("final.ppm", fin);
+    printf("wrote final.ppm %dx%d\n", fin.cols, fin.rows);
+    return 0;
+}

@@ -1,0 +1,57 @@
+"""the C++ mirror of ocvStitcher (csrc/stitcher.hpp) and the replay example: compile with plain g++ against
+the C-ABI, read the reference's two YAML shapes (a stitcher cfg + a cameras.yaml `structures:` entry written
+from the committed r_cams.json fixture), check the geometry in plan mode (CPU) and the frame loop on the GPU"""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def write_cfgs(tmp_path, rig_r):
+    cams = tmp_path / "cameras.yaml"
+    lines = ["cameras:", " -", "  vendor: lijing   # unrelated list", "structures:", " -", "  vendor: lijing",
+             "  sensor: imx390", "  sttype: 4cam-black", "  undistor: true", "  fov: 120", "  inputsz: 640", "  params:",
+             "   -", "    cams: [0]", "    cut: [0, 0, 10, 10]", " -", "  vendor: lijing", "  sensor: imx390",
+             "  sttype: 4cam-black", "  undistor: true", "  fov: 120", "  inputsz: 960", "  params:"]
+    for st in rig_r["stitchers"]:
+        v = [repr(x) for x in st["cams"]]
+        lines += ["   -", "    cams: [" + ",".join(v[:20]) + ",", "            " + ",".join(v[20:]) + "]",
+                  "    cut: [%d, %d, %d, %d]" % tuple(st["cut"])]
+    cams.write_text("\n".join(lines) + "\n")
+    cfg = tmp_path / "stitcher.yaml"
+    cfg.write_text("\n".join([
+        "# camera vendor", "vendor: lijing", "sensor: imx390", "sttype: 4cam-black", "undistor: true",
+        "outPutWidth: 960 # 800", "outPutHeight: 540", "fov: 120", 'cameraparams: "%s"' % cams, "num_images: 2",
+        'camcfgpath: "%s/"' % tmp_path, "stitcherMatchConf: 0.3", "stitcherAdjusterConf: 0.7",
+        "stitcherBlenderStrength: 1", "stitcherCameraExThres: 30e2", "stitcherCameraInThres: 500e2", "initMode: 2"]) + "\n")
+    return cfg
+
+
+@pytest.fixture(scope="module")
+def replay_bin(tmp_path_factory, pano):
+    pano.build()
+    out = tmp_path_factory.mktemp("bin") / "replay"
+    lib_dir = os.path.join(ROOT, "img-stitching_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", os.path.join(ROOT, "examples", "replay.cpp"), "-o", str(out),
+                           "-L" + lib_dir, "-lpano_hip", "-Wl,-rpath," + lib_dir, "-lpthread"])
+    return str(out)
+
+
+def test_replay_plan_mode(replay_bin, rig_r, tmp_path):
+    cfg = write_cfgs(tmp_path, rig_r)
+    r = subprocess.run([replay_bin, str(cfg), "--plan"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    # rig R stitcher 0 pano 1452x523, cut 1430x250, strength 1 -> 3 bands; stitcher 1 1484x509
+    assert "stitcher 0: pano 1452x523 at (-721,497), output 1430x250, bands 3" in r.stdout
+    assert "stitcher 1: pano 1484x509 at (-733,523), output 1470x250, bands 3" in r.stdout
+
+
+@pytest.mark.gpu
+def test_replay_frames_on_gpu(replay_bin, rig_r, tmp_path):
+    cfg = write_cfgs(tmp_path, rig_r)
+    r = subprocess.run([replay_bin, str(cfg), "--frames", "2"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "wrote final.ppm 1430x500" in r.stdout
+    assert os.path.getsize(tmp_path / "final.ppm") > 1430 * 500 * 3

@@ -1,0 +1,76 @@
+"""world_size-2 (and 4) gloo test of the multi-GPU host logic on CPU tensors: camera ranges, in-place landing of
+every rank's pyramid slots on rank 0, panorama hand-off when a rank owns a whole group."""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, total_cams, cams_per_group, slot_bytes, q):
+    sys.path.insert(0, ROOT)
+    sh = importlib.import_module("img-stitching_amd.sharding")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    plans = sh.group_plan(total_cams, cams_per_group, world, rank)
+    for g, plan in enumerate(plans):
+        buf = torch.zeros(cams_per_group * slot_bytes, dtype=torch.uint8)
+        # "feed" my cameras: slot c of group g carries the byte pattern (g*16 + c + 1)
+        for c in range(cams_per_group):
+            if (plan["bits"] >> c) & 1:
+                buf[c * slot_bytes:(c + 1) * slot_bytes] = g * 16 + c + 1
+        sh.exchange_slots(dist, rank, buf, slot_bytes, plan["moves"])
+        pano = torch.zeros(8, dtype=torch.uint8)
+        if plan["blend_here"]:
+            # every slot of the group must now be present, each in its own place
+            for c in range(cams_per_group):
+                ok &= bool((buf[c * slot_bytes:(c + 1) * slot_bytes] == g * 16 + c + 1).all())
+            pano[:] = 100 + g
+        if plan["pano_from"] != 0:
+            if rank == plan["pano_from"]:
+                dist.send(pano, dst=0)
+            elif rank == 0:
+                dist.recv(pano, src=plan["pano_from"])
+        if rank == 0:
+            ok &= bool((pano == 100 + g).all())
+    dist.barrier()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_slot_exchange(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + world + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 8, 4, 4096, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r for r, _ in res) == list(range(world))
+    assert all(ok for _, ok in res)
+
+
+def test_plans():
+    sh = importlib.import_module("img-stitching_amd.sharding")
+    assert sh.camera_shards(8, 4) == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    with pytest.raises(ValueError):
+        sh.camera_shards(8, 3)
+    # 8 ranks, 2 groups of 4: rank 5 feeds camera 1 of group 1 and sends that slot to rank 0
+    p = sh.group_plan(8, 4, 8, 5)
+    assert p[0]["bits"] == 0 and p[1]["bits"] == 0b0010 and (5, 1, 1) in p[1]["moves"] and not p[1]["blend_here"]
+    # 2 ranks: rank 1 owns group 1 entirely, blends it and ships the panorama
+    p = sh.group_plan(8, 4, 2, 1)
+    assert p[1]["bits"] == 0b1111 and p[1]["moves"] == [] and p[1]["blend_here"] and p[1]["pano_from"] == 1
+    # 1 rank: everything local
+    p = sh.group_plan(8, 4, 1, 0)
+    assert all(x["bits"] == 0b1111 and x["blend_here"] and not x["moves"] for x in p)
