@@ -14,6 +14,8 @@
 
 #include "pano_kernels.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <limits.h>
 #include <stdlib.h>
 
@@ -336,31 +338,30 @@ void launch_build_warp_lut(const WarpCam& c, uint32_t* lut, int lut_pitch, hipSt
     hipLaunchKernelGGL(build_warp_lut_kernel, grid, block, 0, s, c, lut, lut_pitch);
 }
 
-// NPX = pixels per lane (4 or 8): more pixels per lane = more independent fetches in flight per wave
-template <int ABL, int NPX>
+// NPX = pixels per lane, ROWS = tile rows per lane (rows y, y+4, y+8, ...: a block covers 4*ROWS rows).
+// The table entries of all ROWS rows are fetched up front; more work per wave amortises the per-wave
+// start-up (kernarg fetch, address setup) and keeps more loads in flight.
+template <int ABL, int NPX, int ROWS>
 __global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
     const WarpCam& c = P.cam[blockIdx.z];
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * NPX;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x0 >= c.tw || y >= c.th) return;
-    unsigned code[NPX];
-    if (NPX >= 4) {
+    const int ybase = blockIdx.y * (4 * ROWS) + threadIdx.y;
+    if (x0 >= c.tw || ybase >= c.th) return;
+    static_assert(NPX == 4, "one 16-byte table load per row");
+    uint4 mm[ROWS];
 #pragma unroll
-        for (int g = 0; g < NPX / 4; g++) {
-            // the table rows are padded to a multiple of 8 entries
-            const uint4 mm = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0 + 4 * g);
-            code[4 * g] = mm.x; code[4 * g + 1] = mm.y; code[4 * g + 2] = mm.z; code[4 * g + 3] = mm.w;
-        }
-    } else if (NPX == 2) {
-        const uint2 mm = *reinterpret_cast<const uint2*>(c.lut + (size_t)y * c.lut_pitch + x0);
-        code[0] = mm.x; code[NPX - 1] = mm.y;
-    } else {
-        code[0] = c.lut[(size_t)y * c.lut_pitch + x0];
+    for (int r = 0; r < ROWS; r++) {
+        const int y = min(ybase + 4 * r, c.th - 1);
+        mm[r] = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0);
     }
     const int sh1 = c.src_h - 1, stride = c.src_stride;
     const unsigned src_lo = (unsigned)(size_t)c.src & 3u;
-    int v[NPX][3];
-    {
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int y = ybase + 4 * r;
+        if (y >= c.th) break;
+        const unsigned code[4] = {mm[r].x, mm[r].y, mm[r].z, mm[r].w};
+        int v[NPX][3];
         uint2 t[NPX], u[NPX];
         int fa[NPX], fb[NPX];
         bool marked = false;
@@ -392,75 +393,71 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
                     sample_bilinear_reflect<0>(c.src, c.src_w, c.src_h, stride, fx, fy, v[j]);
                 }
         }
-    }
-    if (c.gain) {
+        if (c.gain) {
 #pragma unroll
-        for (int j = 0; j < NPX; j++) apply_gain(c, min(x0 + j, c.tw - 1), y, v[j]);
-    }
-    uint8_t* d = (uint8_t*)c.dst + (size_t)y * c.dst_pitch + x0;
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-        unsigned pk[(NPX + 3) / 4];
-#pragma unroll
-        for (int g = 0; g < (NPX + 3) / 4; g++) {
-            pk[g] = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (4 * g + k < NPX) pk[g] |= (unsigned)v[4 * g + k][ch] << (8 * k);
+            for (int j = 0; j < NPX; j++) apply_gain(c, min(x0 + j, c.tw - 1), y, v[j]);
         }
-        if (ABL == 4 && pk[0] != 0x12345678u) continue;  // diagnostic: no stores
-        // rows are padded to 16 bytes
-        if (NPX == 8) *reinterpret_cast<uint2*>(d + (size_t)ch * c.dst_plane) = make_uint2(pk[0], pk[(NPX + 3) / 4 - 1]);
-        else if (NPX == 4) *reinterpret_cast<unsigned*>(d + (size_t)ch * c.dst_plane) = pk[0];
-        else if (NPX == 2) *reinterpret_cast<unsigned short*>(d + (size_t)ch * c.dst_plane) = (unsigned short)pk[0];
-        else d[(size_t)ch * c.dst_plane] = (uint8_t)pk[0];
+        uint8_t* d = (uint8_t*)c.dst + (size_t)y * c.dst_pitch + x0;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const unsigned pk = (unsigned)v[0][ch] | ((unsigned)v[1][ch] << 8) | ((unsigned)v[2][ch] << 16) | ((unsigned)v[3][ch] << 24);
+            if (ABL == 4 && pk != 0x12345678u) continue;  // diagnostic: no stores
+            *reinterpret_cast<unsigned*>(d + (size_t)ch * c.dst_plane) = pk;  // rows are padded to 16 bytes
+        }
     }
 }
 
-void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hipStream_t s) {
+void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hipStream_t s, hipEvent_t ev_start,
+                       hipEvent_t ev_stop) {
     dim3 block(64, 4, 1);
     dim3 grid((max_tw + 255) / 256, (max_th + 3) / 4, ncam);
-#ifdef PANO_DIAG
-    // diagnostic build only (libpano_hip_diag.so): ablation variants for profiling, never shipped
-    static const int abl = getenv("PANO_WARP_ABL") ? atoi(getenv("PANO_WARP_ABL")) : 0;
-    switch (abl) {
-        case 1: hipLaunchKernelGGL(warp_tiles_kernel<1>, grid, block, 0, s, p); return;
-        case 2: hipLaunchKernelGGL(warp_tiles_kernel<2>, grid, block, 0, s, p); return;
-        case 3: hipLaunchKernelGGL(warp_tiles_kernel<3>, grid, block, 0, s, p); return;
-        case 4: hipLaunchKernelGGL(warp_tiles_kernel<4>, grid, block, 0, s, p); return;
-        default: break;
-    }
-#endif
     // the table form needs every camera of the launch to carry a table (frames <= 2048 x 2048)
     bool all_lut = true;
     for (int i = 0; i < ncam; i++) all_lut &= p.cam[i].lut != nullptr;
+#define PANO_LAUNCH_K1(K, G)                                                                   \
+    do {                                                                                       \
+        if (ev_start && ev_stop) hipExtLaunchKernelGGL(K, G, block, 0, s, ev_start, ev_stop, 0, p); \
+        else hipLaunchKernelGGL(K, G, block, 0, s, p);                                        \
+    } while (0)
     if (all_lut) {
-        int npx = 4;
+        int rows = 1;
 #ifdef PANO_DIAG
         static const int labl = getenv("PANO_LUT_ABL") ? atoi(getenv("PANO_LUT_ABL")) : 0;
-        if (getenv("PANO_LUT_NPX")) npx = atoi(getenv("PANO_LUT_NPX"));
-        dim3 g8((max_tw + 511) / 512, (max_th + 3) / 4, ncam);
-        if (labl == 1 && npx == 4) { hipLaunchKernelGGL((warp_tiles_lut_kernel<1, 4>), grid, block, 0, s, p); return; }
-        if (labl == 4 && npx == 4) { hipLaunchKernelGGL((warp_tiles_lut_kernel<4, 4>), grid, block, 0, s, p); return; }
-        if (labl == 1 && npx == 8) { hipLaunchKernelGGL((warp_tiles_lut_kernel<1, 8>), g8, block, 0, s, p); return; }
-        if (labl == 4 && npx == 8) { hipLaunchKernelGGL((warp_tiles_lut_kernel<4, 8>), g8, block, 0, s, p); return; }
-#endif
-        if (npx == 8) {
-            dim3 grid8((max_tw + 511) / 512, (max_th + 3) / 4, ncam);
-            hipLaunchKernelGGL((warp_tiles_lut_kernel<0, 8>), grid8, block, 0, s, p);
-#ifdef PANO_DIAG
-        } else if (npx == 2) {
-            dim3 grid2((max_tw + 127) / 128, (max_th + 3) / 4, ncam);
-            hipLaunchKernelGGL((warp_tiles_lut_kernel<0, 2>), grid2, block, 0, s, p);
-        } else if (npx == 1) {
-            dim3 grid1((max_tw + 63) / 64, (max_th + 3) / 4, ncam);
-            hipLaunchKernelGGL((warp_tiles_lut_kernel<0, 1>), grid1, block, 0, s, p);
-#endif
-        } else {
-            hipLaunchKernelGGL((warp_tiles_lut_kernel<0, 4>), grid, block, 0, s, p);
+        if (getenv("PANO_LUT_ROWS")) rows = atoi(getenv("PANO_LUT_ROWS"));
+        if (labl == 1) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<1, 4, 1>), grid); return; }
+        if (labl == 4) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<4, 4, 1>), grid); return; }
+        if (rows == 4) {
+            dim3 g4(grid.x, (max_th + 15) / 16, ncam);
+            PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, 4, 4>), g4);
+            return;
         }
+        if (rows == 8) {
+            dim3 g8(grid.x, (max_th + 31) / 32, ncam);
+            PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, 4, 8>), g8);
+            return;
+        }
+#endif
+        if (rows == 2) {
+            dim3 g2(grid.x, (max_th + 7) / 8, ncam);
+            PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, 4, 2>), g2);
+            return;
+        }
+        PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, 4, 1>), grid);
     }
-    else hipLaunchKernelGGL(warp_tiles_kernel<0>, grid, block, 0, s, p);
+    else {
+#ifdef PANO_DIAG
+        static const int abl = getenv("PANO_WARP_ABL") ? atoi(getenv("PANO_WARP_ABL")) : 0;
+        switch (abl) {
+            case 1: PANO_LAUNCH_K1(warp_tiles_kernel<1>, grid); return;
+            case 2: PANO_LAUNCH_K1(warp_tiles_kernel<2>, grid); return;
+            case 3: PANO_LAUNCH_K1(warp_tiles_kernel<3>, grid); return;
+            case 4: PANO_LAUNCH_K1(warp_tiles_kernel<4>, grid); return;
+            default: break;
+        }
+#endif
+        PANO_LAUNCH_K1(warp_tiles_kernel<0>, grid);
+    }
+#undef PANO_LAUNCH_K1
 }
 
 // stage entry: RotationWarper::warp to an 8UC3 image (no border, byte pitch)

@@ -70,7 +70,9 @@ struct CanvasParams {
 };
 
 // K1: fused REFLECT border + mapBackward + fixed-point bilinear remap + 8U->16S
-void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hipStream_t s);
+// ev_start/ev_stop (optional) receive the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL)
+void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hipStream_t s,
+                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // builds the static remap table of one camera tile (run once per pano_prepare)
 void launch_build_warp_lut(const WarpCam& c, uint32_t* lut, int lut_pitch, hipStream_t s);
 // stage entry: plain RotationWarper::warp to an 8UC3 image

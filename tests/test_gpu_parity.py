@@ -105,6 +105,32 @@ def test_stages_and_compose_c1_bit_exact(pano, po, c1, bands):
     assert np.array_equal(ctx.compose_host(c1["frames"]), want)
 
 
+def test_graph_replay(pano, po, torch, c1, monkeypatch):
+    """PANO_GRAPH=1: the frame's launch sequence captured once per buffer set and replayed"""
+    monkeypatch.setenv("PANO_GRAPH", "1")
+    masks = oracle_masks(po, c1)
+    ctx = make_ctx(pano, c1, 0, num_bands=4)
+    for i in range(4):
+        ctx.set_mask(i, masks[i])
+    want, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 4)
+    st = torch.cuda.Stream()
+    d = [torch.from_numpy(f).cuda() for f in c1["frames"]]
+    out = torch.zeros((257, 1333, 3), dtype=torch.uint8, device="cuda")
+    for rep in range(3):   # capture, then two replays; new frame content between replays
+        out.zero_()
+        torch.cuda.synchronize()
+        ctx.compose([t.data_ptr() for t in d], [480 * 3] * 4, out.data_ptr(), 1333 * 3, st.cuda_stream)
+        st.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+    d[0].copy_(torch.from_numpy(c1["frames"][1]).cuda())
+    torch.cuda.synchronize()
+    frames2 = [c1["frames"][1]] + c1["frames"][1:]
+    want2, _ = po.compose(frames2, c1["K"], c1["R"], c1["scale"], masks, 4)
+    ctx.compose([t.data_ptr() for t in d], [480 * 3] * 4, out.data_ptr(), 1333 * 3, st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want2)
+
+
 def test_on_the_fly_warp_kernel(pano, po, c1, monkeypatch):
     """frames up to 2048 x 2048 use the static remap table; PANO_WARP_ON_THE_FLY=1 selects the projecting
     kernel that larger frames use - both must give the oracle's bits"""
