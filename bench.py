@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bands", type=int, default=5)
+    ap.add_argument("--one-stream", action="store_true", help="both groups on one stream (no overlap)")
     ap.add_argument("--force-sharded-path", action="store_true", help="diagnostic: run the N>1 step code at N=1")
     args = ap.parse_args()
 
@@ -79,10 +80,12 @@ def main():
     outs = [torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in range(NG)]
     fptr = [[t.data_ptr() for t in fr] for fr in frames]
     strides = [W * 3] * NC
-    # a real (non-null) stream: the library replays its per-frame launch sequence as a hipGraph there
-    work_stream = torch.cuda.Stream()
-    torch.cuda.set_stream(work_stream)
-    stream = work_stream.cuda_stream
+    # one HIP stream per camera group, like the reference's one thread per stitcher (src/master.cpp:314-318):
+    # the latency-bound small pyramid levels of one group overlap the bandwidth-bound kernels of the other
+    group_streams = [torch.cuda.Stream() for _ in range(NG)]
+    torch.cuda.set_stream(group_streams[0])
+    stream = group_streams[0].cuda_stream
+    gstream = [st.cuda_stream for st in group_streams] if not args.one_stream else [stream] * NG
 
     # camera sharding (world > 1): host logic in img-stitching_amd/sharding.py (also exercised on gloo/CPU)
     sh = importlib.import_module("img-stitching_amd.sharding")
@@ -94,6 +97,10 @@ def main():
         slot_views.append((torch.as_tensor(DevView(base, slot * NC), device="cuda"), slot))
 
     def step_single():
+        for grp in range(NG):
+            ctxs[grp].compose(fptr[grp], strides, outs[grp].data_ptr(), ow * 3, gstream[grp])
+
+    def step_serial():
         for grp in range(NG):
             ctxs[grp].compose(fptr[grp], strides, outs[grp].data_ptr(), ow * 3, stream)
 
@@ -135,7 +142,7 @@ def main():
         c.stage_stats(reset=True)
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        (step_serial if step is step_single else step)()   # one stream: kernels timed without co-runners
     torch.cuda.synchronize()
     dt_profiled = time.perf_counter() - t1
     if world > 1:

@@ -64,6 +64,7 @@ struct pano_ctx {
     uint32_t* lut[kMaxCams] = {};   // static remap tables of K1 (frames <= 2048 x 2048)
     int lut_pitch[kMaxCams] = {};
     bool use_lut = true;
+    uint8_t* owner[kMaxLevels] = {};
     float* wsum[kMaxLevels] = {};
     int16_t* canvas[kMaxLevels] = {};
 
@@ -158,6 +159,7 @@ void free_device(pano_ctx* c) {
         for (int l = 0; l < kMaxLevels; l++) dfree(c->wgt[i][l]);
     }
     for (int l = 0; l < kMaxLevels; l++) {
+        dfree(c->owner[l]);
         dfree(c->wsum[l]);
         dfree(c->canvas[l]);
     }
@@ -275,6 +277,9 @@ pano_status ensure_weights(pano_ctx* c, hipStream_t s) {
     // the summed canvas weights are not read by the blend (it re-adds the same f32 terms in the same
     // order); they are kept for stage inspection
     for (int l = 0; l <= P.bands; l++) launch_sum_weights(c->pyr, l, c->wsum[l], P.canvas.w >> l, P.canvas.h >> l, s);
+    // owner maps of the vector levels
+    for (int l = 0; l <= P.bands; l++)
+        if (c->cv.fast[l]) launch_build_owner(c->pyr, c->cv, l, c->owner[l], s);
     HIP_TRY(c, hipGetLastError());
     c->weights_dirty = false;
     return PANO_OK;
@@ -576,6 +581,18 @@ pano_status pano_prepare(pano_ctx* c) {
                    ((r.w >> l) << l) == r.w && ((r.x >> l) << l) == r.x;
         }
         c->cv.fast[l] = fast ? 1 : 0;
+        if (fast) {
+            c->cv.opitch[l] = (int)align_up((size_t)(P.canvas.w >> l) / 4, 64);
+            HIP_TRY(c, hipMalloc((void**)&c->owner[l], (size_t)c->cv.opitch[l] * ((P.canvas.h >> l) / 2)));
+            c->cv.owner[l] = c->owner[l];
+        }
+    }
+    // the levels above the last vector level run fused (one normalise launch + one LDS collapse launch)
+    c->cv.small_base = 0;
+    if (P.bands >= 1) {
+        int k = 0;
+        while (k <= P.bands && c->cv.fast[k]) k++;
+        if (k >= 1 && P.bands - k + 1 >= 2) c->cv.small_base = k;
     }
     c->cv.w0 = P.canvas.w; c->cv.h0 = P.canvas.h;
     c->cv.bands = P.bands < 0 ? 0 : P.bands;
@@ -869,7 +886,12 @@ pano_status pano_blend(pano_ctx* c, uint8_t* d_out, size_t out_stride, void* str
     if (P.bands < 0) {
         launch_no_blend(c->pyr, cv, s);
     } else {
-        for (int l = P.bands; l >= 0; l--) launch_blend_level(c->pyr, cv, l, s);
+        int top = P.bands;
+        if (cv.small_base > 0) {
+            launch_blend_small(c->pyr, cv, s);
+            top = cv.small_base - 1;
+        }
+        for (int l = top; l >= 0; l--) launch_blend_level(c->pyr, cv, l, s);
     }
     if (c->profiling) {
         if (c->ev_cur < 0 && (st = begin_slot(c)) != PANO_OK) return st;
@@ -1065,7 +1087,8 @@ pano_status pano_debug_get_canvas_weights(pano_ctx* c, int level, float* h_dst, 
 pano_status pano_debug_get_canvas(pano_ctx* c, int level, int16_t* h_dst, int* w, int* h) {
     pano_status st = check_compute(c);
     if (st != PANO_OK) return st;
-    // level 0 is written straight to the 8U panorama and never materialised
+    // level 0 is written straight to the 8U panorama and never materialised; levels above the fused base
+    // (CanvasParams::small_base) hold the normalised Laplacian, not the collapsed image
     if (level < 1 || level >= c->levels || !w || !h || c->plan.bands < 0) return PANO_EINVAL;
     *w = c->plan.canvas.w >> level;
     *h = c->plan.canvas.h >> level;

@@ -726,35 +726,40 @@ __device__ __forceinline__ void up_h4(const int p[4], int o[4]) {
     o[2] = p[1] + 6 * p[2] + p[3];
     o[3] = 4 * (p[2] + p[3]);
 }
-// the 4 x 3 coarse neighbourhood of a 4 x 2 fine block: rows y-1, y, y+1 (y = Y0/2), columns x-1 .. x+2
+// the 4 x 3 coarse neighbourhood of a 4 x 2 fine block: rows y-1, y, y+1 (y = Y0/2), columns x-1 .. x+2, with
+// pyrUp's border rule (left/top reflect-101, right/bottom replicate) applied.  Branch-free, so that a caller's
+// loads can all be issued before the first is consumed: each row is ONE aligned fetch of a window that is
+// clamped into the row (8 bytes of u8 / 12 bytes of int16), and the four samples are picked by shifts.
 template <typename T>
 __device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int m, int pitch, int x, int y,
                                             int p[3][4]) {
-    const bool interior = x >= 1 && x + 2 <= n - 1;
-    int yi[3] = {y > 0 ? y - 1 : (m > 1 ? 1 : 0), y, min(y + 1, m - 1)};
-    if (interior) {
+    const int yi[3] = {y > 0 ? y - 1 : (m > 1 ? 1 : 0), y, min(y + 1, m - 1)};
+    const int xi[4] = {x > 0 ? x - 1 : (n > 1 ? 1 : 0), x, min(x + 1, n - 1), min(x + 2, n - 1)};
+    const int base = min(max(x - 1, 0), max(n - 4, 0));
+    if (sizeof(T) == 1) {
+        const int ab = base & ~3;  // 4-byte aligned; every xi lies in [ab, ab + 7]
+        uint2 d[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint2*>(S + (size_t)yi[r] * pitch + ab);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            const T* q = S + (size_t)yi[r] * pitch + (x - 1);
-            if (sizeof(T) == 1) {
-                unsigned d;
-                __builtin_memcpy(&d, q, 4);
-                p[r][0] = d & 0xff; p[r][1] = (d >> 8) & 0xff; p[r][2] = (d >> 16) & 0xff; p[r][3] = d >> 24;
-            } else {
-                uint2 d;
-                __builtin_memcpy(&d, q, 8);
-                p[r][0] = (int16_t)(d.x & 0xffff); p[r][1] = (int16_t)(d.x >> 16);
-                p[r][2] = (int16_t)(d.y & 0xffff); p[r][3] = (int16_t)(d.y >> 16);
-            }
+            const unsigned long long q = ((unsigned long long)d[r].y << 32) | d[r].x;
+#pragma unroll
+            for (int k = 0; k < 4; k++) p[r][k] = (int)((q >> (8 * (xi[k] - ab))) & 0xffu);
         }
     } else {
-        int xi[4] = {x > 0 ? x - 1 : (n > 1 ? 1 : 0), x, min(x + 1, n - 1), min(x + 2, n - 1)};
+        const int ab = base & ~1;  // even element index = 4-byte aligned; every xi lies in [ab, ab + 4]
+        uint3 d[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const T* q = S + (size_t)yi[r] * pitch;
+        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint3*>(S + (size_t)yi[r] * pitch + ab);
 #pragma unroll
-            for (int k = 0; k < 4; k++) p[r][k] = (int)q[xi[k]];
-        }
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = xi[k] - ab;
+                const unsigned w = j < 2 ? d[r].x : (j < 4 ? d[r].y : d[r].z);
+                p[r][k] = (int)(int16_t)(w >> (16 * (j & 1)));
+            }
     }
 }
 // pyrUp of a 4 x 2 block: up[0][..] = fine row Y0 (even), up[1][..] = fine row Y0+1 (odd)
@@ -769,6 +774,52 @@ __device__ __forceinline__ void up_block(const int p[3][4], int up[2][4]) {
     }
 }
 
+// store a finished 4 x 2 block: canvas level (planar int16) or, at level 0, dst_mask + convertTo(8U) + cut
+template <bool L0>
+__device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0, int Y0, const int v[3][2][4], bool o00,
+                                            bool o01, bool o02, bool o03, bool o10, bool o11, bool o12, bool o13) {
+    if (!L0) {
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                uint2 pk;
+                pk.x = ((unsigned)v[pl][r][0] & 0xffffu) | ((unsigned)v[pl][r][1] << 16);
+                pk.y = ((unsigned)v[pl][r][2] & 0xffffu) | ((unsigned)v[pl][r][3] << 16);
+                *reinterpret_cast<uint2*>(C.img[l] + (size_t)pl * C.cplane[l] + (size_t)(Y0 + r) * C.cpitch[l] + X0) = pk;
+            }
+    } else {
+        const bool on[2][4] = {{o00, o01, o02, o03}, {o10, o11, o12, o13}};
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int Y = Y0 + r;
+            if (Y < C.cut_y || Y >= C.cut_y + C.cut_h) continue;
+            unsigned b[12];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) b[3 * k + pl] = on[r][k] ? (unsigned)sat8i(v[pl][r][k]) : 0u;
+            uint8_t* d = C.out + (size_t)(Y - C.cut_y) * C.out_stride + 3 * (X0 - C.cut_x);
+            const bool whole = X0 >= C.cut_x && X0 + 4 <= C.cut_x + C.cut_w;
+            if (whole && (((size_t)d) & 3) == 0) {
+                uint3 pk;
+                pk.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                pk.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                pk.z = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+                *reinterpret_cast<uint3*>(d) = pk;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (X0 + k >= C.cut_x && X0 + k < C.cut_x + C.cut_w) {
+                        d[3 * k] = (uint8_t)b[3 * k];
+                        d[3 * k + 1] = (uint8_t)b[3 * k + 1];
+                        d[3 * k + 2] = (uint8_t)b[3 * k + 2];
+                    }
+            }
+        }
+    }
+}
+
 template <bool L0>
 __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, CanvasParams C, int lvl) {
     const int l = L0 ? 0 : lvl;
@@ -780,6 +831,77 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     if (L0) {
         if (X0 >= C.cut_x + C.cut_w || Y0 >= C.cut_y + C.cut_h) return;
     } else if (X0 >= cw || Y0 >= ch) {
+        return;
+    }
+    // Away from the seams a block belongs to exactly one camera with weight 1.0f everywhere (or to none):
+    // the static owner map says so in one byte, and the block needs no weights, no float math and no division:
+    //   acc = lap, W = 1  =>  norm = lap - sign(lap)  (see below)
+    const unsigned code = C.owner[l][(size_t)(Y0 >> 1) * C.opitch[l] + (X0 >> 2)];
+    const unsigned ucode = __builtin_amdgcn_readfirstlane(code);
+    if (ucode != 0xffu && __builtin_amdgcn_ballot_w64(code != ucode) == 0) {
+        // the whole wave (a 256 x 2 strip) has one owner: its parameters are scalar, the code is straight-line
+        // and every load is in flight before the first use
+        int v[3][2][4];
+        int cp[3][3][4];
+        if (l < C.bands) {
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+                load_coarse<int16_t>(C.img[l + 1] + (size_t)pl * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
+                                     Y0 >> 1, cp[pl]);
+        }
+        if (ucode < 8u) {
+            const PyrCam& c = P.cam[ucode];
+            const int x = X0 - (c.tx >> l), y = Y0 - (c.ty >> l);
+            const int tw = c.w0 >> l, th = c.h0 >> l;
+            unsigned g0[3], g1[3];
+            int p[3][3][4];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                const uint8_t* g = c.lvl[l] + (size_t)pl * c.plane[l] + (size_t)y * c.pitch[l] + x;
+                g0[pl] = *reinterpret_cast<const unsigned*>(g);
+                g1[pl] = *reinterpret_cast<const unsigned*>(g + c.pitch[l]);
+                if (l < C.bands)
+                    load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)pl * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1], x >> 1,
+                                         y >> 1, p[pl]);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                int up[2][4];
+                if (l < C.bands) {
+                    up_block(p[pl], up);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) up[0][k] = up[1][k] = 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int l0 = sat16i((int)((g0[pl] >> (8 * k)) & 0xffu) - up[0][k]);
+                    const int l1 = sat16i((int)((g1[pl] >> (8 * k)) & 0xffu) - up[1][k]);
+                    v[pl][0][k] = l0 - (l0 > 0) + (l0 < 0);
+                    v[pl][1][k] = l1 - (l1 > 0) + (l1 < 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[pl][r][k] = 0;
+        }
+        if (l < C.bands) {
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                int up[2][4];
+                up_block(cp[pl], up);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[pl][r][k] = sat16i(v[pl][r][k] + up[r][k]);
+            }
+        }
+        const bool on = ucode < 8u;  // W == 1 > eps; an unowned block has W == 0
+        store_block<L0>(C, l, X0, Y0, v, on, on, on, on, on, on, on, on);
         return;
     }
     // phase A: which cameras carry weight on this 4 x 2 block.  All weight loads are issued together.
@@ -924,47 +1046,185 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
                 v[pl][r][k] = l < C.bands ? sat16i(nrm + up[r][k]) : nrm;
             }
     }
-    if (!L0) {
+    bool on[2][4];
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++)
+    for (int r = 0; r < 2; r++)
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
-                uint2 pk;
-                pk.x = ((unsigned)v[pl][r][0] & 0xffffu) | ((unsigned)v[pl][r][1] << 16);
-                pk.y = ((unsigned)v[pl][r][2] & 0xffffu) | ((unsigned)v[pl][r][3] << 16);
-                *reinterpret_cast<uint2*>(C.img[l] + (size_t)pl * C.cplane[l] + (size_t)(Y0 + r) * C.cpitch[l] + X0) = pk;
-            }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int Y = Y0 + r;
-            if (Y < C.cut_y || Y >= C.cut_y + C.cut_h) continue;
-            unsigned b[12];
-#pragma unroll
+        for (int k = 0; k < 4; k++) on[r][k] = W[r][k] > 1e-5f;
+    store_block<L0>(C, l, X0, Y0, v, on[0][0], on[0][1], on[0][2], on[0][3], on[1][0], on[1][1], on[1][2], on[1][3]);
+}
+
+// owner map of a vector level: one byte per 4 x 2 block (see CanvasParams::owner)
+__global__ __launch_bounds__(256) void build_owner_kernel(PyrParams P, CanvasParams C, int l, uint8_t* owner) {
+    const int cw = C.w0 >> l, ch = C.h0 >> l;
+    const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+    if (bx * 4 >= cw || by * 2 >= ch) return;
+    int holders = 0, unit_cam = -1;
+    bool all_unit = true;
+    for (int i = 0; i < P.ncam; i++) {
+        const PyrCam& c = P.cam[i];
+        const int x = bx * 4 - (c.tx >> l), y = by * 2 - (c.ty >> l);
+        if ((unsigned)x >= (unsigned)(c.w0 >> l) || (unsigned)y >= (unsigned)(c.h0 >> l)) continue;
+        bool any = false, unit = true;
+        for (int r = 0; r < 2; r++)
             for (int k = 0; k < 4; k++) {
-                const bool on = W[r][k] > 1e-5f;
-#pragma unroll
-                for (int pl = 0; pl < 3; pl++) b[3 * k + pl] = on ? (unsigned)sat8i(v[pl][r][k]) : 0u;
+                const float w = cam_weight(c, l, x + k, y + r);
+                any |= w != 0.f;
+                unit &= w == 1.0f;
             }
-            uint8_t* d = C.out + (size_t)(Y - C.cut_y) * C.out_stride + 3 * (X0 - C.cut_x);
-            const bool whole = X0 >= C.cut_x && X0 + 4 <= C.cut_x + C.cut_w;
-            if (whole && (((size_t)d) & 3) == 0) {
-                uint3 pk;
-                pk.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-                pk.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-                pk.z = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
-                *reinterpret_cast<uint3*>(d) = pk;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (X0 + k >= C.cut_x && X0 + k < C.cut_x + C.cut_w) {
-                        d[3 * k] = (uint8_t)b[3 * k];
-                        d[3 * k + 1] = (uint8_t)b[3 * k + 1];
-                        d[3 * k + 2] = (uint8_t)b[3 * k + 2];
-                    }
-            }
+        if (any) {
+            holders++;
+            unit_cam = i;
+            all_unit &= unit;
         }
     }
+    uint8_t code = 0xff;
+    if (holders == 0) code = 0xfe;
+    else if (holders == 1 && all_unit) code = (uint8_t)unit_cam;
+    owner[(size_t)by * C.opitch[l] + bx] = code;
+}
+void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint8_t* owner, hipStream_t s) {
+    const int bw = (c.w0 >> l) / 4, bh = (c.h0 >> l) / 2;
+    dim3 block(64, 4, 1), grid((bw + 63) / 64, (bh + 3) / 4, 1);
+    hipLaunchKernelGGL(build_owner_kernel, grid, block, 0, s, p, c, l, owner);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small levels (small_base .. bands): every one of them is latency bound on its own (a handful of waves
+// walking a chain of dependent loads), and the per-level launches used to cost more than the two large
+// levels together.  They are split differently:
+//   1. norm_small_kernel - ONE launch over all small levels: the camera half of the blend,
+//        norm_l = (short)(sum_cams (short)(lap_l * w_l) / (sum_cams w_l + 1e-5f)),
+//      which does not depend on any other canvas level, written to the canvas level buffers;
+//   2. collapse_small_kernel - ONE launch: each workgroup owns a 64 x 16 tile of level small_base and
+//      rebuilds the collapse chain out_l = sat16(norm_l + pyrUp(out_{l+1})) for the footprint of its tile
+//      through LDS, coarse to fine (the halo is recomputed per workgroup: a few hundred pixels).
+// Only out_{small_base} is needed by the next (vector) level; canvas levels above it keep norm_l.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void norm_small_kernel(PyrParams P, CanvasParams C) {
+    const int l = C.small_base + blockIdx.z;
+    const int cw = C.w0 >> l, ch = C.h0 >> l;
+    const int X = blockIdx.x * 64 + threadIdx.x, Y = blockIdx.y * 4 + threadIdx.y;
+    if (X >= cw || Y >= ch) return;
+    float wv[kCams];
+#pragma unroll
+    for (int i = 0; i < kCams; i++) {
+        wv[i] = 0.f;
+        if (i < P.ncam) {
+            const PyrCam& c = P.cam[i];
+            const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
+            if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l)) wv[i] = cam_weight(c, l, x, y);
+        }
+    }
+    int acc[3] = {0, 0, 0};
+    float W = 0.f;
+#pragma unroll
+    for (int i = 0; i < kCams; i++) {
+        const float w = wv[i];
+        if (w == 0.f) continue;
+        const PyrCam& c = P.cam[i];
+        const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
+        const int tw = c.w0 >> l, th = c.h0 >> l;
+        W += w;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            int lap = c.lvl[l][(size_t)k * c.plane[l] + (size_t)y * c.pitch[l] + x];
+            if (l < C.bands)
+                lap = sat16i(lap - pyr_up_px<uint8_t>(c.lvl[l + 1] + (size_t)k * c.plane[l + 1], tw >> 1, th >> 1,
+                                                      c.pitch[l + 1], x, y));
+            acc[k] = (int16_t)(acc[k] + (int16_t)(int)((float)lap * w));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int v;
+        if (W == 1.0f) v = acc[k] - (acc[k] > 0) + (acc[k] < 0);
+        else v = (int16_t)(int)((float)acc[k] / (W + 1e-5f));
+        C.img[l][(size_t)k * C.cplane[l] + (size_t)Y * C.cpitch[l] + X] = (int16_t)v;
+    }
+}
+
+constexpr int kSmallTileW = 64, kSmallTileH = 16;
+// footprint of a level-`small_base` tile at the coarser levels: R_{l+1} = [R_l.lo/2 - 1, R_l.hi/2 + 1] clamped
+struct SmallRegion {
+    int x0, y0, w, h;
+};
+constexpr int kSmallLdsElems = 2048;  // int16 per plane for all coarser regions of a tile (< 800 needed); 12 KB total
+
+__global__ __launch_bounds__(256) void collapse_small_kernel(CanvasParams C) {
+    __shared__ int16_t lds[3 * kSmallLdsElems];
+    const int k0 = C.small_base, nb = C.bands;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    // regions for every level of the chain (all threads compute the same small table)
+    SmallRegion R[kLevels];
+    int off[kLevels];
+    {
+        const int cw = C.w0 >> k0, ch = C.h0 >> k0;
+        int x0 = blockIdx.x * kSmallTileW, y0 = blockIdx.y * kSmallTileH;
+        int x1 = min(x0 + kSmallTileW, cw) - 1, y1 = min(y0 + kSmallTileH, ch) - 1;
+        int o = 0;
+        for (int l = k0; l <= nb; l++) {
+            R[l].x0 = x0; R[l].y0 = y0; R[l].w = x1 - x0 + 1; R[l].h = y1 - y0 + 1;
+            off[l] = o;
+            if (l > k0) o += R[l].w * R[l].h;  // level k0 goes straight to global memory
+            const int nw = C.w0 >> (l + 1), nh = C.h0 >> (l + 1);
+            x0 = max((x0 >> 1) - 1, 0); y0 = max((y0 >> 1) - 1, 0);
+            x1 = min((x1 >> 1) + 1, nw - 1); y1 = min((y1 >> 1) + 1, nh - 1);
+        }
+    }
+    for (int l = nb; l >= k0; l--) {
+        const int cw = C.w0 >> l, ch = C.h0 >> l;
+        const SmallRegion r = R[l];
+        const int n = r.w * r.h;
+        for (int e = tid; e < n * 3; e += 256) {
+            const int pl = e / n, q = e - pl * n;
+            const int yy = q / r.w, xx = q - yy * r.w;
+            const int X = r.x0 + xx, Y = r.y0 + yy;
+            int v = C.img[l][(size_t)pl * C.cplane[l] + (size_t)Y * C.cpitch[l] + X];  // norm_l
+            if (l < nb) {
+                // pyrUp of out_{l+1}, read from its LDS region (every index it needs lies inside that region)
+                const SmallRegion rc = R[l + 1];
+                const int16_t* S = lds + pl * kSmallLdsElems + off[l + 1];
+                const int nx = cw >> 1, ny = ch >> 1;
+                const int x = X >> 1, y = Y >> 1;
+                int xi[3], wx[3], yi[3], wy[3];
+                if (!(X & 1)) {
+                    xi[0] = x > 0 ? x - 1 : (nx > 1 ? 1 : 0); xi[1] = x; xi[2] = min(x + 1, nx - 1);
+                    wx[0] = 1; wx[1] = 6; wx[2] = 1;
+                } else {
+                    xi[0] = x; xi[1] = min(x + 1, nx - 1); xi[2] = x;
+                    wx[0] = 4; wx[1] = 4; wx[2] = 0;
+                }
+                if (!(Y & 1)) {
+                    yi[0] = y > 0 ? y - 1 : (ny > 1 ? 1 : 0); yi[1] = y; yi[2] = min(y + 1, ny - 1);
+                    wy[0] = 1; wy[1] = 6; wy[2] = 1;
+                } else {
+                    yi[0] = y; yi[1] = min(y + 1, ny - 1); yi[2] = y;
+                    wy[0] = 4; wy[1] = 4; wy[2] = 0;
+                }
+                int acc = 0;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int16_t* row = S + (yi[j] - rc.y0) * rc.w - rc.x0;
+                    acc += ((int)row[xi[0]] * wx[0] + (int)row[xi[1]] * wx[1] + (int)row[xi[2]] * wx[2]) * wy[j];
+                }
+                v = sat16i(v + sat16i((acc + 32) >> 6));
+            }
+            if (l > k0) lds[pl * kSmallLdsElems + off[l] + q] = (int16_t)v;
+            else C.img[l][(size_t)pl * C.cplane[l] + (size_t)Y * C.cpitch[l] + X] = (int16_t)v;
+        }
+        __syncthreads();
+    }
+}
+
+void launch_blend_small(const PyrParams& p, const CanvasParams& c, hipStream_t s) {
+    const int k0 = c.small_base;
+    const int cw = c.w0 >> k0, ch = c.h0 >> k0;
+    dim3 block(64, 4, 1);
+    dim3 g1((cw + 63) / 64, (ch + 3) / 4, c.bands - k0 + 1);
+    hipLaunchKernelGGL(norm_small_kernel, g1, block, 0, s, p, c);
+    dim3 g2((cw + kSmallTileW - 1) / kSmallTileW, (ch + kSmallTileH - 1) / kSmallTileH, 1);
+    hipLaunchKernelGGL(collapse_small_kernel, g2, block, 0, s, c);
 }
 
 void launch_blend_level(const PyrParams& p, const CanvasParams& c, int l, hipStream_t s) {

@@ -60,6 +60,9 @@ struct CanvasParams {
     int cpitch[kLevels];       // int16 elements per row
     int cplane[kLevels];       // int16 elements per plane
     int fast[kLevels];         // 1: every tile origin / size of this level is 4x2 aligned -> vector kernel
+    const uint8_t* owner[kLevels];  // vector levels: per 4x2 block, the single unit-weight camera (0..7), 0xFE none, 0xFF mixed
+    int opitch[kLevels];       // owner bytes per block row
+    int small_base;            // >0: levels small_base..bands run as one normalise launch + one LDS collapse launch
     int w0, h0;                // padded canvas size
     int bands;
     // final output
@@ -85,6 +88,10 @@ void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s
 // K3: one blend level for the whole canvas (Laplacian, weight, accumulate, normalise, collapse);
 // level 0 writes the cut 8U panorama
 void launch_blend_level(const PyrParams& p, const CanvasParams& c, int l, hipStream_t s);
+// the small levels small_base..bands in two launches
+void launch_blend_small(const PyrParams& p, const CanvasParams& c, hipStream_t s);
+// owner map of a vector level (run when masks change)
+void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint8_t* owner, hipStream_t s);
 // Blender::NO path
 void launch_no_blend(const PyrParams& p, const CanvasParams& c, hipStream_t s);
 
