@@ -736,30 +736,35 @@ __device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int 
     const int yi[3] = {y > 0 ? y - 1 : (m > 1 ? 1 : 0), y, min(y + 1, m - 1)};
     const int xi[4] = {x > 0 ? x - 1 : (n > 1 ? 1 : 0), x, min(x + 1, n - 1), min(x + 2, n - 1)};
     const int base = min(max(x - 1, 0), max(n - 4, 0));
+    // sample k is element xi[k] - base (0..3) of the 4-element window starting at `base`
+    const int sh[4] = {xi[0] - base, xi[1] - base, xi[2] - base, xi[3] - base};
     if (sizeof(T) == 1) {
-        const int ab = base & ~3;  // 4-byte aligned; every xi lies in [ab, ab + 7]
+        const int ab = base & ~3;  // 4-byte aligned fetch of 8 bytes; the window starts at byte base - ab (0..3)
         uint2 d[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint2*>(S + (size_t)yi[r] * pitch + ab);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            const unsigned long long q = ((unsigned long long)d[r].y << 32) | d[r].x;
+            const unsigned win = __builtin_amdgcn_alignbyte(d[r].y, d[r].x, (unsigned)(base - ab));
 #pragma unroll
-            for (int k = 0; k < 4; k++) p[r][k] = (int)((q >> (8 * (xi[k] - ab))) & 0xffu);
+            for (int k = 0; k < 4; k++) p[r][k] = (int)((win >> (8 * sh[k])) & 0xffu);
         }
     } else {
-        const int ab = base & ~1;  // even element index = 4-byte aligned; every xi lies in [ab, ab + 4]
+        const int ab = base & ~1;  // even element index = 4-byte aligned fetch of 12 bytes; window at element base - ab (0..1)
         uint3 d[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint3*>(S + (size_t)yi[r] * pitch + ab);
+        const unsigned bs = (unsigned)(base - ab) * 2u;  // 0 or 2 bytes
 #pragma unroll
-        for (int r = 0; r < 3; r++)
+        for (int r = 0; r < 3; r++) {
+            const unsigned w0 = __builtin_amdgcn_alignbyte(d[r].y, d[r].x, bs);
+            const unsigned w1 = __builtin_amdgcn_alignbyte(d[r].z, d[r].y, bs);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int j = xi[k] - ab;
-                const unsigned w = j < 2 ? d[r].x : (j < 4 ? d[r].y : d[r].z);
-                p[r][k] = (int)(int16_t)(w >> (16 * (j & 1)));
+                const unsigned w = sh[k] < 2 ? w0 : w1;
+                p[r][k] = (int)(int16_t)(w >> (16 * (sh[k] & 1)));
             }
+        }
     }
 }
 // pyrUp of a 4 x 2 block: up[0][..] = fine row Y0 (even), up[1][..] = fine row Y0+1 (odd)
@@ -820,14 +825,17 @@ __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0
     }
 }
 
-template <bool L0>
+template <bool L0, int ABL = 0>
 __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, CanvasParams C, int lvl) {
     const int l = L0 ? 0 : lvl;
     const int cw = C.w0 >> l, ch = C.h0 >> l;
     // level 0 covers only the block-aligned hull of the cut rectangle
     const int bx0 = L0 ? (C.cut_x & ~3) : 0, by0 = L0 ? (C.cut_y & ~1) : 0;
-    const int X0 = bx0 + (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int Y0 = by0 + (blockIdx.y * 4 + threadIdx.y) * 2;
+    // a wave is 16 x 4 blocks = 64 x 8 pixels (not a 256-pixel strip): four times fewer waves straddle a seam,
+    // and a wave that does not straddle one takes the single-owner fast path below
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int X0 = bx0 + (blockIdx.x * 16 + (tid & 15)) * 4;
+    const int Y0 = by0 + (blockIdx.y * 16 + (tid >> 4)) * 2;
     if (L0) {
         if (X0 >= C.cut_x + C.cut_w || Y0 >= C.cut_y + C.cut_h) return;
     } else if (X0 >= cw || Y0 >= ch) {
@@ -845,9 +853,17 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         int cp[3][3][4];
         if (l < C.bands) {
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++)
-                load_coarse<int16_t>(C.img[l + 1] + (size_t)pl * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
-                                     Y0 >> 1, cp[pl]);
+            for (int pl = 0; pl < 3; pl++) {
+                if (ABL == 1) {  // diagnostic: no canvas loads
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) cp[pl][r][k] = X0 + r + k;
+                } else {
+                    load_coarse<int16_t>(C.img[l + 1] + (size_t)pl * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1],
+                                         X0 >> 1, Y0 >> 1, cp[pl]);
+                }
+            }
         }
         if (ucode < 8u) {
             const PyrCam& c = P.cam[ucode];
@@ -858,11 +874,23 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) {
                 const uint8_t* g = c.lvl[l] + (size_t)pl * c.plane[l] + (size_t)y * c.pitch[l] + x;
-                g0[pl] = *reinterpret_cast<const unsigned*>(g);
-                g1[pl] = *reinterpret_cast<const unsigned*>(g + c.pitch[l]);
-                if (l < C.bands)
-                    load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)pl * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1], x >> 1,
-                                         y >> 1, p[pl]);
+                if (ABL == 3) {  // diagnostic: no level-l tile loads
+                    g0[pl] = x * 0x01010101u; g1[pl] = y * 0x01010101u;
+                } else {
+                    g0[pl] = *reinterpret_cast<const unsigned*>(g);
+                    g1[pl] = *reinterpret_cast<const unsigned*>(g + c.pitch[l]);
+                }
+                if (l < C.bands) {
+                    if (ABL == 2) {  // diagnostic: no coarse tile loads
+#pragma unroll
+                        for (int r = 0; r < 3; r++)
+#pragma unroll
+                            for (int k = 0; k < 4; k++) p[pl][r][k] = (x + r + k) & 255;
+                    } else {
+                        load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)pl * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1],
+                                             x >> 1, y >> 1, p[pl]);
+                    }
+                }
             }
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) {
@@ -901,9 +929,11 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
             }
         }
         const bool on = ucode < 8u;  // W == 1 > eps; an unowned block has W == 0
+        if (ABL == 4 && v[0][0][0] != 0x7fffffff) return;  // diagnostic: no stores
         store_block<L0>(C, l, X0, Y0, v, on, on, on, on, on, on, on, on);
         return;
     }
+    if (ABL == 5) return;  // diagnostic: only the single-owner fast path
     // phase A: which cameras carry weight on this 4 x 2 block.  All weight loads are issued together.
     // Level 0 keeps the mask bytes (2 dwords per camera); coarser levels only keep the verdict and
     // re-read the (cached) f32 weights in phase B, which costs no extra round trip.
@@ -1153,48 +1183,46 @@ constexpr int kSmallLdsElems = 2048;  // int16 per plane for all coarser regions
 
 __global__ __launch_bounds__(256) void collapse_small_kernel(CanvasParams C) {
     __shared__ int16_t lds[3 * kSmallLdsElems];
+    __shared__ int reg[kLevels][5];  // x0, y0, w, h, lds offset of every level's region
     const int k0 = C.small_base, nb = C.bands;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    // regions for every level of the chain (all threads compute the same small table)
-    SmallRegion R[kLevels];
-    int off[kLevels];
-    {
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    if (tx == 0 && ty == 0) {
         const int cw = C.w0 >> k0, ch = C.h0 >> k0;
         int x0 = blockIdx.x * kSmallTileW, y0 = blockIdx.y * kSmallTileH;
         int x1 = min(x0 + kSmallTileW, cw) - 1, y1 = min(y0 + kSmallTileH, ch) - 1;
         int o = 0;
         for (int l = k0; l <= nb; l++) {
-            R[l].x0 = x0; R[l].y0 = y0; R[l].w = x1 - x0 + 1; R[l].h = y1 - y0 + 1;
-            off[l] = o;
-            if (l > k0) o += R[l].w * R[l].h;  // level k0 goes straight to global memory
+            reg[l][0] = x0; reg[l][1] = y0; reg[l][2] = x1 - x0 + 1; reg[l][3] = y1 - y0 + 1;
+            reg[l][4] = o;
+            if (l > k0) o += reg[l][2] * reg[l][3];  // level k0 goes straight to global memory
             const int nw = C.w0 >> (l + 1), nh = C.h0 >> (l + 1);
             x0 = max((x0 >> 1) - 1, 0); y0 = max((y0 >> 1) - 1, 0);
             x1 = min((x1 >> 1) + 1, nw - 1); y1 = min((y1 >> 1) + 1, nh - 1);
         }
     }
+    __syncthreads();
     for (int l = nb; l >= k0; l--) {
         const int cw = C.w0 >> l, ch = C.h0 >> l;
-        const SmallRegion r = R[l];
-        const int n = r.w * r.h;
-        for (int e = tid; e < n * 3; e += 256) {
-            const int pl = e / n, q = e - pl * n;
-            const int yy = q / r.w, xx = q - yy * r.w;
-            const int X = r.x0 + xx, Y = r.y0 + yy;
-            int v = C.img[l][(size_t)pl * C.cplane[l] + (size_t)Y * C.cpitch[l] + X];  // norm_l
-            if (l < nb) {
-                // pyrUp of out_{l+1}, read from its LDS region (every index it needs lies inside that region)
-                const SmallRegion rc = R[l + 1];
-                const int16_t* S = lds + pl * kSmallLdsElems + off[l + 1];
-                const int nx = cw >> 1, ny = ch >> 1;
-                const int x = X >> 1, y = Y >> 1;
-                int xi[3], wx[3], yi[3], wy[3];
-                if (!(X & 1)) {
-                    xi[0] = x > 0 ? x - 1 : (nx > 1 ? 1 : 0); xi[1] = x; xi[2] = min(x + 1, nx - 1);
-                    wx[0] = 1; wx[1] = 6; wx[2] = 1;
-                } else {
-                    xi[0] = x; xi[1] = min(x + 1, nx - 1); xi[2] = x;
-                    wx[0] = 4; wx[1] = 4; wx[2] = 0;
-                }
+        const int rx0 = reg[l][0], ry0 = reg[l][1], rw = reg[l][2], rh = reg[l][3], ro = reg[l][4];
+        const int nx = cw >> 1, ny = ch >> 1;
+        int cx0 = 0, cy0 = 0, cwid = 0, co = 0;
+        if (l < nb) { cx0 = reg[l + 1][0]; cy0 = reg[l + 1][1]; cwid = reg[l + 1][2]; co = reg[l + 1][4]; }
+        // regions are at most 64 wide: lane = column, the 4 waves stride the rows
+        if (tx < rw) {
+            const int X = rx0 + tx;
+            const int x = X >> 1;
+            int xi[3], wx[3];
+            if (!(X & 1)) {
+                xi[0] = x > 0 ? x - 1 : (nx > 1 ? 1 : 0); xi[1] = x; xi[2] = min(x + 1, nx - 1);
+                wx[0] = 1; wx[1] = 6; wx[2] = 1;
+            } else {
+                xi[0] = x; xi[1] = min(x + 1, nx - 1); xi[2] = x;
+                wx[0] = 4; wx[1] = 4; wx[2] = 0;
+            }
+            for (int yy = ty; yy < rh; yy += 4) {
+                const int Y = ry0 + yy;
+                const int y = Y >> 1;
+                int yi[3], wy[3];
                 if (!(Y & 1)) {
                     yi[0] = y > 0 ? y - 1 : (ny > 1 ? 1 : 0); yi[1] = y; yi[2] = min(y + 1, ny - 1);
                     wy[0] = 1; wy[1] = 6; wy[2] = 1;
@@ -1202,16 +1230,24 @@ __global__ __launch_bounds__(256) void collapse_small_kernel(CanvasParams C) {
                     yi[0] = y; yi[1] = min(y + 1, ny - 1); yi[2] = y;
                     wy[0] = 4; wy[1] = 4; wy[2] = 0;
                 }
-                int acc = 0;
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const int16_t* row = S + (yi[j] - rc.y0) * rc.w - rc.x0;
-                    acc += ((int)row[xi[0]] * wx[0] + (int)row[xi[1]] * wx[1] + (int)row[xi[2]] * wx[2]) * wy[j];
+                for (int pl = 0; pl < 3; pl++) {
+                    int v = C.img[l][(size_t)pl * C.cplane[l] + (size_t)Y * C.cpitch[l] + X];  // norm_l
+                    if (l < nb) {
+                        // pyrUp of out_{l+1} from its LDS region (every index it needs lies inside that region)
+                        const int16_t* S = lds + pl * kSmallLdsElems + co;
+                        int acc = 0;
+#pragma unroll
+                        for (int j = 0; j < 3; j++) {
+                            const int16_t* row = S + (yi[j] - cy0) * cwid - cx0;
+                            acc += ((int)row[xi[0]] * wx[0] + (int)row[xi[1]] * wx[1] + (int)row[xi[2]] * wx[2]) * wy[j];
+                        }
+                        v = sat16i(v + sat16i((acc + 32) >> 6));
+                    }
+                    if (l > k0) lds[pl * kSmallLdsElems + ro + yy * rw + tx] = (int16_t)v;
+                    else C.img[l][(size_t)pl * C.cplane[l] + (size_t)Y * C.cpitch[l] + X] = (int16_t)v;
                 }
-                v = sat16i(v + sat16i((acc + 32) >> 6));
             }
-            if (l > k0) lds[pl * kSmallLdsElems + off[l] + q] = (int16_t)v;
-            else C.img[l][(size_t)pl * C.cplane[l] + (size_t)Y * C.cpitch[l] + X] = (int16_t)v;
         }
         __syncthreads();
     }
@@ -1237,9 +1273,18 @@ void launch_blend_level(const PyrParams& p, const CanvasParams& c, int l, hipStr
             w = c.w0 >> l;
             h = c.h0 >> l;
         }
-        dim3 block(64, 4, 1), grid((w + 255) / 256, (h + 7) / 8, 1);
-        if (l == 0) hipLaunchKernelGGL(blend_level_vec_kernel<true>, grid, block, 0, s, p, c, l);
-        else hipLaunchKernelGGL(blend_level_vec_kernel<false>, grid, block, 0, s, p, c, l);
+        dim3 block(64, 4, 1), grid((w + 63) / 64, (h + 31) / 32, 1);
+#ifdef PANO_DIAG
+        static const int kabl = getenv("PANO_K3_ABL") ? atoi(getenv("PANO_K3_ABL")) : 0;
+        if (l == 0 && kabl == 1) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 1>), grid, block, 0, s, p, c, l); return; }
+        if (l == 0 && kabl == 2) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 2>), grid, block, 0, s, p, c, l); return; }
+        if (l == 0 && kabl == 3) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 3>), grid, block, 0, s, p, c, l); return; }
+        if (l == 0 && kabl == 4) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 4>), grid, block, 0, s, p, c, l); return; }
+        if (l == 0 && kabl == 5) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 5>), grid, block, 0, s, p, c, l); return; }
+        if (l == 0 && kabl == 6) return;  // diagnostic: level 0 not launched at all
+#endif
+        if (l == 0) hipLaunchKernelGGL((blend_level_vec_kernel<true, 0>), grid, block, 0, s, p, c, l);
+        else hipLaunchKernelGGL((blend_level_vec_kernel<false, 0>), grid, block, 0, s, p, c, l);
         return;
     }
     int w = l == 0 ? c.cut_w : (c.w0 >> l), h = l == 0 ? c.cut_h : (c.h0 >> l);
