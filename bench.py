@@ -189,6 +189,17 @@ def main():
             "stage_us_per_launch": {k: round(stage_ms[i] / max(stage_n[i], 1) * 1e3, 2)
                                     for i, k in enumerate(("warp", "pyramid", "blend"))},
         }
+        if world == 1:
+            # the reference-shaped entry (host cv::Mat in, host cv::Mat out; H2D + compose + D2H, synchronous):
+            # reported for DESIGN.md, never the `value`
+            hframes = [[f.cpu().numpy() for f in fr] for fr in frames]
+            for grp in range(NG):
+                ctxs[grp].compose_host(hframes[grp])
+            th = time.perf_counter()
+            for _ in range(20):
+                for grp in range(NG):
+                    ctxs[grp].compose_host(hframes[grp])
+            result["host_buffer_path_panoramas_per_s"] = round(20 / (time.perf_counter() - th), 1)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(ctxs, g, args.bands)
         print(json.dumps(result), flush=True)

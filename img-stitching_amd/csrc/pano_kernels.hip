@@ -137,6 +137,18 @@ __device__ __forceinline__ void apply_gain(const WarpCam& c, int x, int y, int v
 // ------------------------------------------------------------------------------------------------
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 
+// XCD-aware block order (MI355X: 8 XCDs, each with its own 4 MB L2; consecutive workgroup ids are dealt
+// round-robin over the XCDs).  Remap the linear id so that each XCD walks one contiguous band of tile rows:
+// neighbouring row blocks share source rows / stencil halos, which then hit in that XCD's L2 instead of being
+// fetched once per XCD.  Bijective for any block count (cdna_hip_programming.md, T1).  Speed only.
+__device__ __forceinline__ void xcd_remap(int gx, int gy, int& bx, int& by) {
+    const int nblk = gx * gy, id = by * gx + bx;
+    const int xcd = id & 7, q = nblk >> 3, r = nblk & 7;
+    const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    by = nid / gx;
+    bx = nid - by * gx;
+}
+
 // The 6 tap bytes B0 G0 R0 B1 G1 R1 at byte offset o of the frame, returned in the low 6 bytes of a uint2.
 // An unaligned 8-byte load costs the texture-address unit roughly twice an aligned one (measured: the
 // table-form K1 runs 30 us with unaligned taps, 22 us aligned), so fetch the enclosing 4-byte-aligned
@@ -344,8 +356,13 @@ void launch_build_warp_lut(const WarpCam& c, uint32_t* lut, int lut_pitch, hipSt
 template <int ABL, int NPX, int ROWS>
 __global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
     const WarpCam& c = P.cam[blockIdx.z];
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * NPX;
-    const int ybase = blockIdx.y * (4 * ROWS) + threadIdx.y;
+    int bx = blockIdx.x, by = blockIdx.y;
+    // XCD-aware order is available but NOT used: it cut this kernel's fetched bytes by 36 % (FETCH_SIZE 42.8 ->
+    // 27.3 MB raw) and still ran 15 % slower (23.8 vs 20.5 us, A/B in one process) - the kernel is bound by
+    // tap-fetch issue and latency, not by DRAM bandwidth.  ABL == 8 (diagnostic build) turns it on.
+    if (ABL == 8) xcd_remap(gridDim.x, gridDim.y, bx, by);
+    const int x0 = (bx * 64 + threadIdx.x) * NPX;
+    const int ybase = by * (4 * ROWS) + threadIdx.y;
     if (x0 >= c.tw || ybase >= c.th) return;
     static_assert(NPX == 4, "one 16-byte table load per row");
     uint4 mm[ROWS];
@@ -426,6 +443,7 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
         if (getenv("PANO_LUT_ROWS")) rows = atoi(getenv("PANO_LUT_ROWS"));
         if (labl == 1) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<1, 4, 1>), grid); return; }
         if (labl == 4) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<4, 4, 1>), grid); return; }
+        if (labl == 8) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<8, 4, 1>), grid); return; }
         if (rows == 4) {
             dim3 g4(grid.x, (max_th + 15) / 16, ncam);
             PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, 4, 4>), g4);

@@ -261,3 +261,26 @@ def test_c4_cylindrical_7_bands_properties(pano, po):
     ctx.set_cut((1000, 300, 6000, 900))
     assert np.array_equal(ctx.compose_host(frames), full[300:1200, 1000:7000])
     assert full[:, :, :].max() > 0
+
+
+def test_c4_full_size_bit_exact(pano, po):
+    """config 4 at full size (4 x 3840x2160, cylindrical, 7 bands, block gains; the projecting K1 variant because
+    the frames exceed the remap table's 2048 limit) against the oracle"""
+    d = c4_rig()
+    rng = np.random.default_rng(11)
+    frames = [synth_frame(3840, 2160, 7 + i) for i in range(4)]
+    ctx = make_ctx(pano, d, 1, num_bands=7)
+    ctx.build_masks_voronoi()
+    masks = [ctx.get_mask(i) for i in range(4)]
+    full = []
+    for i in range(4):
+        r = ctx.roi(i)
+        g = (0.8 + 0.45 * rng.random(((r[3] + 31) // 32, (r[2] + 31) // 32))).astype(np.float32)
+        ctx.set_gain_map(i, g)
+        full.append(po.resize_linear_32f(g, r[2], r[3]))
+    got = ctx.compose_host(frames)
+    po.set_threads(16)
+    want, _ = po.compose(frames, d["K"], d["R"], d["scale"], masks, 7, kind=1, gain_maps=full)
+    po.set_threads(1)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
