@@ -284,3 +284,26 @@ def test_c4_full_size_bit_exact(pano, po):
     po.set_threads(1)
     assert got.shape == want.shape
     assert np.array_equal(got, want)
+
+
+def test_c1_against_committed_golden(pano, c1):
+    """the HIP path against the committed golden vectors (tests/golden/c1_golden.json, c1_pano_b4.png) - no oracle
+    code runs in this test"""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN, load_png_bgr
+    g = json.load(open(os.path.join(GOLDEN, "c1_golden.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    for nb in (-1, 0, 2, 4):
+        ctx = make_ctx(pano, c1, 0, num_bands=nb)
+        assert [list(ctx.roi(i)) for i in range(4)] == g["rois"]
+        ctx.build_masks_voronoi()
+        assert [sha(ctx.get_mask(i)) for i in range(4)] == g["mask_sha256"]
+        out = ctx.compose_host(c1["frames"])
+        assert sha(out) == g["pano_sha256"][str(nb)]
+        if nb == 4:
+            assert np.array_equal(out, load_png_bgr(os.path.join(GOLDEN, "c1_pano_b4.png")))
+        if nb == 2:
+            ctx.set_cut(g["cut"])
+            assert sha(ctx.compose_host(c1["frames"])) == g["pano_cut_sha256"]

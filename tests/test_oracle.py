@@ -194,3 +194,25 @@ def test_compose_cut_and_threads(po, c1):
     assert np.array_equal(par, full)
     with pytest.raises(ValueError):
         po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 2, cut=(0, 0, 2000, 100))
+
+
+def test_oracle_reproduces_committed_golden(po, c1):
+    """tests/golden/c1_golden.json + c1_pano_b4.png were written by tests/golden/make_golden.py from this oracle;
+    any change of the restatement's arithmetic shows up here"""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN, load_png_bgr
+    g = json.load(open(os.path.join(GOLDEN, "c1_golden.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    masks = po.prepare_masks_voronoi(0, 480, 270, c1["K"], c1["R"], c1["scale"])
+    for i in range(4):
+        p = po.projector(0, c1["scale"], c1["K"][i], c1["R"][i])
+        assert list(po.warp_roi(p, 480, 270)) == g["rois"][i]
+        assert sha(po.warp(p, c1["frames"][i])[1]) == g["warp_sha256"][i]
+        assert sha(masks[i]) == g["mask_sha256"][i]
+    for nb in (-1, 0, 2, 4):
+        pano, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, nb)
+        assert sha(pano) == g["pano_sha256"][str(nb)]
+        if nb == 4:
+            assert np.array_equal(pano, load_png_bgr(os.path.join(GOLDEN, "c1_pano_b4.png")))
