@@ -45,13 +45,15 @@ __device__ __forceinline__ int reflect_idx(int p, int n) {
     if (q < 0) q += period;
     return q < n ? q : period - 1 - q;
 }
-// BORDER_REFLECT_101 for the pyramid stencils: p is never farther than 2 outside [0, n)
+// BORDER_REFLECT_101 for the pyramid stencils: p is never farther than 2 outside [0, n).  Three folds cover every
+// n >= 2 (n == 2: -2 -> 2 -> 0, 3 -> -1 -> 1), exactly like cv::borderInterpolate's loop.
 __device__ __forceinline__ int reflect101_idx(int p, int n) {
     if ((unsigned)p < (unsigned)n) return p;
     if (n == 1) return 0;
-    p = p < 0 ? -p : 2 * n - 2 - p;
-    p = p < 0 ? -p : p;                 // n == 2
-    return min(p, n - 1);
+    p = p < 0 ? -p : p;
+    p = p >= n ? 2 * n - 2 - p : p;
+    p = p < 0 ? -p : p;
+    return min(p, n - 1);  // only reached by the out-of-image outputs of a partial last group (values unused)
 }
 
 // Spherical/CylindricalProjector::mapBackward from the separable factors, then the 1/32-pixel

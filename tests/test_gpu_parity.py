@@ -307,3 +307,45 @@ def test_c1_against_committed_golden(pano, c1):
         if nb == 2:
             ctx.set_cut(g["cut"])
             assert sha(ctx.compose_host(c1["frames"])) == g["pano_cut_sha256"]
+
+
+def _rig(n, w, h, f, yaw0, step, pitch_deg=0.0):
+    import math
+    from helpers import ry
+    K = [f, 0.0, w / 2.0, 0.0, f, h / 2.0, 0.0, 0.0, 1.0]
+    Rs = []
+    for i in range(n):
+        r = np.array(ry(yaw0 + i * step), np.float64).reshape(3, 3)
+        t = math.radians(pitch_deg * ((-1) ** i))
+        rx = np.array([[1, 0, 0], [0, math.cos(t), -math.sin(t)], [0, math.sin(t), math.cos(t)]])
+        Rs.append((r @ rx).astype(np.float32).reshape(9).tolist())
+    return {"K": [K] * n, "R": Rs, "scale": f, "w": w, "h": h, "n": n}
+
+
+@pytest.mark.parametrize("case", ["8cams", "odd_size_max_bands", "tiny", "two_bands_one_cam"])
+def test_extreme_shapes(pano, po, case):
+    """PANO_MAX_CAMS cameras in one context, odd frame sizes, the maximum band count on a small panorama (levels
+    shrink to a couple of pixels), a 1-camera context"""
+    if case == "8cams":
+        d, bands, kind = _rig(8, 320, 180, 300.0, 35.0, -10.0, 3.0), 3, 0
+    elif case == "odd_size_max_bands":
+        d, bands, kind = _rig(3, 333, 187, 250.0, 20.0, -20.0, 2.0), 8, 0
+    elif case == "tiny":
+        d, bands, kind = _rig(2, 37, 23, 30.0, 10.0, -20.0), 2, 1
+    else:
+        d, bands, kind = _rig(1, 200, 120, 180.0, 0.0, 0.0), 2, 0
+    frames = [synth_frame(d["w"], d["h"], 3 + i) for i in range(d["n"])]
+    ctx = make_ctx(pano, d, kind, num_bands=bands)
+    ctx.build_masks_voronoi()
+    masks = [ctx.get_mask(i) for i in range(d["n"])]
+    want_masks = oracle_masks(po, d, kind)
+    for i in range(d["n"]):
+        assert np.array_equal(masks[i], want_masks[i])
+    rois = [ctx.roi(i) for i in range(d["n"])]
+    b = po.Blender(bands)
+    b.prepare([r[:2] for r in rois], [r[2:] for r in rois])
+    assert ctx.num_bands() == b.num_bands()
+    want, _ = po.compose(frames, d["K"], d["R"], d["scale"], masks, bands, kind=kind)
+    got = ctx.compose_host(frames)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
