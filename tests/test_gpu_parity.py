@@ -349,3 +349,56 @@ def test_extreme_shapes(pano, po, case):
     got = ctx.compose_host(frames)
     assert got.shape == want.shape
     assert np.array_equal(got, want)
+
+
+def test_randomised_rigs(pano, po):
+    """seeded random rigs: 2-5 cameras, random focal / yaw step / pitch / roll, odd frame sizes, both projectors,
+    0-6 bands, random cut, soft random masks on half of the cases"""
+    import math
+    rng = np.random.default_rng(2024)
+    done = 0
+    for case in range(40):
+        n = int(rng.integers(2, 6))
+        w, h = int(rng.integers(40, 400)), int(rng.integers(30, 260))
+        f = float(rng.uniform(0.6, 1.6)) * w
+        step = float(rng.uniform(8.0, 30.0)) * (1 if rng.random() < 0.5 else -1)
+        yaw0 = -step * (n - 1) / 2 + float(rng.uniform(-5, 5))
+        kind = int(rng.integers(0, 2))
+        bands = int(rng.integers(0, 7))
+        K = [f, 0.0, w / 2.0 + float(rng.uniform(-5, 5)), 0.0, f * float(rng.uniform(0.95, 1.05)), h / 2.0, 0.0, 0.0, 1.0]
+        Rs = []
+        for i in range(n):
+            a, b, c = math.radians(yaw0 + i * step), math.radians(float(rng.uniform(-6, 6))), math.radians(float(rng.uniform(-4, 4)))
+            ry_ = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+            rx_ = np.array([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+            rz_ = np.array([[math.cos(c), -math.sin(c), 0], [math.sin(c), math.cos(c), 0], [0, 0, 1]])
+            Rs.append((ry_ @ rx_ @ rz_).astype(np.float32).reshape(9).tolist())
+        d = {"K": [K] * n, "R": Rs, "scale": f * float(rng.uniform(0.9, 1.1)), "w": w, "h": h, "n": n}
+        try:
+            ctx = make_ctx(pano, d, kind, num_bands=bands)
+        except pano.PanoError as e:
+            assert e.status == -6   # a camera wraps the seam: rejected, never computed wrongly
+            continue
+        frames = [synth_frame(w, h, 100 + case * 8 + i) for i in range(n)]
+        if case % 2:
+            masks = [rng.integers(0, 256, size=(ctx.roi(i)[3], ctx.roi(i)[2]), dtype=np.uint8) for i in range(n)]
+            for i in range(n):
+                ctx.set_mask(i, masks[i])
+        else:
+            ctx.build_masks_voronoi()
+            masks = [ctx.get_mask(i) for i in range(n)]
+            want_masks = oracle_masks(po, d, kind)
+            for i in range(n):
+                assert np.array_equal(masks[i], want_masks[i]), case
+        pr = ctx.pano_rect()
+        cut = None
+        if case % 3 == 0 and pr[2] > 20 and pr[3] > 20:
+            cx, cy = int(rng.integers(0, pr[2] // 2)), int(rng.integers(0, pr[3] // 2))
+            cut = (cx, cy, int(rng.integers(1, pr[2] - cx + 1)), int(rng.integers(1, pr[3] - cy + 1)))
+            ctx.set_cut(cut)
+        want, _ = po.compose(frames, d["K"], d["R"], d["scale"], masks, bands, kind=kind, cut=cut)
+        got = ctx.compose_host(frames)
+        assert got.shape == want.shape, case
+        assert np.array_equal(got, want), (case, n, w, h, kind, bands, cut)
+        done += 1
+    assert done >= 25
