@@ -77,10 +77,10 @@ def load_library():
 # every symbol include/pano.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
     "pano_create", "pano_destroy", "pano_last_error", "pano_version", "pano_set_camera",
-    "pano_set_cameras_from_list", "pano_load_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
+    "pano_set_cameras_from_list", "pano_load_camera_file", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
     "pano_build_masks_voronoi", "pano_get_mask", "pano_set_gain_map", "pano_warp", "pano_warp_mask", "pano_compose",
-    "pano_compose_host", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_set_profiling",
+    "pano_compose_host", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_set_profiling",
     "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_debug_get_level", "pano_debug_get_weights",
     "pano_debug_get_canvas_weights", "pano_debug_get_canvas",
 ]
@@ -132,6 +132,9 @@ class Context:
 
     def load_camera_file(self, path):
         self._ck(self.lib.pano_load_camera_file(self.h, os.fsencode(path)))
+
+    def save_camera_file(self, path):
+        self._ck(self.lib.pano_save_camera_file(self.h, os.fsencode(path)))
 
     def prepare(self):
         self._ck(self.lib.pano_prepare(self.h))
@@ -214,6 +217,16 @@ class Context:
 
     def warp_mask(self, i, d_dst, dst_stride, stream=0):
         self._ck(self.lib.pano_warp_mask(self.h, i, _vp(d_dst), C.c_size_t(dst_stride), _vp(stream)))
+
+    # -- caller-side assembly (device pointers)
+    def stack_master(self, d_up, up_w, up_h, up_stride, d_down, dw, dh, d_stride, d_out, out_stride, stream=0):
+        self._ck(self.lib.pano_stack_master(self.h, _vp(d_up), up_w, up_h, C.c_size_t(up_stride), _vp(d_down), dw, dh,
+                                            C.c_size_t(d_stride), _vp(d_out), C.c_size_t(out_stride), _vp(stream)))
+
+    def stack_finalcut(self, d_up, up_w, up_h, up_stride, d_down, dw, dh, d_stride, finalcut, d_out, out_stride, stream=0):
+        self._ck(self.lib.pano_stack_finalcut(self.h, _vp(d_up), up_w, up_h, C.c_size_t(up_stride), _vp(d_down), dw, dh,
+                                              C.c_size_t(d_stride), int(finalcut), _vp(d_out), C.c_size_t(out_stride),
+                                              _vp(stream)))
 
     # -- measurement
     def set_profiling(self, on):

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -456,6 +457,28 @@ pano_status pano_load_camera_file(pano_ctx* c, const char* path) {
         return fail(c, PANO_ERR, "camera parameter file: record shape");
     }
     c->cfg.warped_image_scale = c->scale;
+    return PANO_OK;
+}
+
+pano_status pano_save_camera_file(pano_ctx* c, const char* path) {
+    if (!c || !path) return PANO_EINVAL;
+    for (int i = 0; i < c->cfg.num_images; i++)
+        if (!c->have_cam[i]) return fail(c, PANO_ESTATE, "camera parameters missing");
+    FILE* f = fopen(path, "a");
+    if (!f) return fail(c, PANO_ERR, "cannot open camera parameter file for append");
+    time_t tt = time(nullptr);
+    struct tm tmv;
+    localtime_r(&tt, &tmv);
+    char stamp[64];
+    strftime(stamp, sizeof(stamp), "%F-%H-%M-%S:", &tmv);
+    fprintf(f, "%s\n", stamp);
+    for (int i = 0; i < c->cfg.num_images; i++) {
+        for (int k = 0; k < 9; k++) fprintf(f, "%g,", c->K[i][k]);
+        for (int k = 0; k < 9; k++) fprintf(f, "%g,", c->R[i][k]);
+        fprintf(f, "\n");
+    }
+    fprintf(f, "%g\n", c->scale);
+    fclose(f);
     return PANO_OK;
 }
 
@@ -982,6 +1005,38 @@ pano_status pano_compose_host(pano_ctx* c, const uint8_t* const* h_frames, const
     HIP_TRY(c, hipMemcpy2DAsync(h_out, out_stride, c->stage_out, out_pitch, (size_t)P.cut.w * 3, P.cut.h,
                                 hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    return PANO_OK;
+}
+
+pano_status pano_stack_master(pano_ctx* c, const uint8_t* d_up, int up_w, int up_h, size_t up_stride, const uint8_t* d_down,
+                              int down_w, int down_h, size_t down_stride, uint8_t* d_out, size_t out_stride, void* stream) {
+    if (!c) return PANO_EINVAL;
+    if (c->device < 0) return fail(c, PANO_ENODEVICE, "plan-only context");
+    if (!d_up || !d_down || !d_out || up_w < 1 || up_h < 1 || down_w < 1 || down_h < 1 || up_stride < (size_t)up_w * 3 ||
+        down_stride < (size_t)down_w * 3 || out_stride < (size_t)down_w * 3)
+        return PANO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool resize_up = !(up_w == down_w && up_h == down_h);  // cv::resize to the same size is a copy
+    const int rows = 2 * down_h;
+    launch_stack(d_up, up_w, up_h, (int)up_stride, 0, resize_up, d_down, (int)down_stride, 0, d_out, down_w, down_h,
+                 (int)out_stride, rows / 2 - 5, 10, (hipStream_t)stream);
+    HIP_TRY(c, hipGetLastError());
+    return PANO_OK;
+}
+
+pano_status pano_stack_finalcut(pano_ctx* c, const uint8_t* d_up, int up_w, int up_h, size_t up_stride, const uint8_t* d_down,
+                                int down_w, int down_h, size_t down_stride, int finalcut, uint8_t* d_out, size_t out_stride,
+                                void* stream) {
+    if (!c) return PANO_EINVAL;
+    if (c->device < 0) return fail(c, PANO_ENODEVICE, "plan-only context");
+    const int width = std::min(up_w, down_w), height = std::min(up_h, down_h) - 2 * finalcut;
+    if (!d_up || !d_down || !d_out || finalcut < 0 || width < 1 || height < 1 || up_stride < (size_t)up_w * 3 ||
+        down_stride < (size_t)down_w * 3 || out_stride < (size_t)width * 3)
+        return PANO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    launch_stack(d_up, width, height, (int)up_stride, finalcut, false, d_down, (int)down_stride, finalcut, d_out, width, height,
+                 (int)out_stride, height - 2, 4, (hipStream_t)stream);
+    HIP_TRY(c, hipGetLastError());
     return PANO_OK;
 }
 

@@ -1405,6 +1405,67 @@ void launch_sum_weights(const PyrParams& p, int l, float* wsum, int cw, int ch, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// caller-side assembly (src/master.cpp:321-326, src/panocamimpl.cpp:354-360): optional cv::resize INTER_LINEAR of
+// the upper half (CV_8U: short coefficients x2048 from fx = (float)((dx+0.5)*scale-0.5), int horizontal pass,
+// ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2 >> 2 vertical pass), vconcat, black divider
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void linear_coef_8u(int d, int ssize, int dsize, bool clamp_edge, int& s0, int& s1, int& a0,
+                                               int& a1) {
+    const double scale = (double)ssize / dsize;
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (clamp_edge) {  // horizontal: fx is reset at the borders
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    }
+    a0 = sat16i(cv_round_dev((1.f - f) * 2048.f));
+    a1 = sat16i(cv_round_dev(f * 2048.f));
+    s0 = min(max(s, 0), ssize - 1);
+    s1 = min(max(s + 1, 0), ssize - 1);
+}
+__global__ __launch_bounds__(256) void stack_kernel(const uint8_t* up, int up_w, int up_h, int up_stride, int up_y0,
+                                                    int resize_up, const uint8_t* down, int down_stride, int down_y0,
+                                                    uint8_t* out, int out_w, int top_h, int out_stride, int bar_y,
+                                                    int bar_h) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= out_w || y >= 2 * top_h) return;
+    int v[3] = {0, 0, 0};
+    if (y < bar_y || y >= bar_y + bar_h) {
+        if (y >= top_h) {
+            const uint8_t* p = down + (size_t)(y - top_h + down_y0) * down_stride + 3 * x;
+            v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+        } else if (!resize_up) {
+            const uint8_t* p = up + (size_t)(y + up_y0) * up_stride + 3 * x;
+            v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+        } else {
+            int x0, x1, a0, a1, y0, y1, b0, b1;
+            linear_coef_8u(x, up_w, out_w, true, x0, x1, a0, a1);
+            linear_coef_8u(y, up_h, top_h, false, y0, y1, b0, b1);
+            const uint8_t* r0 = up + (size_t)y0 * up_stride;
+            const uint8_t* r1 = up + (size_t)y1 * up_stride;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int h0 = r0[3 * x0 + c] * a0 + r0[3 * x1 + c] * a1;
+                const int h1 = r1[3 * x0 + c] * a0 + r1[3 * x1 + c] * a1;
+                v[c] = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            }
+        }
+    }
+    uint8_t* d = out + (size_t)y * out_stride + 3 * x;
+    d[0] = (uint8_t)v[0];
+    d[1] = (uint8_t)v[1];
+    d[2] = (uint8_t)v[2];
+}
+void launch_stack(const uint8_t* up, int up_w, int up_h, int up_stride, int up_y0, bool resize_up, const uint8_t* down,
+                  int down_stride, int down_y0, uint8_t* out, int out_w, int top_h, int out_stride, int bar_y, int bar_h,
+                  hipStream_t s) {
+    dim3 block(64, 4, 1), grid((out_w + 63) / 64, (2 * top_h + 3) / 4, 1);
+    hipLaunchKernelGGL(stack_kernel, grid, block, 0, s, up, up_w, up_h, up_stride, up_y0, resize_up ? 1 : 0, down,
+                       down_stride, down_y0, out, out_w, top_h, out_stride, bar_y, bar_h);
+}
+
+// ------------------------------------------------------------------------------------------------
 // mask preparation
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dilate3x3_kernel(const uint8_t* src, uint8_t* dst, int w, int h) {

@@ -101,6 +101,13 @@ void launch_mask_to_weight(const uint8_t* mask, int mw, int mh, int mpitch, int 
 void launch_pyr_down_f32(const float* src, int sw, int sh, int spitch, float* dst, int dpitch, hipStream_t s);
 void launch_sum_weights(const PyrParams& p, int l, float* wsum, int cw, int ch, hipStream_t s);
 
+// caller-side assembly: out rows [0, top_h) = up (resized to out_w x top_h with cv::resize INTER_LINEAR semantics, or
+// copied from row up_y0 when up_w == out_w && up_rows == top_h), rows [top_h, 2*top_h) = down from row down_y0;
+// rows [bar_y, bar_y + bar_h) black
+void launch_stack(const uint8_t* up, int up_w, int up_h, int up_stride, int up_y0, bool resize_up,
+                  const uint8_t* down, int down_stride, int down_y0, uint8_t* out, int out_w, int top_h, int out_stride,
+                  int bar_y, int bar_h, hipStream_t s);
+
 // mask preparation (Voronoi)
 void launch_dilate3x3(const uint8_t* src, uint8_t* dst, int w, int h, hipStream_t s);
 void launch_resize_linear_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh,

@@ -79,6 +79,11 @@ pano_status pano_set_cameras_from_list(pano_ctx* ctx, const char* comma_separate
  * old 7-line shared-K format of 2222/cameraparaout_*.txt also accepted) */
 pano_status pano_load_camera_file(pano_ctx* ctx, const char* path);
 
+/* append the current K / R / scale as a new record to a cameraparaout_<id>.txt log, in the format
+ * saveCameraParams writes (ocvstitcher.hpp:522-562): "YYYY-MM-DD-HH-MM-SS:" / N lines of 18 values with trailing
+ * commas / scale; values in ostream default formatting (6 significant digits) */
+pano_status pano_save_camera_file(pano_ctx* ctx, const char* path);
+
 /* ---- geometry: RotationWarper::warpRoi x N, resultRoi, band rule, Blender::prepare --------
  * (initSeam compose half, ocvstitcher.hpp:1054-1063, :1107-1121; per-frame :1186-1198).
  * Allocates every device buffer the ctx will ever use. */
@@ -139,6 +144,18 @@ pano_status pano_feed_cameras(pano_ctx* ctx, unsigned cam_bits, const uint8_t* c
 pano_status pano_get_pyramid_slots(pano_ctx* ctx, void** d_base, size_t* slot_bytes);
 /* Blender::blend + 8U + cut over whatever the pyramid slots hold */
 pano_status pano_blend(pano_ctx* ctx, uint8_t* d_out, size_t out_stride, void* hip_stream);
+
+/* ---- caller-side assembly of the two half panoramas (device buffers, BGR8) ------------------------------ */
+/* src/master.cpp:321-326: cv::resize(up, up, down.size()) [INTER_LINEAR], cv::vconcat(up, down), black 10-row
+ * divider centred on the seam.  d_out is down_w x 2*down_h.  `ctx` (either stitcher) names the device. */
+pano_status pano_stack_master(pano_ctx* ctx, const uint8_t* d_up, int up_w, int up_h, size_t up_stride,
+                              const uint8_t* d_down, int down_w, int down_h, size_t down_stride,
+                              uint8_t* d_out, size_t out_stride, void* hip_stream);
+/* src/panocamimpl.cpp:354-360: crop both halves to (min width) x (min height - 2*finalcut) from row `finalcut`,
+ * vconcat, black 4-row divider.  d_out is min_w x 2*(min_h - 2*finalcut). */
+pano_status pano_stack_finalcut(pano_ctx* ctx, const uint8_t* d_up, int up_w, int up_h, size_t up_stride,
+                                const uint8_t* d_down, int down_w, int down_h, size_t down_stride, int finalcut,
+                                uint8_t* d_out, size_t out_stride, void* hip_stream);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 enum { PANO_STAGE_WARP = 0, PANO_STAGE_PYRAMID = 1, PANO_STAGE_BLEND = 2, PANO_NUM_STAGES = 3 };

@@ -875,6 +875,72 @@ void po_gain_apply_8uc3(uint8_t* img, int w, int h, const float* g) {
         for (int c = 0; c < 3; c++) img[k * 3 + c] = sat8(cv_round_f(img[k * 3 + c] * g[k]));
 }
 
+/* ======================================================================== caller-side assembly */
+
+/* cv::resize INTER_LINEAR CV_8U (resize.cpp): fx = (float)((dx+0.5)*scale - 0.5), coefficients
+ * saturate_cast<short>(c * 2048); HResizeLinear int accumulation; VResizeLinear 8u special:
+ * ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2 >> 2.  Equal sizes are a plain copy. */
+void po_resize_linear_8u(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh) {
+    if (sw == dw && sh == dh) {
+        memcpy(dst, src, (size_t)sw * sh * cn);
+        return;
+    }
+    double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    int* xofs = (int*)malloc(sizeof(int) * dw);
+    short* ialpha = (short*)malloc(sizeof(short) * 2 * dw);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ialpha[2 * dx] = sat16(cv_round_f((1.f - fx) * 2048));
+        ialpha[2 * dx + 1] = sat16(cv_round_f(fx * 2048));
+    }
+    int* r0 = (int*)malloc(sizeof(int) * (size_t)dw * cn);
+    int* r1 = (int*)malloc(sizeof(int) * (size_t)dw * cn);
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        short b0 = sat16(cv_round_f((1.f - fy) * 2048)), b1 = sat16(cv_round_f(fy * 2048));
+        int y0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy), y1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
+        const uint8_t* S0 = src + (size_t)y0 * sw * cn;
+        const uint8_t* S1 = src + (size_t)y1 * sw * cn;
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = xofs[dx], sx1 = sx + 1 < sw ? sx + 1 : sx;
+            for (int c = 0; c < cn; c++) {
+                r0[dx * cn + c] = S0[sx * cn + c] * ialpha[2 * dx] + S0[sx1 * cn + c] * ialpha[2 * dx + 1];
+                r1[dx * cn + c] = S1[sx * cn + c] * ialpha[2 * dx] + S1[sx1 * cn + c] * ialpha[2 * dx + 1];
+            }
+        }
+        uint8_t* D = dst + (size_t)dy * dw * cn;
+        for (int x = 0; x < dw * cn; x++) D[x] = (uint8_t)((((b0 * (r0[x] >> 4)) >> 16) + ((b1 * (r1[x] >> 4)) >> 16) + 2) >> 2);
+    }
+    free(xofs); free(ialpha); free(r0); free(r1);
+}
+
+/* src/master.cpp:321-326 */
+void po_stack_master(const uint8_t* up, int uw, int uh, const uint8_t* down, int dw, int dh, uint8_t* out) {
+    po_resize_linear_8u(up, uw, uh, 3, out, dw, dh);
+    memcpy(out + (size_t)dw * dh * 3, down, (size_t)dw * dh * 3);
+    int rows = 2 * dh;
+    for (int y = rows / 2 - 5; y < rows / 2 + 5; y++)  /* cv::rectangle(Rect(0, rows/2-5, cols, 10), 0, filled) */
+        if (y >= 0 && y < rows) memset(out + (size_t)y * dw * 3, 0, (size_t)dw * 3);
+}
+
+/* src/panocamimpl.cpp:354-360 */
+void po_stack_finalcut(const uint8_t* up, int uw, int uh, const uint8_t* down, int dw, int dh, int finalcut, uint8_t* out) {
+    int width = uw < dw ? uw : dw, height = (uh < dh ? uh : dh) - finalcut * 2;
+    for (int y = 0; y < height; y++) {
+        memcpy(out + (size_t)y * width * 3, up + ((size_t)(y + finalcut) * uw) * 3, (size_t)width * 3);
+        memcpy(out + (size_t)(y + height) * width * 3, down + ((size_t)(y + finalcut) * dw) * 3, (size_t)width * 3);
+    }
+    for (int y = height - 2; y < height + 2; y++)  /* cv::rectangle(Rect(0, height-2, width, 4), 0, filled) */
+        if (y >= 0 && y < 2 * height) memset(out + (size_t)y * width * 3, 0, (size_t)width * 3);
+}
+
 /* ======================================================================== mask preparation */
 
 /* ocvStitcher::initSeam (ocvstitcher.hpp:975-1101) with VoronoiSeamFinder in place of GraphCut

@@ -125,6 +125,15 @@ int po_compose(const po_compose_args* a, uint8_t* out, int out_wh[2]);
 /* stage timings of the last po_compose on this thread, ms: warp, feed(pyramids+accumulate), blend */
 void po_last_timings(double ms[3]);
 
+/* ---- caller-side assembly of the two half panoramas (the step right after the path) */
+/* cv::resize(src, dst, dsize) INTER_LINEAR, CV_8U (imgproc/src/resize.cpp: 11-bit fixed-point coefficients) */
+void po_resize_linear_8u(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh);
+/* src/master.cpp:321-326: resize(up -> down.size()), vconcat, black 10-row bar; out is dw x 2*dh */
+void po_stack_master(const uint8_t* up, int uw, int uh, const uint8_t* down, int dw, int dh, uint8_t* out);
+/* src/panocamimpl.cpp:354-360: crop both to min width, min height - 2*finalcut (from row finalcut), vconcat,
+ * black 4-row bar; out is min_w x 2*(min_h - 2*finalcut) */
+void po_stack_finalcut(const uint8_t* up, int uw, int uh, const uint8_t* down, int dw, int dh, int finalcut, uint8_t* out);
+
 void po_set_threads(int n);
 int po_get_threads(void);
 

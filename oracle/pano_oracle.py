@@ -179,6 +179,29 @@ def distance_l1(a):
     return d
 
 
+def resize_linear_8u(a, dw, dh):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    h, w = a.shape[:2]; cn = 1 if a.ndim == 2 else a.shape[2]
+    d = np.empty((dh, dw) + (() if a.ndim == 2 else (cn,)), np.uint8)
+    lib().po_resize_linear_8u(_p(a), w, h, cn, _p(d), int(dw), int(dh))
+    return d
+
+
+def stack_master(up, down):
+    up = np.ascontiguousarray(up, np.uint8); down = np.ascontiguousarray(down, np.uint8)
+    out = np.empty((2 * down.shape[0], down.shape[1], 3), np.uint8)
+    lib().po_stack_master(_p(up), up.shape[1], up.shape[0], _p(down), down.shape[1], down.shape[0], _p(out))
+    return out
+
+
+def stack_finalcut(up, down, finalcut):
+    up = np.ascontiguousarray(up, np.uint8); down = np.ascontiguousarray(down, np.uint8)
+    w = min(up.shape[1], down.shape[1]); h = min(up.shape[0], down.shape[0]) - 2 * finalcut
+    out = np.empty((2 * h, w, 3), np.uint8)
+    lib().po_stack_finalcut(_p(up), up.shape[1], up.shape[0], _p(down), down.shape[1], down.shape[0], int(finalcut), _p(out))
+    return out
+
+
 def bands_from_strength(w, h, strength):
     return lib().po_bands_from_strength(int(w), int(h), C.c_float(strength))
 

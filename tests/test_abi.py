@@ -95,6 +95,25 @@ def test_camera_file_loader(pano, c1, tmp_path):
         pano.Context(4, 480, 270, device=-1).load_camera_file(str(tmp_path / "missing.txt"))
 
 
+def test_camera_file_writer_roundtrip(pano, c1, tmp_path):
+    """saveCameraParams format (ocvstitcher.hpp:522-562): append a record, read it back with the loader"""
+    p = tmp_path / "cameraparaout_0.txt"
+    ctx = pano.Context(4, 480, 270, scale=c1["scale"], num_bands=2, device=-1)
+    for i in range(4):
+        ctx.set_camera(i, c1["K"][i], c1["R"][i])
+    ctx.save_camera_file(str(p))
+    ctx.save_camera_file(str(p))                      # logs are append-only: two records now
+    lines = p.read_text().strip().splitlines()
+    assert len(lines) == 12 and lines[0].endswith(":") and lines[6].endswith(":")
+    assert lines[1].count(",") == 18 and lines[1].startswith("391.047,0,240,0,391.047,135,0,0,1,")
+    assert lines[5] == "381.719"
+    ctx.prepare()
+    ctx2 = pano.Context(4, 480, 270, num_bands=2, device=-1)
+    ctx2.load_camera_file(str(p))
+    ctx2.prepare()
+    assert ctx2.pano_rect() == ctx.pano_rect() and [ctx2.roi(i) for i in range(4)] == [ctx.roi(i) for i in range(4)]
+
+
 def test_errors_and_no_cpu_fallback(pano, c1):
     with pytest.raises(pano.PanoError):
         pano.Context(0, 480, 270, device=-1)

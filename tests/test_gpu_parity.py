@@ -402,3 +402,22 @@ def test_randomised_rigs(pano, po):
         assert np.array_equal(got, want), (case, n, w, h, kind, bands, cut)
         done += 1
     assert done >= 25
+
+
+def test_caller_side_assembly(pano, po, torch, c1):
+    """pano_stack_master / pano_stack_finalcut against the oracle (cv::resize INTER_LINEAR + vconcat + divider)"""
+    rng = np.random.default_rng(9)
+    ctx = make_ctx(pano, c1, 0, num_bands=0)
+    s = torch.cuda.current_stream().cuda_stream
+    for (uw, uh, dw, dh) in ((1430, 250, 1470, 250), (333, 77, 200, 91), (640, 120, 640, 120)):
+        up = rng.integers(0, 256, size=(uh, uw, 3), dtype=np.uint8); down = rng.integers(0, 256, size=(dh, dw, 3), dtype=np.uint8)
+        tu, td = torch.from_numpy(up).cuda(), torch.from_numpy(down).cuda()
+        out = torch.zeros((2 * dh, dw, 3), dtype=torch.uint8, device="cuda")
+        ctx.stack_master(tu.data_ptr(), uw, uh, uw * 3, td.data_ptr(), dw, dh, dw * 3, out.data_ptr(), dw * 3, s)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), po.stack_master(up, down))
+        w, h = min(uw, dw), min(uh, dh) - 8
+        out2 = torch.zeros((2 * h, w, 3), dtype=torch.uint8, device="cuda")
+        ctx.stack_finalcut(tu.data_ptr(), uw, uh, uw * 3, td.data_ptr(), dw, dh, dw * 3, 4, out2.data_ptr(), w * 3, s)
+        torch.cuda.synchronize()
+        assert np.array_equal(out2.cpu().numpy(), po.stack_finalcut(up, down, 4))

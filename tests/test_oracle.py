@@ -216,3 +216,16 @@ def test_oracle_reproduces_committed_golden(po, c1):
         assert sha(pano) == g["pano_sha256"][str(nb)]
         if nb == 4:
             assert np.array_equal(pano, load_png_bgr(os.path.join(GOLDEN, "c1_pano_b4.png")))
+
+
+def test_caller_side_assembly_known_answers(po):
+    """cv::resize INTER_LINEAR 8U, vconcat and the divider bars of master.cpp:321-326 / panocamimpl.cpp:354-360"""
+    a = np.array([[[0, 0, 0], [255, 255, 255]]], np.uint8)
+    assert po.resize_linear_8u(a, 4, 1)[0, :, 0].tolist() == [0, 64, 191, 255]
+    b = np.arange(6 * 4 * 3, dtype=np.uint8).reshape(4, 6, 3)
+    assert np.array_equal(po.resize_linear_8u(b, 6, 4), b)           # same size: copy
+    up = np.full((30, 50, 3), 200, np.uint8); down = np.full((40, 60, 3), 100, np.uint8)
+    m = po.stack_master(up, down)
+    assert m.shape == (80, 60, 3) and (m[:35] == 200).all() and (m[35:45] == 0).all() and (m[45:] == 100).all()
+    f = po.stack_finalcut(up, down, 3)
+    assert f.shape == (48, 50, 3) and (f[:22] == 200).all() and (f[22:26] == 0).all() and (f[26:] == 100).all()
