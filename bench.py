@@ -200,6 +200,22 @@ def main():
                 for grp in range(NG):
                     ctxs[grp].compose_host(hframes[grp])
             result["host_buffer_path_panoramas_per_s"] = round(20 / (time.perf_counter() - th), 1)
+            # streaming form (BASELINE config 5): frames land in the library's pinned slots, two panoramas in flight
+            for grp in range(NG):
+                for s in range(2):
+                    for i in range(NC):
+                        ctxs[grp].stream_input(s, i)[:] = hframes[grp][i]
+            nstream = 60
+            ts = time.perf_counter()
+            for k in range(nstream + 1):
+                s = k & 1
+                if k >= 1:
+                    for grp in range(NG):
+                        ctxs[grp].stream_wait(1 - s)
+                if k < nstream:
+                    for grp in range(NG):
+                        ctxs[grp].stream_submit(s)
+            result["host_streaming_panoramas_per_s"] = round(nstream / (time.perf_counter() - ts), 1)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(ctxs, g, args.bands)
         print(json.dumps(result), flush=True)

@@ -80,7 +80,8 @@ EXPORTS = [
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
     "pano_build_masks_voronoi", "pano_get_mask", "pano_set_gain_map", "pano_warp", "pano_warp_mask", "pano_compose",
-    "pano_compose_host", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_set_profiling",
+    "pano_compose_host", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_stream_input", "pano_stream_output",
+    "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
     "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_debug_get_level", "pano_debug_get_weights",
     "pano_debug_get_canvas_weights", "pano_debug_get_canvas",
 ]
@@ -217,6 +218,26 @@ class Context:
 
     def warp_mask(self, i, d_dst, dst_stride, stream=0):
         self._ck(self.lib.pano_warp_mask(self.h, i, _vp(d_dst), C.c_size_t(dst_stride), _vp(stream)))
+
+    # -- streaming slots: numpy views of the library's pinned buffers
+    def stream_input(self, slot, cam):
+        p = C.c_void_p(); st = C.c_size_t()
+        self._ck(self.lib.pano_stream_input(self.h, slot, cam, C.byref(p), C.byref(st)))
+        buf = (C.c_uint8 * (st.value * self.height)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(self.height, st.value)[:, :self.width * 3].reshape(self.height, self.width, 3)
+
+    def stream_output(self, slot):
+        p = C.c_void_p(); st = C.c_size_t()
+        self._ck(self.lib.pano_stream_output(self.h, slot, C.byref(p), C.byref(st)))
+        w, h = self.output_size()
+        buf = (C.c_uint8 * (st.value * h)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(h, st.value)[:, :w * 3].reshape(h, w, 3)
+
+    def stream_submit(self, slot):
+        self._ck(self.lib.pano_stream_submit(self.h, slot))
+
+    def stream_wait(self, slot):
+        self._ck(self.lib.pano_stream_wait(self.h, slot))
 
     # -- caller-side assembly (device pointers)
     def stack_master(self, d_up, up_w, up_h, up_stride, d_down, dw, dh, d_stride, d_out, out_stride, stream=0):

@@ -78,6 +78,19 @@ struct pano_ctx {
     uint8_t* stage_out = nullptr;
     size_t stage_out_pitch = 0;
     hipStream_t own_stream = nullptr;
+    // streaming slots (pano_stream_*): pinned host buffers, per-slot device buffers, copy streams and events
+    struct StreamSlot {
+        uint8_t* h_in[kMaxCams] = {};
+        uint8_t* d_in[kMaxCams] = {};
+        uint8_t* h_out = nullptr;
+        uint8_t* d_out = nullptr;
+        hipStream_t h2d = nullptr, d2h = nullptr;
+        hipEvent_t in_ready = nullptr, composed = nullptr, out_ready = nullptr;
+        bool busy = false;
+    };
+    StreamSlot slots[PANO_STREAM_SLOTS];
+    bool slots_ready = false;
+    size_t slot_in_pitch = 0, slot_out_pitch = 0;
 
     // profiling: a ring of event quads so that the timed loop never has to wait for the GPU
     static constexpr int kEvRing = 64;
@@ -164,6 +177,24 @@ void free_device(pano_ctx* c) {
         dfree(c->wsum[l]);
         dfree(c->canvas[l]);
     }
+    for (auto& sl : c->slots) {
+        for (int i = 0; i < kMaxCams; i++) {
+            if (sl.h_in[i]) (void)hipHostFree(sl.h_in[i]);
+            sl.h_in[i] = nullptr;
+            dfree(sl.d_in[i]);
+        }
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        sl.h_out = nullptr;
+        dfree(sl.d_out);
+        if (sl.h2d) (void)hipStreamDestroy(sl.h2d);
+        if (sl.d2h) (void)hipStreamDestroy(sl.d2h);
+        if (sl.in_ready) (void)hipEventDestroy(sl.in_ready);
+        if (sl.composed) (void)hipEventDestroy(sl.composed);
+        if (sl.out_ready) (void)hipEventDestroy(sl.out_ready);
+        sl.h2d = sl.d2h = nullptr;
+        sl.in_ready = sl.composed = sl.out_ready = nullptr;
+    }
+    c->slots_ready = false;
     dfree(c->pyr_base);
     dfree(c->stage_out);
     if (c->ev_valid)
@@ -1037,6 +1068,87 @@ pano_status pano_stack_finalcut(pano_ctx* c, const uint8_t* d_up, int up_w, int 
     launch_stack(d_up, width, height, (int)up_stride, finalcut, false, d_down, (int)down_stride, finalcut, d_out, width, height,
                  (int)out_stride, height - 2, 4, (hipStream_t)stream);
     HIP_TRY(c, hipGetLastError());
+    return PANO_OK;
+}
+
+namespace {
+pano_status ensure_slots(pano_ctx* c) {
+    if (c->slots_ready) return PANO_OK;
+    const Plan& P = c->plan;
+    c->slot_in_pitch = align_up((size_t)P.src_w * 3, 256);
+    c->slot_out_pitch = align_up((size_t)P.pano.w * 3, 256);  // room for any later cut
+    for (auto& sl : c->slots) {
+        for (int i = 0; i < P.n; i++) {
+            HIP_TRY(c, hipHostMalloc((void**)&sl.h_in[i], c->slot_in_pitch * P.src_h, hipHostMallocDefault));
+            HIP_TRY(c, hipMalloc((void**)&sl.d_in[i], c->slot_in_pitch * P.src_h + 64));
+        }
+        HIP_TRY(c, hipHostMalloc((void**)&sl.h_out, c->slot_out_pitch * P.pano.h, hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc((void**)&sl.d_out, c->slot_out_pitch * P.pano.h));
+        HIP_TRY(c, hipStreamCreateWithFlags(&sl.h2d, hipStreamNonBlocking));
+        HIP_TRY(c, hipStreamCreateWithFlags(&sl.d2h, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&sl.in_ready, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&sl.composed, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&sl.out_ready, hipEventDisableTiming));
+    }
+    c->slots_ready = true;
+    return PANO_OK;
+}
+}  // namespace
+
+pano_status pano_stream_input(pano_ctx* c, int slot, int cam, uint8_t** h_ptr, size_t* stride) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (slot < 0 || slot >= PANO_STREAM_SLOTS || cam < 0 || cam >= c->plan.n || !h_ptr || !stride) return PANO_EINVAL;
+    if ((st = ensure_slots(c)) != PANO_OK) return st;
+    *h_ptr = c->slots[slot].h_in[cam];
+    *stride = c->slot_in_pitch;
+    return PANO_OK;
+}
+
+pano_status pano_stream_output(pano_ctx* c, int slot, uint8_t** h_ptr, size_t* stride) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (slot < 0 || slot >= PANO_STREAM_SLOTS || !h_ptr || !stride) return PANO_EINVAL;
+    if ((st = ensure_slots(c)) != PANO_OK) return st;
+    *h_ptr = c->slots[slot].h_out;
+    *stride = c->slot_out_pitch;
+    return PANO_OK;
+}
+
+pano_status pano_stream_submit(pano_ctx* c, int slot) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (slot < 0 || slot >= PANO_STREAM_SLOTS) return PANO_EINVAL;
+    if ((st = ensure_slots(c)) != PANO_OK) return st;
+    pano_ctx::StreamSlot& sl = c->slots[slot];
+    if (sl.busy) return fail(c, PANO_ESTATE, "slot still in flight: pano_stream_wait it first");
+    const Plan& P = c->plan;
+    const uint8_t* frames[kMaxCams];
+    size_t pitches[kMaxCams];
+    for (int i = 0; i < P.n; i++) {
+        HIP_TRY(c, hipMemcpyAsync(sl.d_in[i], sl.h_in[i], c->slot_in_pitch * P.src_h, hipMemcpyHostToDevice, sl.h2d));
+        frames[i] = sl.d_in[i];
+        pitches[i] = c->slot_in_pitch;
+    }
+    HIP_TRY(c, hipEventRecord(sl.in_ready, sl.h2d));
+    HIP_TRY(c, hipStreamWaitEvent(c->own_stream, sl.in_ready, 0));
+    if ((st = pano_compose(c, frames, pitches, sl.d_out, c->slot_out_pitch, c->own_stream)) != PANO_OK) return st;
+    HIP_TRY(c, hipEventRecord(sl.composed, c->own_stream));
+    HIP_TRY(c, hipStreamWaitEvent(sl.d2h, sl.composed, 0));
+    HIP_TRY(c, hipMemcpyAsync(sl.h_out, sl.d_out, c->slot_out_pitch * P.cut.h, hipMemcpyDeviceToHost, sl.d2h));
+    HIP_TRY(c, hipEventRecord(sl.out_ready, sl.d2h));
+    sl.busy = true;
+    return PANO_OK;
+}
+
+pano_status pano_stream_wait(pano_ctx* c, int slot) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (slot < 0 || slot >= PANO_STREAM_SLOTS || !c->slots_ready) return PANO_EINVAL;
+    pano_ctx::StreamSlot& sl = c->slots[slot];
+    if (!sl.busy) return fail(c, PANO_ESTATE, "slot was not submitted");
+    HIP_TRY(c, hipEventSynchronize(sl.out_ready));
+    sl.busy = false;
     return PANO_OK;
 }
 

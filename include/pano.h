@@ -134,6 +134,18 @@ pano_status pano_compose(pano_ctx* ctx, const uint8_t* const* d_frames, const si
 pano_status pano_compose_host(pano_ctx* ctx, const uint8_t* const* h_frames, const size_t* strides,
                               uint8_t* h_out, size_t out_stride);
 
+/* ---- streaming form for a capture loop (BASELINE config 5: frames arrive in host memory at camera rate) ------
+ * The reference's loop (src/master.cpp:302-411) pops one cv::Mat per camera from the capture queues and calls
+ * process().  Here the library owns PINNED host buffers in PANO_STREAM_SLOTS slots: the producer writes camera i's
+ * frame of slot s into pano_stream_input(s, i), pano_stream_submit(s) queues H2D -> compose -> D2H and returns at
+ * once, pano_stream_wait(s) blocks until the panorama of slot s is in pano_stream_output(s).  The H2D of one slot
+ * overlaps the kernels of the other (separate copy streams, events). */
+#define PANO_STREAM_SLOTS 2
+pano_status pano_stream_input(pano_ctx* ctx, int slot, int cam, uint8_t** h_ptr, size_t* stride);
+pano_status pano_stream_output(pano_ctx* ctx, int slot, uint8_t** h_ptr, size_t* stride);
+pano_status pano_stream_submit(pano_ctx* ctx, int slot);
+pano_status pano_stream_wait(pano_ctx* ctx, int slot);
+
 /* ---- camera-sharded (multi-GPU) form of the same path -------------------------------------- */
 /* warp + Gaussian pyramid of the cameras selected by cam_bits (bit i = camera i) into the ctx's
  * pyramid slots; d_frames entries of unselected cameras are ignored */

@@ -421,3 +421,23 @@ def test_caller_side_assembly(pano, po, torch, c1):
         ctx.stack_finalcut(tu.data_ptr(), uw, uh, uw * 3, td.data_ptr(), dw, dh, dw * 3, 4, out2.data_ptr(), w * 3, s)
         torch.cuda.synchronize()
         assert np.array_equal(out2.cpu().numpy(), po.stack_finalcut(up, down, 4))
+
+
+def test_streaming_slots(pano, po, c1):
+    """pano_stream_*: pinned double-buffered H2D -> compose -> D2H; two frames in flight, results per slot"""
+    masks = oracle_masks(po, c1)
+    ctx = make_ctx(pano, c1, 0, num_bands=3)
+    for i in range(4):
+        ctx.set_mask(i, masks[i])
+    sets = [c1["frames"], c1["frames"][::-1]]
+    wants = [po.compose(f, c1["K"], c1["R"], c1["scale"], masks, 3)[0] for f in sets]
+    for rep in range(3):
+        for s in range(2):
+            for i in range(4):
+                ctx.stream_input(s, i)[:] = sets[s][i]
+            ctx.stream_submit(s)
+        with pytest.raises(pano.PanoError):
+            ctx.stream_submit(0)          # still in flight
+        for s in range(2):
+            ctx.stream_wait(s)
+            assert np.array_equal(ctx.stream_output(s), wants[s])
