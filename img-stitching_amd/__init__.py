@@ -34,6 +34,11 @@ class PanoError(RuntimeError):
         super().__init__(f"{_STATUS.get(status, status)}: {msg}")
 
 
+class Undistort(C.Structure):
+    _fields_ = [("raw_w", C.c_int), ("raw_h", C.c_int), ("undist_w", C.c_int), ("undist_h", C.c_int),
+                ("K", C.c_double * 9), ("dist", C.c_double * 4), ("rect", C.c_int * 4)]
+
+
 class Config(C.Structure):
     _fields_ = [("num_images", C.c_int), ("width", C.c_int), ("height", C.c_int), ("projector", C.c_int),
                 ("warped_image_scale", C.c_float), ("blend_strength", C.c_float), ("num_bands", C.c_int),
@@ -79,7 +84,7 @@ EXPORTS = [
     "pano_create", "pano_destroy", "pano_last_error", "pano_version", "pano_set_camera",
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
-    "pano_build_masks_voronoi", "pano_get_mask", "pano_set_gain_map", "pano_warp", "pano_warp_mask", "pano_compose",
+    "pano_build_masks_voronoi", "pano_get_mask", "pano_set_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
     "pano_compose_host", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_stream_input", "pano_stream_output",
     "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
     "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_debug_get_level", "pano_debug_get_weights",
@@ -106,6 +111,7 @@ class Context:
         self.h = C.c_void_p()
         self.n = num_images
         self.width, self.height = width, height
+        self.frame_w, self.frame_h = width, height   # raw size once a front end is set
         st = self.lib.pano_create(C.byref(cfg), C.byref(self.h))
         if st != 0:
             self.h = None
@@ -136,6 +142,20 @@ class Context:
 
     def save_camera_file(self, path):
         self._ck(self.lib.pano_save_camera_file(self.h, os.fsencode(path)))
+
+    def set_undistort(self, cam, raw_wh, undist_wh, K, dist, rect):
+        u = Undistort()
+        u.raw_w, u.raw_h = raw_wh; u.undist_w, u.undist_h = undist_wh
+        for i in range(9):
+            u.K[i] = float(K[i])
+        for i in range(4):
+            u.dist[i] = float(dist[i]); u.rect[i] = int(rect[i])
+        self._ck(self.lib.pano_set_undistort(self.h, cam, C.byref(u)))
+        self.frame_w, self.frame_h = raw_wh
+
+    def new_camera_matrix(self, cam):
+        out = (C.c_double * 9)()
+        self._ck(self.lib.pano_get_new_camera_matrix(self.h, cam, out)); return list(out)
 
     def prepare(self):
         self._ck(self.lib.pano_prepare(self.h))
@@ -185,7 +205,7 @@ class Context:
         frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
         assert len(frames) == self.n
         for f in frames:
-            if f.shape != (self.height, self.width, 3):
+            if f.shape != (self.frame_h, self.frame_w, 3):
                 raise PanoError(-2, "frame shape")
         w, h = self.output_size()
         out = np.empty((h, w, 3), np.uint8)
@@ -223,8 +243,9 @@ class Context:
     def stream_input(self, slot, cam):
         p = C.c_void_p(); st = C.c_size_t()
         self._ck(self.lib.pano_stream_input(self.h, slot, cam, C.byref(p), C.byref(st)))
-        buf = (C.c_uint8 * (st.value * self.height)).from_address(p.value)
-        return np.frombuffer(buf, np.uint8).reshape(self.height, st.value)[:, :self.width * 3].reshape(self.height, self.width, 3)
+        buf = (C.c_uint8 * (st.value * self.frame_h)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(self.frame_h, st.value)[:, :self.frame_w * 3].reshape(
+            self.frame_h, self.frame_w, 3)
 
     def stream_output(self, slot):
         p = C.c_void_p(); st = C.c_size_t()

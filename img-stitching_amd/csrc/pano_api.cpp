@@ -62,6 +62,12 @@ struct pano_ctx {
     int wpitch[kMaxCams][kMaxLevels] = {};
     float* wgt[kMaxCams][kMaxLevels] = {};
     uint8_t* mask0[kMaxCams] = {};  // level-0 tile-sized mask with the CONSTANT border of feed()
+    // fused undistort front end
+    bool have_fe[kMaxCams] = {};
+    pano_undistort und[kMaxCams] = {};
+    double newK[kMaxCams][9] = {};
+    FrontEndDev* d_fe[kMaxCams] = {};
+    int frame_w = 0, frame_h = 0;   // size of the frames pano_compose takes (raw size with a front end)
     uint32_t* lut[kMaxCams] = {};   // static remap tables of K1 (frames <= 2048 x 2048)
     int lut_pitch[kMaxCams] = {};
     bool use_lut = true;
@@ -166,7 +172,7 @@ void free_device(pano_ctx* c) {
     drop_graphs(c);
     for (int i = 0; i < kMaxCams; i++) {
         dfree(c->colA[i]); dfree(c->rowB[i]); dfree(c->colA_roi[i]); dfree(c->rowB_roi[i]);
-        dfree(c->mask[i]); dfree(c->gain[i]); dfree(c->mask0[i]); dfree(c->lut[i]);
+        dfree(c->mask[i]); dfree(c->gain[i]); dfree(c->mask0[i]); dfree(c->lut[i]); dfree(c->d_fe[i]);
         dfree(c->gcol[i]); dfree(c->grow[i]); dfree(c->gcol_roi[i]); dfree(c->grow_roi[i]);
         dfree(c->gcolw[i]); dfree(c->groww[i]); dfree(c->gcolw_roi[i]); dfree(c->groww_roi[i]);
         dfree(c->stage_in[i]);
@@ -209,8 +215,11 @@ void free_device(pano_ctx* c) {
 WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t stride, bool roi_only) {
     WarpCam w{};
     w.src = src;
-    w.src_w = c->plan.src_w;
-    w.src_h = c->plan.src_h;
+    w.src_w = c->frame_w;
+    w.src_h = c->frame_h;
+    w.out_w = c->plan.src_w;
+    w.out_h = c->plan.src_h;
+    w.fe = c->d_fe[i];
     w.src_stride = (int)stride;
     std::memcpy(w.m, c->plan.proj[i].k_rinv, sizeof(w.m));
     if (roi_only) {
@@ -491,6 +500,26 @@ pano_status pano_load_camera_file(pano_ctx* c, const char* path) {
     return PANO_OK;
 }
 
+pano_status pano_set_undistort(pano_ctx* c, int cam, const pano_undistort* u) {
+    if (!c || !u || cam < 0 || cam >= c->cfg.num_images) return PANO_EINVAL;
+    if (c->prepared) return fail(c, PANO_ESTATE, "the front end is fixed after pano_prepare");
+    if (u->raw_w < 2 || u->raw_h < 2 || u->undist_w < 2 || u->undist_h < 2 || u->rect[2] < 1 || u->rect[3] < 1 ||
+        u->rect[0] < 0 || u->rect[1] < 0 || u->rect[0] + u->rect[2] > u->undist_w || u->rect[1] + u->rect[3] > u->undist_h ||
+        !(u->K[0] > 0) || !(u->K[4] > 0))
+        return fail(c, PANO_EINVAL, "undistort parameters");
+    if (u->raw_w > 2048 || u->raw_h > 2048) return fail(c, PANO_EINVAL, "front end needs raw frames <= 2048 x 2048");
+    c->und[cam] = *u;
+    optimalNewCameraMatrix(u->K, u->dist, u->undist_w, u->undist_h, c->newK[cam]);
+    c->have_fe[cam] = true;
+    return PANO_OK;
+}
+
+pano_status pano_get_new_camera_matrix(const pano_ctx* c, int cam, double newK[9]) {
+    if (!c || !newK || cam < 0 || cam >= c->cfg.num_images || !c->have_fe[cam]) return PANO_EINVAL;
+    std::memcpy(newK, c->newK[cam], 9 * sizeof(double));
+    return PANO_OK;
+}
+
 pano_status pano_save_camera_file(pano_ctx* c, const char* path) {
     if (!c || !path) return PANO_EINVAL;
     for (int i = 0; i < c->cfg.num_images; i++)
@@ -522,6 +551,20 @@ pano_status pano_prepare(pano_ctx* c) {
     P.n = n;
     P.src_w = c->cfg.width;
     P.src_h = c->cfg.height;
+    c->frame_w = P.src_w;
+    c->frame_h = P.src_h;
+    {
+        int nfe = 0;
+        for (int i = 0; i < n; i++) nfe += c->have_fe[i] ? 1 : 0;
+        if (nfe != 0 && nfe != n) return fail(c, PANO_ESTATE, "set the undistort front end for every camera or for none");
+        if (nfe) {
+            for (int i = 1; i < n; i++)
+                if (c->und[i].raw_w != c->und[0].raw_w || c->und[i].raw_h != c->und[0].raw_h)
+                    return fail(c, PANO_EINVAL, "all cameras must share one raw frame size");
+            c->frame_w = c->und[0].raw_w;
+            c->frame_h = c->und[0].raw_h;
+        }
+    }
     for (int i = 0; i < n; i++) {
         if (!c->have_cam[i]) return fail(c, PANO_ESTATE, "camera parameters missing");
         P.proj[i].set(c->cfg.projector, c->scale, c->K[i], c->R[i]);
@@ -590,19 +633,32 @@ pano_status pano_prepare(pano_ctx* c) {
         HIP_TRY(c, hipMalloc((void**)&c->wsum[l], (size_t)cw * ch * sizeof(float)));
         if (l > 0) HIP_TRY(c, hipMalloc((void**)&c->canvas[l], (size_t)c->cv.cplane[l] * 3 * sizeof(int16_t) + 256));
     }
+    for (int i = 0; i < n; i++)
+        if (c->have_fe[i]) {
+            FrontEndDev fe{};
+            const pano_undistort& u = c->und[i];
+            fe.raw_w = u.raw_w; fe.raw_h = u.raw_h; fe.undist_w = u.undist_w; fe.undist_h = u.undist_h;
+            fe.out_w = P.src_w; fe.out_h = P.src_h;
+            std::memcpy(fe.rect, u.rect, sizeof(fe.rect));
+            std::memcpy(fe.K, u.K, sizeof(fe.K));
+            std::memcpy(fe.newK, c->newK[i], sizeof(fe.newK));
+            std::memcpy(fe.dist, u.dist, sizeof(fe.dist));
+            pano_status us = upload(c, &c->d_fe[i], &fe, sizeof(fe));
+            if (us != PANO_OK) return us;
+        }
     // static remap tables of the warp (K1): the projection of every tile pixel is fixed from here on.
     // PANO_WARP_ON_THE_FLY=1 keeps the projecting kernel (also what frames beyond 2048 x 2048 use).
     // hipGraph replay of the frame is opt-in (PANO_GRAPH=1): measured on MI355X the 12 stream-ordered launches
     // of a frame run 3 % faster than the replayed graph (0.268 vs 0.276 ms per 8-camera panorama) - the GPU,
     // not the host, is the limiter
     c->use_graph = getenv("PANO_GRAPH") && atoi(getenv("PANO_GRAPH"));
-    c->use_lut = P.src_w <= 2048 && P.src_h <= 2048 && !(getenv("PANO_WARP_ON_THE_FLY") && atoi(getenv("PANO_WARP_ON_THE_FLY")));
+    c->use_lut = c->frame_w <= 2048 && c->frame_h <= 2048 && !(getenv("PANO_WARP_ON_THE_FLY") && atoi(getenv("PANO_WARP_ON_THE_FLY")));
     if (c->use_lut) {
         for (int i = 0; i < n; i++) {
             const FeedTile& t = P.tile[i];
             c->lut_pitch[i] = (int)align_up((size_t)t.rect.w, 8);
             HIP_TRY(c, hipMalloc((void**)&c->lut[i], (size_t)c->lut_pitch[i] * t.rect.h * sizeof(uint32_t)));
-            WarpCam w = make_warp_cam(c, i, nullptr, (size_t)P.src_w * 3, false);
+            WarpCam w = make_warp_cam(c, i, nullptr, (size_t)c->frame_w * 3, false);
             launch_build_warp_lut(w, c->lut[i], c->lut_pitch[i], nullptr);
         }
         HIP_TRY(c, hipDeviceSynchronize());
@@ -769,6 +825,7 @@ pano_status pano_build_masks_voronoi(pano_ctx* c) {
         to_free.push_back(smask[i]);
         WarpCam w{};
         w.src_w = ssw; w.src_h = ssh;
+        w.out_w = ssw; w.out_h = ssh;
         std::memcpy(w.m, pj.k_rinv, sizeof(w.m));
         w.colA = dA; w.rowB = dB; w.tw = sroi[i].w; w.th = sroi[i].h;
         launch_warp_mask(w, smask[i], sroi[i].w, s);
@@ -875,7 +932,7 @@ pano_status pano_warp(pano_ctx* c, int i, const uint8_t* d_src, size_t src_strid
     pano_status s = check_compute(c);
     if (s != PANO_OK) return s;
     if (!d_src || !d_dst || i < 0 || i >= c->plan.n) return PANO_EINVAL;
-    if (src_stride < (size_t)c->plan.src_w * 3 || dst_stride < (size_t)c->plan.roi[i].w * 3) return PANO_EINVAL;
+    if (src_stride < (size_t)c->frame_w * 3 || dst_stride < (size_t)c->plan.roi[i].w * 3) return PANO_EINVAL;
     WarpCam w = make_warp_cam(c, i, d_src, src_stride, true);
     w.dst = d_dst;
     w.dst_pitch = (int)dst_stride;
@@ -906,7 +963,7 @@ pano_status pano_feed_cameras(pano_ctx* c, unsigned cam_bits, const uint8_t* con
     int k = 0, mw = 0, mh = 0;
     for (int i = 0; i < P.n; i++) {
         if (!((cam_bits >> i) & 1u)) continue;
-        if (!d_frames[i] || strides[i] < (size_t)P.src_w * 3) return fail(c, PANO_EINVAL, "frame pointer / stride");
+        if (!d_frames[i] || strides[i] < (size_t)c->frame_w * 3) return fail(c, PANO_EINVAL, "frame pointer / stride");
         wp.cam[k++] = make_warp_cam(c, i, d_frames[i], strides[i], false);
         mw = std::max(mw, P.tile[i].rect.w);
         mh = std::max(mh, P.tile[i].rect.h);
@@ -1011,11 +1068,11 @@ pano_status pano_compose_host(pano_ctx* c, const uint8_t* const* h_frames, const
     if (st != PANO_OK) return st;
     if (!h_frames || !strides || !h_out) return PANO_EINVAL;
     const Plan& P = c->plan;
-    const size_t in_pitch = align_up((size_t)P.src_w * 3, 256), out_pitch = align_up((size_t)P.cut.w * 3, 256);
+    const size_t in_pitch = align_up((size_t)c->frame_w * 3, 256), out_pitch = align_up((size_t)P.cut.w * 3, 256);
     if (!c->stage_out || c->stage_in_pitch != in_pitch || c->stage_out_pitch != out_pitch) {
         for (int i = 0; i < P.n; i++) {
             dfree(c->stage_in[i]);
-            HIP_TRY(c, hipMalloc((void**)&c->stage_in[i], in_pitch * P.src_h + 64));
+            HIP_TRY(c, hipMalloc((void**)&c->stage_in[i], in_pitch * c->frame_h + 64));
         }
         dfree(c->stage_out);
         HIP_TRY(c, hipMalloc((void**)&c->stage_out, out_pitch * P.cut.h));
@@ -1026,8 +1083,8 @@ pano_status pano_compose_host(pano_ctx* c, const uint8_t* const* h_frames, const
     const uint8_t* frames[kMaxCams];
     size_t pitches[kMaxCams];
     for (int i = 0; i < P.n; i++) {
-        if (!h_frames[i] || strides[i] < (size_t)P.src_w * 3) return PANO_EINVAL;
-        HIP_TRY(c, hipMemcpy2DAsync(c->stage_in[i], in_pitch, h_frames[i], strides[i], (size_t)P.src_w * 3, P.src_h,
+        if (!h_frames[i] || strides[i] < (size_t)c->frame_w * 3) return PANO_EINVAL;
+        HIP_TRY(c, hipMemcpy2DAsync(c->stage_in[i], in_pitch, h_frames[i], strides[i], (size_t)c->frame_w * 3, c->frame_h,
                                     hipMemcpyHostToDevice, s));
         frames[i] = c->stage_in[i];
         pitches[i] = in_pitch;
@@ -1075,12 +1132,12 @@ namespace {
 pano_status ensure_slots(pano_ctx* c) {
     if (c->slots_ready) return PANO_OK;
     const Plan& P = c->plan;
-    c->slot_in_pitch = align_up((size_t)P.src_w * 3, 256);
+    c->slot_in_pitch = align_up((size_t)c->frame_w * 3, 256);
     c->slot_out_pitch = align_up((size_t)P.pano.w * 3, 256);  // room for any later cut
     for (auto& sl : c->slots) {
         for (int i = 0; i < P.n; i++) {
-            HIP_TRY(c, hipHostMalloc((void**)&sl.h_in[i], c->slot_in_pitch * P.src_h, hipHostMallocDefault));
-            HIP_TRY(c, hipMalloc((void**)&sl.d_in[i], c->slot_in_pitch * P.src_h + 64));
+            HIP_TRY(c, hipHostMalloc((void**)&sl.h_in[i], c->slot_in_pitch * c->frame_h, hipHostMallocDefault));
+            HIP_TRY(c, hipMalloc((void**)&sl.d_in[i], c->slot_in_pitch * c->frame_h + 64));
         }
         HIP_TRY(c, hipHostMalloc((void**)&sl.h_out, c->slot_out_pitch * P.pano.h, hipHostMallocDefault));
         HIP_TRY(c, hipMalloc((void**)&sl.d_out, c->slot_out_pitch * P.pano.h));
@@ -1126,7 +1183,7 @@ pano_status pano_stream_submit(pano_ctx* c, int slot) {
     const uint8_t* frames[kMaxCams];
     size_t pitches[kMaxCams];
     for (int i = 0; i < P.n; i++) {
-        HIP_TRY(c, hipMemcpyAsync(sl.d_in[i], sl.h_in[i], c->slot_in_pitch * P.src_h, hipMemcpyHostToDevice, sl.h2d));
+        HIP_TRY(c, hipMemcpyAsync(sl.d_in[i], sl.h_in[i], c->slot_in_pitch * c->frame_h, hipMemcpyHostToDevice, sl.h2d));
         frames[i] = sl.d_in[i];
         pitches[i] = c->slot_in_pitch;
     }
@@ -1199,7 +1256,7 @@ pano_status pano_get_warp_bytes(const pano_ctx* c, uint64_t* src_bytes, uint64_t
     if (!c || !c->prepared || !src_bytes || !dst_bytes) return PANO_EINVAL;
     uint64_t s = 0, d = 0;
     for (int i = 0; i < c->plan.n; i++) {
-        s += (uint64_t)c->plan.src_w * c->plan.src_h * 3;
+        s += (uint64_t)c->frame_w * c->frame_h * 3;
         d += (uint64_t)c->plan.tile[i].rect.w * c->plan.tile[i].rect.h * 3;  // planar u8 tile, written once
     }
     *src_bytes = s;

@@ -73,6 +73,32 @@ __device__ __forceinline__ void map_backward(const float* __restrict__ m, float2
     }
 }
 
+// stitcher-frame coordinates -> raw-frame coordinates through the inverse of the reference's undistort chain
+// (nvcam.hpp:898-921, :1094): resize(undist->out), resize(crop->undist), crop, initUndistortRectifyMap's formula
+// with R = I at the fractional position, resize(raw->undist).  double, same expression order as the oracle.
+__device__ __forceinline__ void front_end_map(const FrontEndDev& fe, float xo, float yo, float& xr, float& yr) {
+    double x = ((double)xo + 0.5) * ((double)fe.undist_w / fe.out_w) - 0.5;
+    double y = ((double)yo + 0.5) * ((double)fe.undist_h / fe.out_h) - 0.5;
+    x = (x + 0.5) * ((double)fe.rect[2] / fe.undist_w) - 0.5 + fe.rect[0];
+    y = (y + 0.5) * ((double)fe.rect[3] / fe.undist_h) - 0.5 + fe.rect[1];
+    const double nx = (x - fe.newK[2]) / fe.newK[0], ny = (y - fe.newK[5]) / fe.newK[4];
+    const double x2 = nx * nx, y2 = ny * ny, r2 = x2 + y2, _2xy = 2 * nx * ny;
+    const double kr = 1 + ((0 * r2 + fe.dist[1]) * r2 + fe.dist[0]) * r2;
+    const double xd = nx * kr + fe.dist[2] * _2xy + fe.dist[3] * (r2 + 2 * x2);
+    const double yd = ny * kr + fe.dist[2] * (r2 + 2 * y2) + fe.dist[3] * _2xy;
+    double u = fe.K[0] * xd + fe.K[2], v = fe.K[4] * yd + fe.K[5];
+    u = (u + 0.5) * ((double)fe.raw_w / fe.undist_w) - 0.5;
+    v = (v + 0.5) * ((double)fe.raw_h / fe.undist_h) - 0.5;
+    xr = (float)u;
+    yr = (float)v;
+}
+// mapBackward (+ front end)
+__device__ __forceinline__ void map_source(const WarpCam& c, const float* __restrict__ m, float2 A, float2 B, float& x,
+                                           float& y) {
+    map_backward(m, A, B, x, y);
+    if (c.fe) front_end_map(*c.fe, x, y, x, y);
+}
+
 // remapBilinear<FixedPtCast<int,uchar,15>>: sum(p*w)+16384 >> 15 with w = (32-a|a)(32-b|b)*32
 // == ((32-b)*(p00*(32-a)+p01*a) + b*(p10*(32-a)+p11*a) + 512) >> 10, exact in integers.
 template <int ABL = 0>
@@ -229,7 +255,7 @@ __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
     // mapBackward, in OpenCV's evaluation order: (m0*x_ + m1*y_) + m2*z_ ; the m1*y_ products are per row
     const float y_ = B.y, t1x = m[1] * y_, t1y = m[4] * y_, t1z = m[7] * y_;
     float X[4], Y[4], Z[4];
-    bool fast = true;
+    bool fast = c.fe == nullptr;  // the straight-line path projects into the stitcher frame only
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const float x_ = B.x * A[j].x, z_ = B.x * A[j].y;
@@ -289,7 +315,7 @@ __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float fx, fy;
-            map_backward(m, A[j], B, fx, fy);
+            map_source(c, m, A[j], B, fx, fy);
             sample_bilinear_reflect<0>(c.src, sw, sh, stride, fx, fy, v[j]);
         }
     }
@@ -333,7 +359,7 @@ __global__ __launch_bounds__(256) void build_warp_lut_kernel(WarpCam c, uint32_t
     uint32_t code = 0xffffffffu;
     if (x < c.tw) {
         float fx, fy;
-        map_backward(c.m, c.colA[x], c.rowB[y], fx, fy);
+        map_source(c, c.m, c.colA[x], c.rowB[y], fx, fy);
         const int isx = cv_round_dev(fx * 32.f), isy = cv_round_dev(fy * 32.f);
         const int ix = sat16i(isx >> 5), iy = sat16i(isy >> 5);
         int xs, a1, ys, b1;
@@ -371,6 +397,7 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         const int y = min(ybase + 4 * r, c.th - 1);
+        // plain (cached) loads and stores: non-temporal ones for the streamed table and tile measured 15 % slower
         mm[r] = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0);
     }
     const int sh1 = c.src_h - 1, stride = c.src_stride;
@@ -408,7 +435,7 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
             for (int j = 0; j < NPX; j++)
                 if (code[j] == 0xffffffffu) {
                     float fx, fy;
-                    map_backward(c.m, c.colA[min(x0 + j, c.tw - 1)], c.rowB[y], fx, fy);
+                    map_source(c, c.m, c.colA[min(x0 + j, c.tw - 1)], c.rowB[y], fx, fy);
                     sample_bilinear_reflect<0>(c.src, c.src_w, c.src_h, stride, fx, fy, v[j]);
                 }
         }
@@ -491,7 +518,7 @@ __global__ __launch_bounds__(256) void warp_image_kernel(WarpCam c) {
     if (x >= c.tw || y >= c.th) return;
     float fx, fy;
     int v[3];
-    map_backward(c.m, c.colA[x], c.rowB[y], fx, fy);
+    map_source(c, c.m, c.colA[x], c.rowB[y], fx, fy);
     sample_bilinear_reflect(c.src, c.src_w, c.src_h, c.src_stride, fx, fy, v);
     if (c.gain) apply_gain(c, x, y, v);
     uint8_t* d = (uint8_t*)c.dst + (size_t)y * c.dst_pitch + 3 * x;
@@ -513,7 +540,7 @@ __global__ __launch_bounds__(256) void warp_mask_kernel(WarpCam c, uint8_t* dst,
     float fx, fy;
     map_backward(c.m, c.colA[x], c.rowB[y], fx, fy);
     int sx = sat16i(cv_round_dev(fx)), sy = sat16i(cv_round_dev(fy));
-    dst[(size_t)y * dst_stride + x] = ((unsigned)sx < (unsigned)c.src_w && (unsigned)sy < (unsigned)c.src_h) ? 255 : 0;
+    dst[(size_t)y * dst_stride + x] = ((unsigned)sx < (unsigned)c.out_w && (unsigned)sy < (unsigned)c.out_h) ? 255 : 0;
 }
 void launch_warp_mask(const WarpCam& c, uint8_t* dst, int dst_stride, hipStream_t s) {
     dim3 block(64, 4, 1), grid((c.tw + 63) / 64, (c.th + 3) / 4, 1);

@@ -10,6 +10,13 @@ namespace pano {
 constexpr int kCams = 8;
 constexpr int kLevels = 9;
 
+// fused undistort front end of one camera (device copy; see include/pano.h pano_undistort)
+struct FrontEndDev {
+    int raw_w, raw_h, undist_w, undist_h, out_w, out_h;
+    int rect[4];
+    double K[9], newK[9], dist[4];
+};
+
 // one camera's slice of the fused warp launch (K1)
 struct WarpCam {
     const uint8_t* src;   // BGR8 interleaved frame
@@ -26,6 +33,8 @@ struct WarpCam {
     // static remap table (frames up to 2048 x 2048): one dword per tile pixel, see build_warp_lut_kernel
     const uint32_t* lut;  // nullptr -> project on the fly
     int lut_pitch;        // dwords per row (multiple of 4)
+    const FrontEndDev* fe; // nullptr, or the undistort front end: src is then the RAW frame (src_w x src_h raw)
+    int out_w, out_h;     // the stitcher's frame size (mask warp inside test); == src_w x src_h without a front end
     const float* gain;    // [gh][gw] block gains or nullptr
     const int2* gcol;     // [tw] {sx, sx1}   (REFLECT folded like colA)
     const float2* gcolw;  // [tw] {1-fx, fx}

@@ -210,6 +210,48 @@ inline bool makePlan(Plan& P, int requested_bands) {
     return true;
 }
 
+// cvUndistortPoints without R / P: 5 fixed-point iterations (imgproc/src/undistort.cpp)
+inline void undistortPoint(const double K[9], const double d[4], double u, double v, double& ox, double& oy) {
+    const double fx = K[0], fy = K[4], ifx = 1. / fx, ify = 1. / fy, cx = K[2], cy = K[5];
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        double r2 = x * x + y * y;
+        double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((0 * r2 + d[1]) * r2 + d[0]) * r2);
+        if (icdist < 0) {
+            x = (u - cx) * ifx;
+            y = (v - cy) * ify;
+            break;
+        }
+        double deltaX = 2 * d[2] * x * y + d[3] * (r2 + 2 * x * x);
+        double deltaY = d[2] * (r2 + 2 * y * y) + 2 * d[3] * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    ox = x;
+    oy = y;
+}
+
+// cv::getOptimalNewCameraMatrix(K, dist, size, alpha = 1, size): 9x9 grid of f32 points -> outer rectangle -> the
+// projection that maps it onto the viewport (calib3d/src/calibration.cpp; reference nvcam.hpp:830)
+inline void optimalNewCameraMatrix(const double K[9], const double dist[4], int w, int h, double newK[9]) {
+    const int N = 9;
+    float oX0 = std::numeric_limits<float>::max(), oX1 = -oX0, oY0 = oX0, oY1 = -oX0;
+    for (int y = 0; y < N; y++)
+        for (int x = 0; x < N; x++) {
+            float px = (float)x * w / (N - 1), py = (float)y * h / (N - 1);
+            double ux, uy;
+            undistortPoint(K, dist, (double)px, (double)py, ux, uy);
+            float fx_ = (float)ux, fy_ = (float)uy;
+            oX0 = (std::min)(oX0, fx_); oX1 = (std::max)(oX1, fx_);
+            oY0 = (std::min)(oY0, fy_); oY1 = (std::max)(oY1, fy_);
+        }
+    const float ow = oX1 - oX0, oh = oY1 - oY0;
+    const double fx1 = (w - 1) / ow, fy1 = (h - 1) / oh;  // int / float: an f32 quotient, as in OpenCV
+    for (int i = 0; i < 9; i++) newK[i] = 0;
+    newK[0] = fx1; newK[4] = fy1; newK[2] = -fx1 * oX0; newK[5] = -fy1 * oY0; newK[8] = 1;
+}
+
 // Separable factors of Spherical/CylindricalProjector::mapBackward on the integer (u, v) grid:
 //   spherical:   x_ = sinf(pi - v/s) * sinf(u/s),  y_ = cosf(pi - v/s),  z_ = sinf(pi - v/s) * cosf(u/s)
 //   cylindrical: x_ = sinf(u/s),                   y_ = v/s,             z_ = cosf(u/s)

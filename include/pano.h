@@ -111,6 +111,25 @@ pano_status pano_set_mask(pano_ctx* ctx, int i, const uint8_t* h_mask, int w, in
 pano_status pano_build_masks_voronoi(pano_ctx* ctx);
 pano_status pano_get_mask(pano_ctx* ctx, int i, uint8_t* h_mask, size_t stride);
 
+/* ---- fused undistort front end (reference include/nvcam.hpp:823-833, :898-921, :1094) ----------------------
+ * The reference undistorts each captured frame on the CPU before the stitcher sees it: resize(raw -> undist size),
+ * remap(INTER_CUBIC) with initUndistortRectifyMap / getOptimalNewCameraMatrix(alpha=1) maps, crop `rect`,
+ * resize(-> undist size), resize(-> outPut size).  With a front end set, pano_compose takes the RAW captured frames
+ * (raw_w x raw_h) and the warp kernel samples them through the composed coordinate map of those five steps and the
+ * projection - one bilinear tap set per panorama pixel, no intermediate images.  (A different resampling from the
+ * reference's cubic + three bilinear passes: parity for this entry is defined against the fused map, DESIGN.md.)
+ * Call before pano_prepare, for every camera or for none; all cameras share raw_w x raw_h <= 2048 x 2048. */
+typedef struct pano_undistort {
+    int raw_w, raw_h;        /* stCamCfg.camSrcWidth/Height: the frames handed to pano_compose */
+    int undist_w, undist_h;  /* stCamCfg.undistoredWidth/Height */
+    double K[9];             /* cameras.yaml `K` of the lens at undist size, row-major */
+    double dist[4];          /* cameras.yaml `distorParams`: k1 k2 p1 p2 */
+    int rect[4];             /* cameras.yaml `rect`: crop x y w h */
+} pano_undistort;
+pano_status pano_set_undistort(pano_ctx* ctx, int cam, const pano_undistort* u);
+/* cv::getOptimalNewCameraMatrix(K, dist, undist size, 1) as the front end uses it (nvcam.hpp:830) */
+pano_status pano_get_new_camera_matrix(const pano_ctx* ctx, int cam, double newK[9]);
+
 /* ---- exposure: BlocksGainCompensator::apply (src/stitching_detailed.cpp:841) ---------------- */
 /* block gain map of camera i (f32, gw x gh), bilinearly resized to the ROI like apply() does;
  * NULL removes it */

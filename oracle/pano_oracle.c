@@ -989,6 +989,68 @@ void po_prepare_masks_voronoi(int n, int kind, int sw, int sh, const float* Ks, 
     free(ones); free(mw); free(corners); free(sizes);
 }
 
+/* ======================================================================== fused undistort front end */
+
+/* cvUndistortPoints without R / P (imgproc/src/undistort.cpp cvUndistortPointsInternal): 5 fixed-point iterations */
+static void undistort_point(const double K[9], const double d[4], double u, double v, double* ox, double* oy) {
+    double fx = K[0], fy = K[4], ifx = 1. / fx, ify = 1. / fy, cx = K[2], cy = K[5];
+    double x = (u - cx) * ifx, y = (v - cy) * ify, x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        double r2 = x * x + y * y;
+        double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((0 * r2 + d[1]) * r2 + d[0]) * r2);
+        if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+        double deltaX = 2 * d[2] * x * y + d[3] * (r2 + 2 * x * x);
+        double deltaY = d[2] * (r2 + 2 * y * y) + 2 * d[3] * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    *ox = x; *oy = y;
+}
+
+/* cvGetOptimalNewCameraMatrix, alpha = 1, newImgSize = imgSize, centerPrincipalPoint = 0: icvGetRectangles on a 9x9
+ * grid of float points, then the projection that maps the OUTER rectangle to the viewport */
+void po_optimal_new_camera_matrix(const double K[9], const double dist[4], int w, int h, double newK[9]) {
+    const int N = 9;
+    float oX0 = 3.402823466e+38F, oX1 = -3.402823466e+38F, oY0 = 3.402823466e+38F, oY1 = -3.402823466e+38F;
+    for (int y = 0; y < N; y++)
+        for (int x = 0; x < N; x++) {
+            float px = (float)x * w / (N - 1), py = (float)y * h / (N - 1);
+            double ux, uy;
+            undistort_point(K, dist, (double)px, (double)py, &ux, &uy);
+            float fx_ = (float)ux, fy_ = (float)uy;
+            if (fx_ < oX0) oX0 = fx_;
+            if (fx_ > oX1) oX1 = fx_;
+            if (fy_ < oY0) oY0 = fy_;
+            if (fy_ > oY1) oY1 = fy_;
+        }
+    float ow = oX1 - oX0, oh = oY1 - oY0;
+    double fx1 = (w - 1) / ow, fy1 = (h - 1) / oh;
+    double cx1 = -fx1 * oX0, cy1 = -fy1 * oY0;
+    for (int i = 0; i < 9; i++) newK[i] = 0;
+    /* alpha = 1: M = fx0*(1-alpha) + fx1*alpha with (1-alpha) == 0 */
+    newK[0] = fx1; newK[4] = fy1; newK[2] = cx1; newK[5] = cy1; newK[8] = 1;
+}
+
+/* inverse of: resize(undist->out), resize(crop->undist), crop, remap(undistort maps), resize(raw->undist).
+ * cv::resize maps dst centre (d+0.5)*scale-0.5; the undistort map is initUndistortRectifyMap's formula with R = I
+ * (imgproc/src/undistort.cpp), evaluated at the fractional position.  double throughout, one final cast. */
+void po_front_end_map(const po_front_end* fe, const double newK[9], float xo, float yo, float* xr, float* yr) {
+    double x = ((double)xo + 0.5) * ((double)fe->undist_w / fe->out_w) - 0.5;
+    double y = ((double)yo + 0.5) * ((double)fe->undist_h / fe->out_h) - 0.5;
+    x = (x + 0.5) * ((double)fe->rect[2] / fe->undist_w) - 0.5 + fe->rect[0];
+    y = (y + 0.5) * ((double)fe->rect[3] / fe->undist_h) - 0.5 + fe->rect[1];
+    double nx = (x - newK[2]) / newK[0], ny = (y - newK[5]) / newK[4];
+    double x2 = nx * nx, y2 = ny * ny, r2 = x2 + y2, _2xy = 2 * nx * ny;
+    double kr = 1 + ((0 * r2 + fe->dist[1]) * r2 + fe->dist[0]) * r2;
+    double xd = nx * kr + fe->dist[2] * _2xy + fe->dist[3] * (r2 + 2 * x2);
+    double yd = ny * kr + fe->dist[2] * (r2 + 2 * y2) + fe->dist[3] * _2xy;
+    double u = fe->K[0] * xd + fe->K[2], v = fe->K[4] * yd + fe->K[5];
+    u = (u + 0.5) * ((double)fe->raw_w / fe->undist_w) - 0.5;
+    v = (v + 0.5) * ((double)fe->raw_h / fe->undist_h) - 0.5;
+    *xr = (float)u;
+    *yr = (float)v;
+}
+
 /* ======================================================================== whole frame */
 
 static __thread double g_ms[3];
@@ -1015,6 +1077,21 @@ int po_compose(const po_compose_args* a, uint8_t* out, int out_wh[2]) {
         int w = sizes[2 * i], h = sizes[2 * i + 1], c[2];
         double t0 = now_ms();
         uint8_t* warped = (uint8_t*)malloc((size_t)w * h * 3);
+        if (a->front) {
+            /* fused front end: the spherical map of the stitcher frame, pushed through the five inverse steps,
+             * then cv::remap's fixed-point bilinear on the RAW frame */
+            const po_front_end* fe = &a->front[i];
+            double newK[9];
+            po_optimal_new_camera_matrix(fe->K, fe->dist, fe->undist_w, fe->undist_h, newK);
+            float* xm = (float*)malloc(sizeof(float) * (size_t)w * h);
+            float* ym = (float*)malloc(sizeof(float) * (size_t)w * h);
+            po_build_maps(&P[i], a->src_w, a->src_h, xm, ym);
+            for (size_t k = 0; k < (size_t)w * h; k++) po_front_end_map(fe, newK, xm[k], ym[k], &xm[k], &ym[k]);
+            po_remap_8u(a->frames[i], fe->raw_w, fe->raw_h, (size_t)fe->raw_w * 3, 3, xm, ym, w, h, PO_INTER_LINEAR,
+                        PO_BORDER_REFLECT, warped, (size_t)w * 3);
+            free(xm); free(ym);
+            c[0] = corners[2 * i]; c[1] = corners[2 * i + 1];
+        } else
         po_warp_8u(&P[i], a->frames[i], a->src_w, a->src_h, (size_t)a->src_w * 3, 3, PO_INTER_LINEAR, PO_BORDER_REFLECT,
                    warped, c);
         if (a->gain_maps && a->gain_maps[i]) po_gain_apply_8uc3(warped, w, h, a->gain_maps[i]);

@@ -106,6 +106,26 @@ void po_gain_apply_8uc3(uint8_t* img, int w, int h, const float* gain_map /* w*h
 void po_prepare_masks_voronoi(int n, int kind, int src_w, int src_h, const float* K9s, const float* R9s,
                               float warped_image_scale, uint8_t** masks_out);
 
+/* ---- fused undistort front end (reference include/nvcam.hpp:823-833, :898-921, :1094).
+ * The reference undistorts every captured frame on the CPU before the stitcher sees it:
+ *   resize(raw -> undist size) -> remap(INTER_CUBIC, maps of initUndistortRectifyMap with
+ *   getOptimalNewCameraMatrix(alpha=1)) -> crop rect -> resize(-> undist size) -> resize(-> outPut size)
+ * The fused form composes the COORDINATE maps of those five steps behind the spherical map and samples the raw frame
+ * once (fixed-point bilinear, like the warp).  It is a different resampling from the reference chain (one bilinear
+ * tap set instead of cubic + three bilinear passes), so its parity is defined against this restatement only. */
+typedef struct po_front_end {
+    int raw_w, raw_h;       /* captured frame */
+    int undist_w, undist_h; /* undistoredWidth / Height */
+    double K[9];            /* lens matrix at undist size (cameras.yaml K) */
+    double dist[4];         /* k1 k2 p1 p2 */
+    int rect[4];            /* crop x y w h */
+    int out_w, out_h;       /* outPutWidth / Height = the stitcher's frame size */
+} po_front_end;
+/* cv::getOptimalNewCameraMatrix(K, dist, size, alpha = 1, size) (calib3d/src/calibration.cpp) */
+void po_optimal_new_camera_matrix(const double K[9], const double dist[4], int w, int h, double newK[9]);
+/* stitcher-frame coordinates -> raw-frame coordinates through the five inverse steps */
+void po_front_end_map(const po_front_end* fe, const double newK[9], float xo, float yo, float* xr, float* yr);
+
 /* ---- whole per-frame path, ocvStitcher::process (ocvstitcher.hpp:1141-1216) */
 typedef struct po_compose_args {
     int n;              /* num_images */
@@ -119,6 +139,7 @@ typedef struct po_compose_args {
     int num_bands;      /* -1: Blender::NO */
     const float* const* gain_maps;  /* NULL, or n maps each warp_roi(i) sized (exposure apply) */
     int cut[4];         /* x,y,w,h inside dst_roi_final; w==0 -> full */
+    const po_front_end* front; /* NULL, or n front ends: frames are then RAW frames of raw_w x raw_h */
 } po_compose_args;
 /* out must hold cut.w*cut.h*3 bytes (or the full pano).  Returns 0 on success. */
 int po_compose(const po_compose_args* a, uint8_t* out, int out_wh[2]);

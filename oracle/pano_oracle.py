@@ -29,11 +29,32 @@ class Projector(C.Structure):
                 ("r_kinv", C.c_float * 9), ("k_rinv", C.c_float * 9)]
 
 
+class FrontEnd(C.Structure):
+    _fields_ = [("raw_w", C.c_int), ("raw_h", C.c_int), ("undist_w", C.c_int), ("undist_h", C.c_int),
+                ("K", C.c_double * 9), ("dist", C.c_double * 4), ("rect", C.c_int * 4), ("out_w", C.c_int), ("out_h", C.c_int)]
+
+
+def front_end(raw_wh, undist_wh, K, dist, rect, out_wh):
+    fe = FrontEnd()
+    fe.raw_w, fe.raw_h = raw_wh; fe.undist_w, fe.undist_h = undist_wh; fe.out_w, fe.out_h = out_wh
+    for i in range(9):
+        fe.K[i] = float(K[i])
+    for i in range(4):
+        fe.dist[i] = float(dist[i]); fe.rect[i] = int(rect[i])
+    return fe
+
+
+def optimal_new_camera_matrix(K, dist, w, h):
+    Kc = (C.c_double * 9)(*[float(v) for v in K]); dc = (C.c_double * 4)(*[float(v) for v in dist]); out = (C.c_double * 9)()
+    lib().po_optimal_new_camera_matrix(Kc, dc, int(w), int(h), out)
+    return list(out)
+
+
 class ComposeArgs(C.Structure):
     _fields_ = [("n", C.c_int), ("kind", C.c_int), ("src_w", C.c_int), ("src_h", C.c_int),
                 ("frames", C.POINTER(C.c_void_p)), ("K9s", C.POINTER(C.c_float)), ("R9s", C.POINTER(C.c_float)),
                 ("scale", C.c_float), ("masks", C.POINTER(C.c_void_p)), ("num_bands", C.c_int),
-                ("gain_maps", C.POINTER(C.c_void_p)), ("cut", C.c_int * 4)]
+                ("gain_maps", C.POINTER(C.c_void_p)), ("cut", C.c_int * 4), ("front", C.POINTER(FrontEnd))]
 
 
 _lib = None
@@ -287,12 +308,15 @@ class Blender:
         return tuple(r), tuple(t)
 
 
-def compose(frames, Ks, Rs, scale, masks, num_bands, kind=SPHERICAL, gain_maps=None, cut=None):
-    """ocvStitcher::process.  Returns (pano u8 HxWx3, (warp_ms, feed_ms, blend_ms))."""
+def compose(frames, Ks, Rs, scale, masks, num_bands, kind=SPHERICAL, gain_maps=None, cut=None, front=None):
+    """ocvStitcher::process.  Returns (pano u8 HxWx3, (warp_ms, feed_ms, blend_ms)).
+    front: list of FrontEnd (fused undistort): frames are then raw captured frames."""
     n = len(frames)
     frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
     masks = [np.ascontiguousarray(m, dtype=np.uint8) for m in masks]
     h, w = frames[0].shape[:2]
+    if front is not None:
+        w, h = front[0].out_w, front[0].out_h
     Ks = np.ascontiguousarray(np.asarray(Ks, dtype=np.float32).reshape(n, 9))
     Rs = np.ascontiguousarray(np.asarray(Rs, dtype=np.float32).reshape(n, 9))
     a = ComposeArgs()
@@ -306,6 +330,9 @@ def compose(frames, Ks, Rs, scale, masks, num_bands, kind=SPHERICAL, gain_maps=N
         gain_maps = [np.ascontiguousarray(g, dtype=np.float32) for g in gain_maps]
         ga = (C.c_void_p * n)(*[g.ctypes.data for g in gain_maps])
         a.gain_maps = C.cast(ga, C.POINTER(C.c_void_p))
+    if front is not None:
+        fa = (FrontEnd * n)(*front)
+        a.front = C.cast(fa, C.POINTER(FrontEnd))
     rois = [warp_roi(projector(kind, scale, Ks[i], Rs[i]), w, h) for i in range(n)]
     full = result_roi([r[:2] for r in rois], [r[2:] for r in rois])
     if cut is None:

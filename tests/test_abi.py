@@ -145,3 +145,17 @@ def test_full_ring_is_rejected(pano):
     with pytest.raises(pano.PanoError) as e:
         ctx.prepare()
     assert e.value.status == -6
+
+
+def test_new_camera_matrix_matches_oracle(pano, po, rig_r):
+    """getOptimalNewCameraMatrix(alpha=1) of the undistort front end (nvcam.hpp:830): host planner == oracle"""
+    K = [4.890925118101495e+02, 0, 4.940763211103715e+02, 0, 4.912630345468579e+02, 2.865820139005963e+02, 0, 0, 1]
+    dist = [-0.2838, 0.0628, 0, 0]
+    ctx = pano.Context(2, 960, 540, device=-1)
+    ctx.set_undistort(0, (1920, 1080), (960, 540), K, dist, (70, 66, 885, 410))
+    assert ctx.new_camera_matrix(0) == po.optimal_new_camera_matrix(K, dist, 960, 540)
+    with pytest.raises(pano.PanoError):
+        ctx.set_undistort(1, (4096, 2160), (960, 540), K, dist, (70, 66, 885, 410))   # raw frame too large for the table
+    ctx.set_cameras_from_list(",".join(repr(v) for v in rig_r["stitchers"][0]["cams"]))
+    with pytest.raises(pano.PanoError):
+        ctx.prepare()                                                                  # front end on one camera only

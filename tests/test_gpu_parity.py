@@ -1,6 +1,8 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C-ABI against the CPU
 oracle on the same inputs.  Everything on this path is integer / fixed-point or exactly-ordered f32,
 so the bar is BIT-EXACT (tolerance 0), stage by stage and end to end."""
+import os
+
 import numpy as np
 import pytest
 
@@ -441,3 +443,33 @@ def test_streaming_slots(pano, po, c1):
         for s in range(2):
             ctx.stream_wait(s)
             assert np.array_equal(ctx.stream_output(s), wants[s])
+
+
+def test_fused_undistort_front_end(pano, po, rig_r):
+    """raw 1920x1080 frames -> (undistort 960x540, crop, resize, resize) -> spherical warp, as ONE composed map
+    sampled once; lens = cameras.yaml sensing/imx390/fov120/960, rig R stitcher 0.  Parity is against the oracle
+    of the fused map (this is a different resampling from the reference's five-pass chain)."""
+    K = [4.890925118101495e+02, 0, 4.940763211103715e+02, 0, 4.912630345468579e+02, 2.865820139005963e+02, 0, 0, 1]
+    dist = [-0.2838, 0.0628, 0, 0]
+    rect = (70, 66, 885, 410)
+    st = rig_r["stitchers"][0]
+    v = st["cams"]
+    d = {"n": 2, "w": 960, "h": 540, "scale": v[-1], "K": [v[0:9], v[18:27]], "R": [v[9:18], v[27:36]]}
+    raw = [synth_frame(1920, 1080, 21 + i) for i in range(2)]
+    for flag in ("0", "1"):          # remap-table and projecting K1 variants
+        os.environ["PANO_WARP_ON_THE_FLY"] = flag
+        try:
+            ctx = pano.Context(2, 960, 540, scale=d["scale"], num_bands=3, cut=st["cut"], device=0)
+            for i in range(2):
+                ctx.set_camera(i, d["K"][i], d["R"][i])
+                ctx.set_undistort(i, (1920, 1080), (960, 540), K, dist, rect)
+            ctx.prepare()
+        finally:
+            os.environ.pop("PANO_WARP_ON_THE_FLY", None)
+        ctx.build_masks_voronoi()
+        masks = [ctx.get_mask(i) for i in range(2)]
+        assert all(np.array_equal(a, b) for a, b in zip(masks, oracle_masks(po, d)))   # masks: stitcher frame geometry
+        fe = [po.front_end((1920, 1080), (960, 540), K, dist, rect, (960, 540)) for _ in range(2)]
+        want, _ = po.compose(raw, d["K"], d["R"], d["scale"], masks, 3, cut=st["cut"], front=fe)
+        got = ctx.compose_host(raw)
+        assert got.shape == (250, 1430, 3) and np.array_equal(got, want)
