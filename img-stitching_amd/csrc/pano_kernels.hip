@@ -1225,44 +1225,63 @@ __global__ __launch_bounds__(256) void norm_small_kernel(PyrParams P, CanvasPara
     }
 }
 
-constexpr int kSmallTileW = 64, kSmallTileH = 16;
+constexpr int kSmallTileW = 32, kSmallTileH = 8;
 // footprint of a level-`small_base` tile at the coarser levels: R_{l+1} = [R_l.lo/2 - 1, R_l.hi/2 + 1] clamped
 struct SmallRegion {
     int x0, y0, w, h;
 };
-constexpr int kSmallLdsElems = 2048;  // int16 per plane for all coarser regions of a tile (< 800 needed); 12 KB total
+constexpr int kSmallLdsElems = 512;  // int16 per plane for all coarser regions of a tile (< 400 needed); 3 KB total
 
+// One workgroup = a 32 x 8 tile of level small_base; its footprint at every coarser level fits the same 32 x 8
+// thread grid (18 x 6, 11 x 5, 8 x 5, ...), so each lane owns at most ONE pixel per level: short serial code per
+// lane, 4 workgroups per CU.
 __global__ __launch_bounds__(256) void collapse_small_kernel(CanvasParams C) {
     __shared__ int16_t lds[3 * kSmallLdsElems];
-    __shared__ int reg[kLevels][5];  // x0, y0, w, h, lds offset of every level's region
     const int k0 = C.small_base, nb = C.bands;
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    if (tx == 0 && ty == 0) {
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int tx = tid & 31, ty = tid >> 5;
+    // footprints of this workgroup's tile at every level of the chain (block-uniform: scalar registers)
+    int rx0[kLevels], ry0[kLevels], rw[kLevels], rh[kLevels], ro[kLevels];
+    {
         const int cw = C.w0 >> k0, ch = C.h0 >> k0;
         int x0 = blockIdx.x * kSmallTileW, y0 = blockIdx.y * kSmallTileH;
         int x1 = min(x0 + kSmallTileW, cw) - 1, y1 = min(y0 + kSmallTileH, ch) - 1;
         int o = 0;
-        for (int l = k0; l <= nb; l++) {
-            reg[l][0] = x0; reg[l][1] = y0; reg[l][2] = x1 - x0 + 1; reg[l][3] = y1 - y0 + 1;
-            reg[l][4] = o;
-            if (l > k0) o += reg[l][2] * reg[l][3];  // level k0 goes straight to global memory
+#pragma unroll
+        for (int j = 0; j < kLevels; j++) {
+            const int l = k0 + j;
+            rx0[j] = x0; ry0[j] = y0; rw[j] = x1 - x0 + 1; rh[j] = y1 - y0 + 1;
+            ro[j] = o;
+            if (j > 0) o += rw[j] * rh[j];  // level k0 goes straight to global memory
             const int nw = C.w0 >> (l + 1), nh = C.h0 >> (l + 1);
             x0 = max((x0 >> 1) - 1, 0); y0 = max((y0 >> 1) - 1, 0);
-            x1 = min((x1 >> 1) + 1, nw - 1); y1 = min((y1 >> 1) + 1, nh - 1);
+            x1 = min((x1 >> 1) + 1, max(nw - 1, 0)); y1 = min((y1 >> 1) + 1, max(nh - 1, 0));
         }
     }
-    __syncthreads();
-    for (int l = nb; l >= k0; l--) {
+    // phase 1: every norm_l value this lane will need, all loads in flight together
+    int16_t nv[kLevels][3];
+#pragma unroll
+    for (int j = 0; j < kLevels; j++) {
+        const int l = k0 + j;
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            int16_t v = 0;
+            if (l <= nb && tx < rw[j] && ty < rh[j])
+                v = C.img[l][(size_t)pl * C.cplane[l] + (size_t)(ry0[j] + ty) * C.cpitch[l] + rx0[j] + tx];
+            nv[j][pl] = v;
+        }
+    }
+    // phase 2: collapse coarse -> fine through LDS
+#pragma unroll
+    for (int j = kLevels - 1; j >= 0; j--) {
+        const int l = k0 + j;
+        if (l > nb) continue;  // block-uniform
         const int cw = C.w0 >> l, ch = C.h0 >> l;
-        const int rx0 = reg[l][0], ry0 = reg[l][1], rw = reg[l][2], rh = reg[l][3], ro = reg[l][4];
         const int nx = cw >> 1, ny = ch >> 1;
-        int cx0 = 0, cy0 = 0, cwid = 0, co = 0;
-        if (l < nb) { cx0 = reg[l + 1][0]; cy0 = reg[l + 1][1]; cwid = reg[l + 1][2]; co = reg[l + 1][4]; }
-        // regions are at most 64 wide: lane = column, the 4 waves stride the rows
-        if (tx < rw) {
-            const int X = rx0 + tx;
-            const int x = X >> 1;
-            int xi[3], wx[3];
+        if (tx < rw[j] && ty < rh[j]) {
+            const int X = rx0[j] + tx, Y = ry0[j] + ty;
+            const int x = X >> 1, y = Y >> 1;
+            int xi[3], wx[3], yi[3], wy[3];
             if (!(X & 1)) {
                 xi[0] = x > 0 ? x - 1 : (nx > 1 ? 1 : 0); xi[1] = x; xi[2] = min(x + 1, nx - 1);
                 wx[0] = 1; wx[1] = 6; wx[2] = 1;
@@ -1270,34 +1289,30 @@ __global__ __launch_bounds__(256) void collapse_small_kernel(CanvasParams C) {
                 xi[0] = x; xi[1] = min(x + 1, nx - 1); xi[2] = x;
                 wx[0] = 4; wx[1] = 4; wx[2] = 0;
             }
-            for (int yy = ty; yy < rh; yy += 4) {
-                const int Y = ry0 + yy;
-                const int y = Y >> 1;
-                int yi[3], wy[3];
-                if (!(Y & 1)) {
-                    yi[0] = y > 0 ? y - 1 : (ny > 1 ? 1 : 0); yi[1] = y; yi[2] = min(y + 1, ny - 1);
-                    wy[0] = 1; wy[1] = 6; wy[2] = 1;
-                } else {
-                    yi[0] = y; yi[1] = min(y + 1, ny - 1); yi[2] = y;
-                    wy[0] = 4; wy[1] = 4; wy[2] = 0;
-                }
+            if (!(Y & 1)) {
+                yi[0] = y > 0 ? y - 1 : (ny > 1 ? 1 : 0); yi[1] = y; yi[2] = min(y + 1, ny - 1);
+                wy[0] = 1; wy[1] = 6; wy[2] = 1;
+            } else {
+                yi[0] = y; yi[1] = min(y + 1, ny - 1); yi[2] = y;
+                wy[0] = 4; wy[1] = 4; wy[2] = 0;
+            }
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) {
-                    int v = C.img[l][(size_t)pl * C.cplane[l] + (size_t)Y * C.cpitch[l] + X];  // norm_l
-                    if (l < nb) {
-                        // pyrUp of out_{l+1} from its LDS region (every index it needs lies inside that region)
-                        const int16_t* S = lds + pl * kSmallLdsElems + co;
-                        int acc = 0;
+            for (int pl = 0; pl < 3; pl++) {
+                int v = nv[j][pl];
+                if (l < nb && j + 1 < kLevels) {
+                    // pyrUp of out_{l+1} from its LDS region (every index it needs lies inside that region)
+                    const int jc = j + 1 < kLevels ? j + 1 : j;
+                    const int16_t* S = lds + pl * kSmallLdsElems + ro[jc];
+                    int acc = 0;
 #pragma unroll
-                        for (int j = 0; j < 3; j++) {
-                            const int16_t* row = S + (yi[j] - cy0) * cwid - cx0;
-                            acc += ((int)row[xi[0]] * wx[0] + (int)row[xi[1]] * wx[1] + (int)row[xi[2]] * wx[2]) * wy[j];
-                        }
-                        v = sat16i(v + sat16i((acc + 32) >> 6));
+                    for (int t = 0; t < 3; t++) {
+                        const int16_t* row = S + (yi[t] - ry0[jc]) * rw[jc] - rx0[jc];
+                        acc += ((int)row[xi[0]] * wx[0] + (int)row[xi[1]] * wx[1] + (int)row[xi[2]] * wx[2]) * wy[t];
                     }
-                    if (l > k0) lds[pl * kSmallLdsElems + ro + yy * rw + tx] = (int16_t)v;
-                    else C.img[l][(size_t)pl * C.cplane[l] + (size_t)Y * C.cpitch[l] + X] = (int16_t)v;
+                    v = sat16i(v + sat16i((acc + 32) >> 6));
                 }
+                if (j > 0) lds[pl * kSmallLdsElems + ro[j] + ty * rw[j] + tx] = (int16_t)v;
+                else C.img[l][(size_t)pl * C.cplane[l] + (size_t)Y * C.cpitch[l] + X] = (int16_t)v;
             }
         }
         __syncthreads();
