@@ -85,7 +85,7 @@ EXPORTS = [
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
     "pano_build_masks_voronoi", "pano_get_mask", "pano_set_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
-    "pano_compose_host", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_stream_input", "pano_stream_output",
+    "pano_compose_host", "pano_compose_pair", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_stream_input", "pano_stream_output",
     "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
     "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_debug_get_level", "pano_debug_get_weights",
     "pano_debug_get_canvas_weights", "pano_debug_get_canvas",
@@ -219,6 +219,14 @@ class Context:
         ptrs = (C.c_void_p * self.n)(*[int(p) for p in d_frames])
         st = (C.c_size_t * self.n)(*[int(s) for s in strides])
         self._ck(self.lib.pano_compose(self.h, ptrs, st, _vp(d_out), C.c_size_t(out_stride), _vp(stream)))
+
+    def compose_pair(self, other, d_frames_a, strides_a, d_out_a, out_stride_a, d_frames_b, strides_b, d_out_b, out_stride_b,
+                     stream=0):
+        """both stitchers (upper / lower group) in one launch sequence"""
+        pa = (C.c_void_p * self.n)(*[int(p) for p in d_frames_a]); sa = (C.c_size_t * self.n)(*[int(s) for s in strides_a])
+        pb = (C.c_void_p * other.n)(*[int(p) for p in d_frames_b]); sb = (C.c_size_t * other.n)(*[int(s) for s in strides_b])
+        self._ck(self.lib.pano_compose_pair(self.h, other.h, pa, sa, _vp(d_out_a), C.c_size_t(out_stride_a), pb, sb,
+                                            _vp(d_out_b), C.c_size_t(out_stride_b), _vp(stream)))
 
     def feed_cameras(self, cam_bits, d_frames, strides, stream=0):
         ptrs = (C.c_void_p * self.n)(*[int(p) for p in d_frames])

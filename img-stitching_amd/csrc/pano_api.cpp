@@ -704,6 +704,8 @@ pano_status pano_prepare(pano_ctx* c) {
         while (k <= P.bands && c->cv.fast[k]) k++;
         if (k >= 1 && P.bands - k + 1 >= 2) c->cv.small_base = k;
     }
+    c->cv.cam_lo = 0;
+    c->cv.cam_n = n;
     c->cv.w0 = P.canvas.w; c->cv.h0 = P.canvas.h;
     c->cv.bands = P.bands < 0 ? 0 : P.bands;
     c->cv.cut_x = P.cut.x; c->cv.cut_y = P.cut.y; c->cv.cut_w = P.cut.w; c->cv.cut_h = P.cut.h;
@@ -994,15 +996,18 @@ pano_status pano_blend(pano_ctx* c, uint8_t* d_out, size_t out_stride, void* str
     CanvasParams cv = c->cv;
     cv.out = d_out;
     cv.out_stride = (int)out_stride;
+    CanvasSet cs{};
+    cs.n = 1;
+    cs.c[0] = cv;
     if (P.bands < 0) {
-        launch_no_blend(c->pyr, cv, s);
+        launch_no_blend(c->pyr, cs, s);
     } else {
         int top = P.bands;
         if (cv.small_base > 0) {
-            launch_blend_small(c->pyr, cv, s);
+            launch_blend_small(c->pyr, cs, s);
             top = cv.small_base - 1;
         }
-        for (int l = top; l >= 0; l--) launch_blend_level(c->pyr, cv, l, s);
+        for (int l = top; l >= 0; l--) launch_blend_level(c->pyr, cs, l, s);
     }
     if (c->profiling) {
         if (c->ev_cur < 0 && (st = begin_slot(c)) != PANO_OK) return st;
@@ -1060,6 +1065,83 @@ pano_status pano_compose(pano_ctx* c, const uint8_t* const* d_frames, const size
     }
     if ((st = pano_feed_cameras(c, (1u << n) - 1u, d_frames, strides, stream)) != PANO_OK) return st;
     return pano_blend(c, d_out, out_stride, stream);
+}
+
+pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b, const uint8_t* const* fa, const size_t* sa, uint8_t* oa, size_t osa,
+                              const uint8_t* const* fb, const size_t* sb, uint8_t* ob, size_t osb, void* stream) {
+    pano_status st = check_compute(a);
+    if (st != PANO_OK) return st;
+    if ((st = check_compute(b)) != PANO_OK) return st;
+    if (!fa || !sa || !oa || !fb || !sb || !ob) return PANO_EINVAL;
+    const Plan &A = a->plan, &B = b->plan;
+    bool same = a->device == b->device && A.bands == B.bands && A.n + B.n <= kCams && a->cv.small_base == b->cv.small_base &&
+                (a->use_lut && b->use_lut) == (a->use_lut || b->use_lut);
+    for (int l = 0; l < a->levels && same; l++) same = a->cv.fast[l] == b->cv.fast[l];
+    if (!same) {  // different level structure: one after the other, same results
+        if ((st = pano_compose(a, fa, sa, oa, osa, stream)) != PANO_OK) return st;
+        return pano_compose(b, fb, sb, ob, osb, stream);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if ((st = ensure_weights(a, s)) != PANO_OK) return st;
+    if ((st = ensure_weights(b, s)) != PANO_OK) return st;
+    if (osa < (size_t)A.cut.w * 3 || osb < (size_t)B.cut.w * 3) return PANO_EINVAL;
+    // K1: every camera of both contexts in one launch
+    WarpParams wp{};
+    int mw = 0, mh = 0;
+    for (int i = 0; i < A.n; i++) {
+        if (!fa[i] || sa[i] < (size_t)a->frame_w * 3) return fail(a, PANO_EINVAL, "frame pointer / stride");
+        wp.cam[i] = make_warp_cam(a, i, fa[i], sa[i], false);
+        mw = std::max(mw, A.tile[i].rect.w);
+        mh = std::max(mh, A.tile[i].rect.h);
+    }
+    for (int i = 0; i < B.n; i++) {
+        if (!fb[i] || sb[i] < (size_t)b->frame_w * 3) return fail(b, PANO_EINVAL, "frame pointer / stride");
+        wp.cam[A.n + i] = make_warp_cam(b, i, fb[i], sb[i], false);
+        mw = std::max(mw, B.tile[i].rect.w);
+        mh = std::max(mh, B.tile[i].rect.h);
+    }
+    const bool prof = a->profiling;  // stage events of a pair go to the first context's ring
+    if (prof) {
+        if ((st = begin_slot(a)) != PANO_OK) return st;
+        pano_ctx::EvSlot& sl = a->ring[a->ev_cur];
+        launch_warp_tiles(wp, A.n + B.n, mw, mh, s, sl.e[0], sl.e[1]);
+        sl.recorded |= 3u;
+    } else {
+        launch_warp_tiles(wp, A.n + B.n, mw, mh, s);
+    }
+    // K2: merged camera list
+    PyrParams pp = a->pyr;
+    for (int i = 0; i < B.n; i++) pp.cam[A.n + i] = b->pyr.cam[i];
+    pp.ncam = A.n + B.n;
+    const unsigned all = (1u << pp.ncam) - 1u;
+    for (int l = 0; l < A.bands; l++) launch_pyr_down(pp, all, l, s);
+    if (prof && (st = record(a, 2, s)) != PANO_OK) return st;
+    // K3: both canvases per launch
+    CanvasSet cs{};
+    cs.n = 2;
+    cs.c[0] = a->cv;
+    cs.c[0].out = oa;
+    cs.c[0].out_stride = (int)osa;
+    cs.c[1] = b->cv;
+    cs.c[1].out = ob;
+    cs.c[1].out_stride = (int)osb;
+    cs.c[1].cam_lo = A.n;
+    if (A.bands < 0) {
+        launch_no_blend(pp, cs, s);
+    } else {
+        int top = A.bands;
+        if (cs.c[0].small_base > 0) {
+            launch_blend_small(pp, cs, s);
+            top = cs.c[0].small_base - 1;
+        }
+        for (int l = top; l >= 0; l--) launch_blend_level(pp, cs, l, s);
+    }
+    if (prof) {
+        if ((st = record(a, 3, s)) != PANO_OK) return st;
+        a->ev_cur = -1;
+    }
+    HIP_TRY(a, hipGetLastError());
+    return PANO_OK;
 }
 
 pano_status pano_compose_host(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides, uint8_t* h_out,

@@ -693,7 +693,9 @@ __device__ __forceinline__ float cam_weight(const PyrCam& c, int l, int x, int y
     return c.wgt[l][(size_t)y * c.wpitch[l] + x];
 }
 
-__global__ __launch_bounds__(256) void blend_level_kernel(PyrParams P, CanvasParams C, int l) {
+__global__ __launch_bounds__(256) void blend_level_kernel(PyrParams P, CanvasSet CS, int l) {
+    const CanvasParams& C = CS.c[blockIdx.z];
+    const int cam_lo = C.cam_lo, cam_n = C.cam_n;
     const int cw = C.w0 >> l, ch = C.h0 >> l;
     int X = blockIdx.x * 64 + threadIdx.x;
     int Y = blockIdx.y * 4 + threadIdx.y;
@@ -710,8 +712,8 @@ __global__ __launch_bounds__(256) void blend_level_kernel(PyrParams P, CanvasPar
 #pragma unroll
     for (int i = 0; i < kCams; i++) {
         wv[i] = 0.f;
-        if (i < P.ncam) {
-            const PyrCam& c = P.cam[i];
+        if (i < cam_n) {
+            const PyrCam& c = P.cam[cam_lo + i];
             const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
             if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l)) wv[i] = cam_weight(c, l, x, y);
         }
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(256) void blend_level_kernel(PyrParams P, CanvasPar
     for (int i = 0; i < kCams; i++) {
         const float w = wv[i];
         if (w == 0.f) continue;
-        const PyrCam& c = P.cam[i];
+        const PyrCam& c = P.cam[cam_lo + i];
         const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
         const int tw = c.w0 >> l, th = c.h0 >> l;
         W += w;
@@ -877,7 +879,9 @@ __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0
 }
 
 template <bool L0, int ABL = 0>
-__global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, CanvasParams C, int lvl) {
+__global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, CanvasSet CS, int lvl) {
+    const CanvasParams& C = CS.c[blockIdx.z];
+    const int cam_lo = C.cam_lo, cam_n = C.cam_n;
     const int l = L0 ? 0 : lvl;
     const int cw = C.w0 >> l, ch = C.h0 >> l;
     // level 0 covers only the block-aligned hull of the cut rectangle
@@ -917,7 +921,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
             }
         }
         if (ucode < 8u) {
-            const PyrCam& c = P.cam[ucode];
+            const PyrCam& c = P.cam[cam_lo + ucode];
             const int x = X0 - (c.tx >> l), y = Y0 - (c.ty >> l);
             const int tw = c.w0 >> l, th = c.h0 >> l;
             unsigned g0[3], g1[3];
@@ -993,8 +997,8 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
 #pragma unroll
     for (int i = 0; i < kCams; i++) {
         mk[i][0] = mk[i][1] = 0;
-        if (i < P.ncam) {
-            const PyrCam& c = P.cam[i];
+        if (i < cam_n) {
+            const PyrCam& c = P.cam[cam_lo + i];
             const int x = X0 - (c.tx >> l), y = Y0 - (c.ty >> l);
             if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l)) {  // blocks never straddle a tile edge
                 if (L0) {
@@ -1031,7 +1035,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
 #pragma unroll
     for (int i = 0; i < kCams; i++) {
         if (!((live >> i) & 1u)) continue;
-        const PyrCam& c = P.cam[i];
+        const PyrCam& c = P.cam[cam_lo + i];
         const int x = X0 - (c.tx >> l), y = Y0 - (c.ty >> l);
         const int tw = c.w0 >> l, th = c.h0 >> l;
         float w[2][4];
@@ -1182,8 +1186,11 @@ void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint8_
 //      through LDS, coarse to fine (the halo is recomputed per workgroup: a few hundred pixels).
 // Only out_{small_base} is needed by the next (vector) level; canvas levels above it keep norm_l.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void norm_small_kernel(PyrParams P, CanvasParams C) {
-    const int l = C.small_base + blockIdx.z;
+__global__ __launch_bounds__(256) void norm_small_kernel(PyrParams P, CanvasSet CS) {
+    const int nsmall = CS.c[0].bands - CS.c[0].small_base + 1;
+    const CanvasParams& C = CS.c[blockIdx.z / nsmall];
+    const int cam_lo = C.cam_lo, cam_n = C.cam_n;
+    const int l = C.small_base + blockIdx.z % nsmall;
     const int cw = C.w0 >> l, ch = C.h0 >> l;
     const int X = blockIdx.x * 64 + threadIdx.x, Y = blockIdx.y * 4 + threadIdx.y;
     if (X >= cw || Y >= ch) return;
@@ -1191,8 +1198,8 @@ __global__ __launch_bounds__(256) void norm_small_kernel(PyrParams P, CanvasPara
 #pragma unroll
     for (int i = 0; i < kCams; i++) {
         wv[i] = 0.f;
-        if (i < P.ncam) {
-            const PyrCam& c = P.cam[i];
+        if (i < cam_n) {
+            const PyrCam& c = P.cam[cam_lo + i];
             const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
             if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l)) wv[i] = cam_weight(c, l, x, y);
         }
@@ -1203,7 +1210,7 @@ __global__ __launch_bounds__(256) void norm_small_kernel(PyrParams P, CanvasPara
     for (int i = 0; i < kCams; i++) {
         const float w = wv[i];
         if (w == 0.f) continue;
-        const PyrCam& c = P.cam[i];
+        const PyrCam& c = P.cam[cam_lo + i];
         const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
         const int tw = c.w0 >> l, th = c.h0 >> l;
         W += w;
@@ -1235,7 +1242,8 @@ constexpr int kSmallLdsElems = 512;  // int16 per plane for all coarser regions 
 // One workgroup = a 32 x 8 tile of level small_base; its footprint at every coarser level fits the same 32 x 8
 // thread grid (18 x 6, 11 x 5, 8 x 5, ...), so each lane owns at most ONE pixel per level: short serial code per
 // lane, 4 workgroups per CU.
-__global__ __launch_bounds__(256) void collapse_small_kernel(CanvasParams C) {
+__global__ __launch_bounds__(256) void collapse_small_kernel(CanvasSet CS) {
+    const CanvasParams& C = CS.c[blockIdx.z];
     __shared__ int16_t lds[3 * kSmallLdsElems];
     const int k0 = C.small_base, nb = C.bands;
     const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -1319,56 +1327,71 @@ __global__ __launch_bounds__(256) void collapse_small_kernel(CanvasParams C) {
     }
 }
 
-void launch_blend_small(const PyrParams& p, const CanvasParams& c, hipStream_t s) {
+void launch_blend_small(const PyrParams& p, const CanvasSet& cs, hipStream_t s) {
+    const CanvasParams& c = cs.c[0];
     const int k0 = c.small_base;
-    const int cw = c.w0 >> k0, ch = c.h0 >> k0;
+    int cw = 0, ch = 0;
+    for (int g = 0; g < cs.n; g++) {
+        cw = max(cw, cs.c[g].w0 >> k0);
+        ch = max(ch, cs.c[g].h0 >> k0);
+    }
     dim3 block(64, 4, 1);
-    dim3 g1((cw + 63) / 64, (ch + 3) / 4, c.bands - k0 + 1);
-    hipLaunchKernelGGL(norm_small_kernel, g1, block, 0, s, p, c);
-    dim3 g2((cw + kSmallTileW - 1) / kSmallTileW, (ch + kSmallTileH - 1) / kSmallTileH, 1);
-    hipLaunchKernelGGL(collapse_small_kernel, g2, block, 0, s, c);
+    dim3 g1((cw + 63) / 64, (ch + 3) / 4, (c.bands - k0 + 1) * cs.n);
+    hipLaunchKernelGGL(norm_small_kernel, g1, block, 0, s, p, cs);
+    dim3 g2((cw + kSmallTileW - 1) / kSmallTileW, (ch + kSmallTileH - 1) / kSmallTileH, cs.n);
+    hipLaunchKernelGGL(collapse_small_kernel, g2, block, 0, s, cs);
 }
 
-void launch_blend_level(const PyrParams& p, const CanvasParams& c, int l, hipStream_t s) {
+void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStream_t s) {
+    const CanvasParams& c = cs.c[0];
     if (c.fast[l]) {
-        int w, h;
-        if (l == 0) {
-            w = c.cut_x + c.cut_w - (c.cut_x & ~3);
-            h = c.cut_y + c.cut_h - (c.cut_y & ~1);
-        } else {
-            w = c.w0 >> l;
-            h = c.h0 >> l;
+        int w = 0, h = 0;
+        for (int g = 0; g < cs.n; g++) {
+            const CanvasParams& cg = cs.c[g];
+            if (l == 0) {
+                w = max(w, cg.cut_x + cg.cut_w - (cg.cut_x & ~3));
+                h = max(h, cg.cut_y + cg.cut_h - (cg.cut_y & ~1));
+            } else {
+                w = max(w, cg.w0 >> l);
+                h = max(h, cg.h0 >> l);
+            }
         }
-        dim3 block(64, 4, 1), grid((w + 63) / 64, (h + 31) / 32, 1);
+        dim3 block(64, 4, 1), grid((w + 63) / 64, (h + 31) / 32, cs.n);
 #ifdef PANO_DIAG
         static const int kabl = getenv("PANO_K3_ABL") ? atoi(getenv("PANO_K3_ABL")) : 0;
-        if (l == 0 && kabl == 1) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 1>), grid, block, 0, s, p, c, l); return; }
-        if (l == 0 && kabl == 2) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 2>), grid, block, 0, s, p, c, l); return; }
-        if (l == 0 && kabl == 3) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 3>), grid, block, 0, s, p, c, l); return; }
-        if (l == 0 && kabl == 4) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 4>), grid, block, 0, s, p, c, l); return; }
-        if (l == 0 && kabl == 5) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 5>), grid, block, 0, s, p, c, l); return; }
+        if (l == 0 && kabl == 1) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 1>), grid, block, 0, s, p, cs, l); return; }
+        if (l == 0 && kabl == 2) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 2>), grid, block, 0, s, p, cs, l); return; }
+        if (l == 0 && kabl == 3) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 3>), grid, block, 0, s, p, cs, l); return; }
+        if (l == 0 && kabl == 4) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 4>), grid, block, 0, s, p, cs, l); return; }
+        if (l == 0 && kabl == 5) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 5>), grid, block, 0, s, p, cs, l); return; }
         if (l == 0 && kabl == 6) return;  // diagnostic: level 0 not launched at all
 #endif
-        if (l == 0) hipLaunchKernelGGL((blend_level_vec_kernel<true, 0>), grid, block, 0, s, p, c, l);
-        else hipLaunchKernelGGL((blend_level_vec_kernel<false, 0>), grid, block, 0, s, p, c, l);
+        if (l == 0) hipLaunchKernelGGL((blend_level_vec_kernel<true, 0>), grid, block, 0, s, p, cs, l);
+        else hipLaunchKernelGGL((blend_level_vec_kernel<false, 0>), grid, block, 0, s, p, cs, l);
         return;
     }
-    int w = l == 0 ? c.cut_w : (c.w0 >> l), h = l == 0 ? c.cut_h : (c.h0 >> l);
-    dim3 block(64, 4, 1), grid((w + 63) / 64, (h + 3) / 4, 1);
-    hipLaunchKernelGGL(blend_level_kernel, grid, block, 0, s, p, c, l);
+    int w = 0, h = 0;
+    for (int g = 0; g < cs.n; g++) {
+        w = max(w, l == 0 ? cs.c[g].cut_w : (cs.c[g].w0 >> l));
+        h = max(h, l == 0 ? cs.c[g].cut_h : (cs.c[g].h0 >> l));
+    }
+    dim3 block(64, 4, 1), grid((w + 63) / 64, (h + 3) / 4, cs.n);
+    hipLaunchKernelGGL(blend_level_kernel, grid, block, 0, s, p, cs, l);
 }
 
 // Blender::NO: Blender::feed masked copy in feed order, Blender::blend zeroing, convertTo(8U), cut.
 // The level-0 tile is the ROI itself (no border) and mask0 the blend mask.
-__global__ __launch_bounds__(256) void no_blend_kernel(PyrParams P, CanvasParams C) {
+__global__ __launch_bounds__(256) void no_blend_kernel(PyrParams P, CanvasSet CS) {
+    const CanvasParams& C = CS.c[blockIdx.z];
+    const int cam_lo = C.cam_lo, cam_n = C.cam_n;
     int X = blockIdx.x * 64 + threadIdx.x;
     int Y = blockIdx.y * 4 + threadIdx.y;
     if (X >= C.cut_w || Y >= C.cut_h) return;
     X += C.cut_x;
     Y += C.cut_y;
     int v[3] = {0, 0, 0};
-    for (int i = 0; i < P.ncam; i++) {
-        const PyrCam& c = P.cam[i];
+    for (int i = 0; i < cam_n; i++) {
+        const PyrCam& c = P.cam[cam_lo + i];
         const int x = X - c.tx, y = Y - c.ty;
         if ((unsigned)x >= (unsigned)c.w0 || (unsigned)y >= (unsigned)c.h0) continue;
         if (!c.mask0[(size_t)y * c.pitch[0] + x]) continue;
@@ -1380,9 +1403,14 @@ __global__ __launch_bounds__(256) void no_blend_kernel(PyrParams P, CanvasParams
     d[1] = (uint8_t)v[1];
     d[2] = (uint8_t)v[2];
 }
-void launch_no_blend(const PyrParams& p, const CanvasParams& c, hipStream_t s) {
-    dim3 block(64, 4, 1), grid((c.cut_w + 63) / 64, (c.cut_h + 3) / 4, 1);
-    hipLaunchKernelGGL(no_blend_kernel, grid, block, 0, s, p, c);
+void launch_no_blend(const PyrParams& p, const CanvasSet& cs, hipStream_t s) {
+    int w = 0, h = 0;
+    for (int g = 0; g < cs.n; g++) {
+        w = max(w, cs.c[g].cut_w);
+        h = max(h, cs.c[g].cut_h);
+    }
+    dim3 block(64, 4, 1), grid((w + 63) / 64, (h + 3) / 4, cs.n);
+    hipLaunchKernelGGL(no_blend_kernel, grid, block, 0, s, p, cs);
 }
 
 // ------------------------------------------------------------------------------------------------

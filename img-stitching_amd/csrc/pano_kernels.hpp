@@ -72,6 +72,7 @@ struct CanvasParams {
     const uint8_t* owner[kLevels];  // vector levels: per 4x2 block, the single unit-weight camera (0..7), 0xFE none, 0xFF mixed
     int opitch[kLevels];       // owner bytes per block row
     int small_base;            // >0: levels small_base..bands run as one normalise launch + one LDS collapse launch
+    int cam_lo, cam_n;         // this canvas blends cameras [cam_lo, cam_lo + cam_n) of the PyrParams it is launched with
     int w0, h0;                // padded canvas size
     int bands;
     // final output
@@ -79,6 +80,13 @@ struct CanvasParams {
     int out_stride;            // bytes
     int cut_x, cut_y, cut_w, cut_h;  // in padded-canvas coordinates (pano rect origin == canvas origin)
     int final_w, final_h;      // dst_roi_final size (unpadded)
+};
+
+// Up to two canvases (the reference's upper and lower stitcher) share every blend launch: grid.z picks the canvas.
+// Their level structure (bands, vector levels, small_base) must be identical; their geometry need not be.
+struct CanvasSet {
+    CanvasParams c[2];
+    int n;
 };
 
 // K1: fused REFLECT border + mapBackward + fixed-point bilinear remap + 8U->16S
@@ -96,13 +104,13 @@ void launch_warp_mask(const WarpCam& c, uint8_t* dst, int dst_stride, hipStream_
 void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s);
 // K3: one blend level for the whole canvas (Laplacian, weight, accumulate, normalise, collapse);
 // level 0 writes the cut 8U panorama
-void launch_blend_level(const PyrParams& p, const CanvasParams& c, int l, hipStream_t s);
+void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStream_t s);
 // the small levels small_base..bands in two launches
-void launch_blend_small(const PyrParams& p, const CanvasParams& c, hipStream_t s);
+void launch_blend_small(const PyrParams& p, const CanvasSet& cs, hipStream_t s);
 // owner map of a vector level (run when masks change)
 void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint8_t* owner, hipStream_t s);
 // Blender::NO path
-void launch_no_blend(const PyrParams& p, const CanvasParams& c, hipStream_t s);
+void launch_no_blend(const PyrParams& p, const CanvasSet& cs, hipStream_t s);
 
 // weights (run when masks change)
 void launch_mask_to_weight(const uint8_t* mask, int mw, int mh, int mpitch, int left, int top,

@@ -153,6 +153,15 @@ pano_status pano_compose(pano_ctx* ctx, const uint8_t* const* d_frames, const si
 pano_status pano_compose_host(pano_ctx* ctx, const uint8_t* const* h_frames, const size_t* strides,
                               uint8_t* h_out, size_t out_stride);
 
+/* The reference runs its two stitchers (upper / lower camera group) on two threads per frame
+ * (src/master.cpp:314-318).  pano_compose_pair composes both in ONE launch sequence: a single warp launch over
+ * all cameras of both contexts, one launch per pyramid / blend level for both canvases.  Results are identical to
+ * two pano_compose calls; contexts whose level structure differs are simply composed one after the other. */
+pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b,
+                              const uint8_t* const* d_frames_a, const size_t* strides_a, uint8_t* d_out_a, size_t out_stride_a,
+                              const uint8_t* const* d_frames_b, const size_t* strides_b, uint8_t* d_out_b, size_t out_stride_b,
+                              void* hip_stream);
+
 /* ---- streaming form for a capture loop (BASELINE config 5: frames arrive in host memory at camera rate) ------
  * The reference's loop (src/master.cpp:302-411) pops one cv::Mat per camera from the capture queues and calls
  * process().  Here the library owns PINNED host buffers in PANO_STREAM_SLOTS slots: the producer writes camera i's

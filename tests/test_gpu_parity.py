@@ -473,3 +473,44 @@ def test_fused_undistort_front_end(pano, po, rig_r):
         want, _ = po.compose(raw, d["K"], d["R"], d["scale"], masks, 3, cut=st["cut"], front=fe)
         got = ctx.compose_host(raw)
         assert got.shape == (250, 1430, 3) and np.array_equal(got, want)
+
+
+def test_compose_pair(pano, po, torch, c1, rig_r):
+    """pano_compose_pair (both stitchers per launch) == two pano_compose calls == oracle; also a pair whose level
+    structure differs (falls back to sequential composition)"""
+    s = torch.cuda.current_stream().cuda_stream
+    # rig R: stitcher 0 and 1 have different geometry (different ROIs, canvases 1456x528 vs 1488x512) but both 3 bands
+    ctxs, wants, frames_d, outs = [], [], [], []
+    for k in range(2):
+        st = rig_r["stitchers"][k]
+        v = st["cams"]
+        d = {"n": 2, "w": 960, "h": 540, "scale": v[-1], "K": [v[0:9], v[18:27]], "R": [v[9:18], v[27:36]]}
+        frames = [synth_frame(960, 540, 31 + 2 * k + i) for i in range(2)]
+        ctx = make_ctx(pano, d, 0, num_bands=pano.BANDS_FROM_STRENGTH, blend_strength=1.0, cut=st["cut"])
+        ctx.build_masks_voronoi()
+        masks = [ctx.get_mask(i) for i in range(2)]
+        wants.append(po.compose(frames, d["K"], d["R"], d["scale"], masks, 3, cut=st["cut"])[0])
+        ctxs.append(ctx)
+        frames_d.append([torch.from_numpy(f).cuda() for f in frames])
+        w, h = ctx.output_size()
+        outs.append(torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda"))
+    for rep in range(2):
+        for o in outs:
+            o.zero_()
+        ctxs[0].compose_pair(ctxs[1], [t.data_ptr() for t in frames_d[0]], [960 * 3] * 2, outs[0].data_ptr(), outs[0].shape[1] * 3,
+                             [t.data_ptr() for t in frames_d[1]], [960 * 3] * 2, outs[1].data_ptr(), outs[1].shape[1] * 3, s)
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert np.array_equal(outs[k].cpu().numpy(), wants[k]), k
+    # mismatched structure: 2 bands vs 4 bands on config 1
+    masks = oracle_masks(po, c1)
+    ca, cb = make_ctx(pano, c1, 0, num_bands=2), make_ctx(pano, c1, 0, num_bands=4)
+    for i in range(4):
+        ca.set_mask(i, masks[i]); cb.set_mask(i, masks[i])
+    fd = [torch.from_numpy(f).cuda() for f in c1["frames"]]
+    oa = torch.zeros((257, 1333, 3), dtype=torch.uint8, device="cuda"); ob = torch.zeros_like(oa)
+    ca.compose_pair(cb, [t.data_ptr() for t in fd], [480 * 3] * 4, oa.data_ptr(), 1333 * 3,
+                    [t.data_ptr() for t in fd], [480 * 3] * 4, ob.data_ptr(), 1333 * 3, s)
+    torch.cuda.synchronize()
+    assert np.array_equal(oa.cpu().numpy(), po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 2)[0])
+    assert np.array_equal(ob.cpu().numpy(), po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 4)[0])
