@@ -782,49 +782,70 @@ __device__ __forceinline__ void up_h4(const int p[4], int o[4]) {
 // the 4 x 3 coarse neighbourhood of a 4 x 2 fine block: rows y-1, y, y+1 (y = Y0/2), columns x-1 .. x+2, with
 // pyrUp's border rule (left/top reflect-101, right/bottom replicate) applied.  Branch-free, so that a caller's
 // loads can all be issued before the first is consumed: each row is ONE aligned fetch of a window that is
-// clamped into the row (8 bytes of u8 / 12 bytes of int16), and the four samples are picked by shifts.
+// clamped into the row (8 bytes of u8 / 12 bytes of int16); the border rule is a byte permutation (v_perm_b32)
+// of that window.  The four samples of a row stay PACKED: q[r][0] = 4 bytes (u8) or q[r][0..1] = 2 x 2 shorts.
+typedef short s2_t __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int m, int pitch, int x, int y,
-                                            int p[3][4]) {
+                                            unsigned q[3][2]) {
     const int yi[3] = {y > 0 ? y - 1 : (m > 1 ? 1 : 0), y, min(y + 1, m - 1)};
     const int xi[4] = {x > 0 ? x - 1 : (n > 1 ? 1 : 0), x, min(x + 1, n - 1), min(x + 2, n - 1)};
     const int base = min(max(x - 1, 0), max(n - 4, 0));
     // sample k is element xi[k] - base (0..3) of the 4-element window starting at `base`
-    const int sh[4] = {xi[0] - base, xi[1] - base, xi[2] - base, xi[3] - base};
+    const unsigned sh0 = xi[0] - base, sh1 = xi[1] - base, sh2 = xi[2] - base, sh3 = xi[3] - base;
     if (sizeof(T) == 1) {
         const int ab = base & ~3;  // 4-byte aligned fetch of 8 bytes; the window starts at byte base - ab (0..3)
+        const unsigned sel = sh0 | (sh1 << 8) | (sh2 << 16) | (sh3 << 24);
         uint2 d[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint2*>(S + (size_t)yi[r] * pitch + ab);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const unsigned win = __builtin_amdgcn_alignbyte(d[r].y, d[r].x, (unsigned)(base - ab));
-#pragma unroll
-            for (int k = 0; k < 4; k++) p[r][k] = (int)((win >> (8 * sh[k])) & 0xffu);
+            q[r][0] = __builtin_amdgcn_perm(0u, win, sel);
+            q[r][1] = 0;
         }
     } else {
         const int ab = base & ~1;  // even element index = 4-byte aligned fetch of 12 bytes; window at element base - ab (0..1)
+        const unsigned bs = (unsigned)(base - ab) * 2u;  // 0 or 2 bytes
+        // short k of the result = short sh[k] of the 4-short window {w1:w0}: byte selectors 2*sh, 2*sh+1
+        const unsigned selA = (2 * sh0) | ((2 * sh0 + 1) << 8) | ((2 * sh1) << 16) | ((2 * sh1 + 1) << 24);
+        const unsigned selB = (2 * sh2) | ((2 * sh2 + 1) << 8) | ((2 * sh3) << 16) | ((2 * sh3 + 1) << 24);
         uint3 d[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint3*>(S + (size_t)yi[r] * pitch + ab);
-        const unsigned bs = (unsigned)(base - ab) * 2u;  // 0 or 2 bytes
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const unsigned w0 = __builtin_amdgcn_alignbyte(d[r].y, d[r].x, bs);
             const unsigned w1 = __builtin_amdgcn_alignbyte(d[r].z, d[r].y, bs);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const unsigned w = sh[k] < 2 ? w0 : w1;
-                p[r][k] = (int)(int16_t)(w >> (16 * (sh[k] & 1)));
-            }
+            q[r][0] = __builtin_amdgcn_perm(w1, w0, selA);
+            q[r][1] = __builtin_amdgcn_perm(w1, w0, selB);
         }
     }
 }
-// pyrUp of a 4 x 2 block: up[0][..] = fine row Y0 (even), up[1][..] = fine row Y0+1 (odd)
-__device__ __forceinline__ void up_block(const int p[3][4], int up[2][4]) {
+// pyrUp of a 4 x 2 block from the packed 4 x 3 neighbourhood: up[0][..] = fine row Y0 (even), up[1][..] = row Y0+1.
+// Horizontal pass per coarse row: (p0 + 6 p1 + p2, 4 (p1 + p2), p1 + 6 p2 + p3, 4 (p2 + p3)) as dot products
+// (v_dot4_u32_u8 on the byte window / v_dot2_i32_i16 on the short pairs); vertical pass in 32-bit ints.
+template <typename T>
+__device__ __forceinline__ void up_block(const unsigned q[3][2], int up[2][4]) {
     int h[3][4];
 #pragma unroll
-    for (int r = 0; r < 3; r++) up_h4(p[r], h[r]);
+    for (int r = 0; r < 3; r++) {
+        if (sizeof(T) == 1) {
+            const unsigned w = q[r][0];
+            h[r][0] = (int)__builtin_amdgcn_udot4(w, 0x00010601u, 0u, false);
+            h[r][1] = (int)__builtin_amdgcn_udot4(w, 0x00040400u, 0u, false);
+            h[r][2] = (int)__builtin_amdgcn_udot4(w, 0x01060100u, 0u, false);
+            h[r][3] = (int)__builtin_amdgcn_udot4(w, 0x04040000u, 0u, false);
+        } else {
+            const s2_t A = __builtin_bit_cast(s2_t, q[r][0]), B = __builtin_bit_cast(s2_t, q[r][1]);
+            const s2_t c16 = {1, 6}, c04 = {0, 4}, c40 = {4, 0}, c01 = {0, 1}, c61 = {6, 1}, c44 = {4, 4};
+            h[r][0] = __builtin_amdgcn_sdot2(A, c16, (int)B.x, false);
+            h[r][1] = __builtin_amdgcn_sdot2(A, c04, __builtin_amdgcn_sdot2(B, c40, 0, false), false);
+            h[r][2] = __builtin_amdgcn_sdot2(A, c01, __builtin_amdgcn_sdot2(B, c61, 0, false), false);
+            h[r][3] = __builtin_amdgcn_sdot2(B, c44, 0, false);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         up[0][k] = sat16i((h[0][k] + 6 * h[1][k] + h[2][k] + 32) >> 6);
@@ -905,15 +926,13 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         // the whole wave (a 256 x 2 strip) has one owner: its parameters are scalar, the code is straight-line
         // and every load is in flight before the first use
         int v[3][2][4];
-        int cp[3][3][4];
+        unsigned cp[3][3][2];
         if (l < C.bands) {
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) {
                 if (ABL == 1) {  // diagnostic: no canvas loads
 #pragma unroll
-                    for (int r = 0; r < 3; r++)
-#pragma unroll
-                        for (int k = 0; k < 4; k++) cp[pl][r][k] = X0 + r + k;
+                    for (int r = 0; r < 3; r++) cp[pl][r][0] = cp[pl][r][1] = (unsigned)(X0 + r);
                 } else {
                     load_coarse<int16_t>(C.img[l + 1] + (size_t)pl * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1],
                                          X0 >> 1, Y0 >> 1, cp[pl]);
@@ -925,7 +944,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
             const int x = X0 - (c.tx >> l), y = Y0 - (c.ty >> l);
             const int tw = c.w0 >> l, th = c.h0 >> l;
             unsigned g0[3], g1[3];
-            int p[3][3][4];
+            unsigned p[3][3][2];
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) {
                 const uint8_t* g = c.lvl[l] + (size_t)pl * c.plane[l] + (size_t)y * c.pitch[l] + x;
@@ -938,9 +957,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
                 if (l < C.bands) {
                     if (ABL == 2) {  // diagnostic: no coarse tile loads
 #pragma unroll
-                        for (int r = 0; r < 3; r++)
-#pragma unroll
-                            for (int k = 0; k < 4; k++) p[pl][r][k] = (x + r + k) & 255;
+                        for (int r = 0; r < 3; r++) p[pl][r][0] = p[pl][r][1] = (unsigned)(x + r) & 0x7f7f7f7fu;
                     } else {
                         load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)pl * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1],
                                              x >> 1, y >> 1, p[pl]);
@@ -951,7 +968,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
             for (int pl = 0; pl < 3; pl++) {
                 int up[2][4];
                 if (l < C.bands) {
-                    up_block(p[pl], up);
+                    up_block<uint8_t>(p[pl], up);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; k++) up[0][k] = up[1][k] = 0;
@@ -976,7 +993,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) {
                 int up[2][4];
-                up_block(cp[pl], up);
+                up_block<int16_t>(cp[pl], up);
 #pragma unroll
                 for (int r = 0; r < 2; r++)
 #pragma unroll
@@ -1015,7 +1032,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         if (mk[i][0] | mk[i][1]) live |= 1u << i;
     }
     // the coarser canvas level: early on the latency-bound small levels, late (fewer live registers) on level 0
-    int cp[3][3][4];
+    unsigned cp[3][3][2];
     if (!L0 && l < C.bands) {
 #pragma unroll
         for (int pl = 0; pl < 3; pl++)
@@ -1059,7 +1076,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
             for (int k = 0; k < 4; k++) unit &= w[r][k] == 1.0f;
         // issue every load of this camera before using any
         unsigned g0[3], g1[3];
-        int p[3][3][4];
+        unsigned p[3][3][2];
 #pragma unroll
         for (int pl = 0; pl < 3; pl++) {
             const uint8_t* g = c.lvl[l] + (size_t)pl * c.plane[l] + (size_t)y * c.pitch[l] + x;
@@ -1077,7 +1094,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         for (int pl = 0; pl < 3; pl++) {
             int up[2][4];
             if (l < C.bands) {
-                up_block(p[pl], up);
+                up_block<uint8_t>(p[pl], up);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) up[0][k] = up[1][k] = 0;
@@ -1115,7 +1132,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     for (int pl = 0; pl < 3; pl++) {
         int up[2][4];
         if (l < C.bands) {
-            up_block(cp[pl], up);
+            up_block<int16_t>(cp[pl], up);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) up[0][k] = up[1][k] = 0;
