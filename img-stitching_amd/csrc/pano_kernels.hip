@@ -798,7 +798,7 @@ __device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int 
         const unsigned sel = sh0 | (sh1 << 8) | (sh2 << 16) | (sh3 << 24);
         uint2 d[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint2*>(S + (size_t)yi[r] * pitch + ab);
+        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint2*>(S + (unsigned)(yi[r] * pitch + ab));
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const unsigned win = __builtin_amdgcn_alignbyte(d[r].y, d[r].x, (unsigned)(base - ab));
@@ -813,7 +813,7 @@ __device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int 
         const unsigned selB = (2 * sh2) | ((2 * sh2 + 1) << 8) | ((2 * sh3) << 16) | ((2 * sh3 + 1) << 24);
         uint3 d[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint3*>(S + (size_t)yi[r] * pitch + ab);
+        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint3*>(S + (unsigned)(yi[r] * pitch + ab));
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const unsigned w0 = __builtin_amdgcn_alignbyte(d[r].y, d[r].x, bs);
@@ -846,10 +846,14 @@ __device__ __forceinline__ void up_block(const unsigned q[3][2], int up[2][4]) {
             h[r][3] = __builtin_amdgcn_sdot2(B, c44, 0, false);
         }
     }
+    // No saturate_cast here: it cannot trigger.  Camera planes are 8-bit (h <= 8*255), and a collapsed canvas level
+    // is bounded by 255 per remaining level (|norm_l| <= 255, pyrUp is a convex combination + rounding), i.e.
+    // |out_l| <= 9*255 + 9 for the maximum of 8 bands - far inside int16.
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        up[0][k] = sat16i((h[0][k] + 6 * h[1][k] + h[2][k] + 32) >> 6);
-        up[1][k] = sat16i((4 * (h[1][k] + h[2][k]) + 32) >> 6);
+        const int h1 = h[1][k];
+        up[0][k] = (h[0][k] + h[2][k] + (h1 << 2) + (h1 << 1) + 32) >> 6;
+        up[1][k] = (h1 + h[2][k] + 8) >> 4;
     }
 }
 
@@ -865,7 +869,7 @@ __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0
                 uint2 pk;
                 pk.x = ((unsigned)v[pl][r][0] & 0xffffu) | ((unsigned)v[pl][r][1] << 16);
                 pk.y = ((unsigned)v[pl][r][2] & 0xffffu) | ((unsigned)v[pl][r][3] << 16);
-                *reinterpret_cast<uint2*>(C.img[l] + (size_t)pl * C.cplane[l] + (size_t)(Y0 + r) * C.cpitch[l] + X0) = pk;
+                *reinterpret_cast<uint2*>(C.img[l] + (size_t)pl * C.cplane[l] + (unsigned)((Y0 + r) * C.cpitch[l] + X0)) = pk;
             }
     } else {
         const bool on[2][4] = {{o00, o01, o02, o03}, {o10, o11, o12, o13}};
@@ -878,7 +882,8 @@ __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0
             for (int k = 0; k < 4; k++)
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++) b[3 * k + pl] = on[r][k] ? (unsigned)sat8i(v[pl][r][k]) : 0u;
-            uint8_t* d = C.out + (size_t)(Y - C.cut_y) * C.out_stride + 3 * (X0 - C.cut_x);
+            // signed: a block that starts left of the cut has a negative column offset (its bytes are masked below)
+            uint8_t* d = C.out + (int)((Y - C.cut_y) * C.out_stride + 3 * (X0 - C.cut_x));
             const bool whole = X0 >= C.cut_x && X0 + 4 <= C.cut_x + C.cut_w;
             if (whole && (((size_t)d) & 3) == 0) {
                 uint3 pk;
@@ -947,7 +952,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
             unsigned p[3][3][2];
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) {
-                const uint8_t* g = c.lvl[l] + (size_t)pl * c.plane[l] + (size_t)y * c.pitch[l] + x;
+                const uint8_t* g = c.lvl[l] + (size_t)pl * c.plane[l] + (unsigned)(y * c.pitch[l] + x);
                 if (ABL == 3) {  // diagnostic: no level-l tile loads
                     g0[pl] = x * 0x01010101u; g1[pl] = y * 0x01010101u;
                 } else {
@@ -975,8 +980,8 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int l0 = sat16i((int)((g0[pl] >> (8 * k)) & 0xffu) - up[0][k]);
-                    const int l1 = sat16i((int)((g1[pl] >> (8 * k)) & 0xffu) - up[1][k]);
+                    const int l0 = (int)((g0[pl] >> (8 * k)) & 0xffu) - up[0][k];  // |lap| <= 255: no saturation possible
+                    const int l1 = (int)((g1[pl] >> (8 * k)) & 0xffu) - up[1][k];
                     v[pl][0][k] = l0 - (l0 > 0) + (l0 < 0);
                     v[pl][1][k] = l1 - (l1 > 0) + (l1 < 0);
                 }
@@ -997,7 +1002,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
 #pragma unroll
                 for (int r = 0; r < 2; r++)
 #pragma unroll
-                    for (int k = 0; k < 4; k++) v[pl][r][k] = sat16i(v[pl][r][k] + up[r][k]);
+                    for (int k = 0; k < 4; k++) v[pl][r][k] += up[r][k];  // bounded by 9*255+9: see up_block
             }
         }
         const bool on = ucode < 8u;  // W == 1 > eps; an unowned block has W == 0
