@@ -82,7 +82,7 @@ struct pano_ctx {
     uint8_t* stage_in[kMaxCams] = {};
     size_t stage_in_pitch = 0;
     uint8_t* stage_out = nullptr;
-    size_t stage_out_pitch = 0;
+    size_t stage_out_pitch = 0, stage_out_bytes = 0;
     hipStream_t own_stream = nullptr;
     // streaming slots (pano_stream_*): pinned host buffers, per-slot device buffers, copy streams and events
     struct StreamSlot {
@@ -1151,16 +1151,21 @@ pano_status pano_compose_host(pano_ctx* c, const uint8_t* const* h_frames, const
     if (!h_frames || !strides || !h_out) return PANO_EINVAL;
     const Plan& P = c->plan;
     const size_t in_pitch = align_up((size_t)c->frame_w * 3, 256), out_pitch = align_up((size_t)P.cut.w * 3, 256);
-    if (!c->stage_out || c->stage_in_pitch != in_pitch || c->stage_out_pitch != out_pitch) {
+    if (!c->stage_in[0] || c->stage_in_pitch != in_pitch) {
         for (int i = 0; i < P.n; i++) {
             dfree(c->stage_in[i]);
             HIP_TRY(c, hipMalloc((void**)&c->stage_in[i], in_pitch * c->frame_h + 64));
         }
-        dfree(c->stage_out);
-        HIP_TRY(c, hipMalloc((void**)&c->stage_out, out_pitch * P.cut.h));
         c->stage_in_pitch = in_pitch;
-        c->stage_out_pitch = out_pitch;
     }
+    // the output staging buffer follows the cut (pano_set_cut may grow it in either dimension)
+    if (!c->stage_out || out_pitch * (size_t)P.cut.h > c->stage_out_bytes) {
+        HIP_TRY(c, hipDeviceSynchronize());
+        dfree(c->stage_out);
+        c->stage_out_bytes = out_pitch * (size_t)P.cut.h;
+        HIP_TRY(c, hipMalloc((void**)&c->stage_out, c->stage_out_bytes));
+    }
+    c->stage_out_pitch = out_pitch;
     hipStream_t s = c->own_stream;
     const uint8_t* frames[kMaxCams];
     size_t pitches[kMaxCams];

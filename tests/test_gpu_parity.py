@@ -514,3 +514,21 @@ def test_compose_pair(pano, po, torch, c1, rig_r):
     torch.cuda.synchronize()
     assert np.array_equal(oa.cpu().numpy(), po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 2)[0])
     assert np.array_equal(ob.cpu().numpy(), po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 4)[0])
+
+
+def test_cut_alignment_on_vector_path(pano, po, rig_r):
+    """cuts whose origin / size are not multiples of the 4 x 2 blocks of the vector blend kernel (canvas >= 600 kpx)"""
+    st = rig_r["stitchers"][0]
+    v = st["cams"]
+    d = {"n": 2, "w": 960, "h": 540, "scale": v[-1], "K": [v[0:9], v[18:27]], "R": [v[9:18], v[27:36]]}
+    frames = [synth_frame(960, 540, 51 + i) for i in range(2)]
+    ctx = make_ctx(pano, d, 0, num_bands=3)
+    ctx.build_masks_voronoi()
+    masks = [ctx.get_mask(i) for i in range(2)]
+    full, _ = po.compose(frames, d["K"], d["R"], d["scale"], masks, 3)
+    assert np.array_equal(ctx.compose_host(frames), full)
+    for cut in ((1, 1, 5, 3), (3, 7, 1449, 516), (10, 136, 1430, 250), (1451, 522, 1, 1), (2, 0, 6, 523), (0, 521, 1452, 2),
+                (13, 3, 17, 9)):
+        ctx.set_cut(cut)
+        got = ctx.compose_host(frames)
+        assert np.array_equal(got, full[cut[1]:cut[1] + cut[3], cut[0]:cut[0] + cut[2]]), cut
