@@ -10,7 +10,8 @@ spherical warp + 5-band multi-band blend per group, fixed K/R (imx390-derived f=
   N > 1: launched by torch.distributed.run, one rank per GPU; cameras are sharded over the ranks
   (rank r owns cameras [8r/N, 8(r+1)/N)), each rank warps + builds the Gaussian pyramids of its cameras,
   ONE RCCL gather per group lands the pyramid slots on rank 0, which blends.  Total work per step is
-  fixed -> "scaling": "strong".
+  fixed -> "scaling": "strong".  (`replicas_panoramas_per_s` reports, as extra information, the same ranks each
+  composing their own rig with no exchange.)
 
 Prints ONE JSON line (rank 0).  `roofline` is the warp kernel (K1): algorithmic bytes
 sum_cams(W*H*3 read once + Wt*Ht*6 written once) per launch / mean launch duration from HIP events
@@ -146,6 +147,25 @@ def main():
         step()
     torch.cuda.synchronize()
     dt_profiled = time.perf_counter() - t1
+    # N > 1 only, extra information: the same K steps with every rank composing its OWN whole rig (replicas, no
+    # exchange).  One MI355X composes a panorama in ~0.16 ms, less than it takes to move one half panorama (11.6 MB)
+    # over an xGMI link, so sharding ONE rig over GPUs cannot raise throughput; independent rigs scale linearly.
+    replicas_rate = None
+    if world > 1:
+        try:
+            for c in ctxs:
+                c.set_profiling(False)
+            dist.barrier()
+            torch.cuda.synchronize()
+            tr = time.perf_counter()
+            for _ in range(args.steps):
+                step_single()
+            torch.cuda.synchronize()
+            trt = torch.tensor([time.perf_counter() - tr], dtype=torch.float64, device="cuda")
+            dist.all_reduce(trt, op=dist.ReduceOp.MAX)
+            replicas_rate = round(world * args.steps / float(trt.item()), 1)
+        except Exception:  # never let the side measurement break the contract line
+            replicas_rate = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -189,6 +209,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else "cameras sharded %d/rank, RCCL gather to rank 0" % per_rank},
             "roofline": roofline,
             "ms_per_step_event_pass": round(dt_profiled / args.steps * 1e3, 4),
+            "replicas_panoramas_per_s": replicas_rate,
             "stage_us_per_launch": {k: round(stage_ms[i] / max(stage_n[i], 1) * 1e3, 2)
                                     for i, k in enumerate(("warp", "pyramid", "blend"))},
         }
