@@ -389,14 +389,18 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
     // 27.3 MB raw) and still ran 15 % slower (23.8 vs 20.5 us, A/B in one process) - the kernel is bound by
     // tap-fetch issue and latency, not by DRAM bandwidth.  ABL == 8 (diagnostic build) turns it on.
     if (ABL == 8) xcd_remap(gridDim.x, gridDim.y, bx, by);
-    const int x0 = (bx * 64 + threadIdx.x) * NPX;
-    const int ybase = by * (4 * ROWS) + threadIdx.y;
+    // Wave shape: 16 lanes x 4 rows = a 64 x 4 pixel patch (a block = 64 x 16 pixels), not a 256-pixel strip.  Where
+    // the projection tilts rows (towards the tile edges) a long strip drags in dozens of source rows that many other
+    // workgroups - on other XCDs, with their own L2 - need too; compact patches keep the footprint local.
+    // Measured per 4-camera launch: 256x1 21.7 us, 128x2 19.2, 64x4 19.2, 32x8 21.4, 16x16 36.6.
+    const int x0 = (bx * 16 + (threadIdx.x & 15)) * NPX;
+    const int ybase = by * (16 * ROWS) + threadIdx.y * 4 + (threadIdx.x >> 4);
     if (x0 >= c.tw || ybase >= c.th) return;
     static_assert(NPX == 4, "one 16-byte table load per row");
     uint4 mm[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
-        const int y = min(ybase + 4 * r, c.th - 1);
+        const int y = min(ybase + 16 * r, c.th - 1);
         // plain (cached) loads and stores: non-temporal ones for the streamed table and tile measured 15 % slower
         mm[r] = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0);
     }
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
     const unsigned src_lo = (unsigned)(size_t)c.src & 3u;
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
-        const int y = ybase + 4 * r;
+        const int y = ybase + 16 * r;
         if (y >= c.th) break;
         const unsigned code[4] = {mm[r].x, mm[r].y, mm[r].z, mm[r].w};
         int v[NPX][3];
@@ -456,7 +460,8 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
 void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hipStream_t s, hipEvent_t ev_start,
                        hipEvent_t ev_stop) {
     dim3 block(64, 4, 1);
-    dim3 grid((max_tw + 255) / 256, (max_th + 3) / 4, ncam);
+    dim3 grid((max_tw + 255) / 256, (max_th + 3) / 4, ncam);      // projecting kernel: 256 x 4 pixel blocks
+    const dim3 grid_lut((max_tw + 63) / 64, (max_th + 15) / 16, ncam);  // table kernel: 64 x 16 pixel blocks
     // Tried and rejected (A/B in one process, same outputs): (1) XCD-aware block order and (2) padding the column
     // blocks to a multiple of 8 so that each XCD owns a 256-pixel column stripe.  Both cut the fetched bytes to the
     // minimum (FETCH_SIZE 42.8 -> 27 MB raw) and both ran SLOWER (23.8 / 27.1 us vs 21.8 us): concentrating an XCD
@@ -474,26 +479,16 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
 #ifdef PANO_DIAG
         static const int labl = getenv("PANO_LUT_ABL") ? atoi(getenv("PANO_LUT_ABL")) : 0;
         if (getenv("PANO_LUT_ROWS")) rows = atoi(getenv("PANO_LUT_ROWS"));
-        if (labl == 1) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<1, 4, 1>), grid); return; }
-        if (labl == 4) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<4, 4, 1>), grid); return; }
-        if (labl == 8) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<8, 4, 1>), grid); return; }
-        if (rows == 4) {
-            dim3 g4(grid.x, (max_th + 15) / 16, ncam);
-            PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, 4, 4>), g4);
-            return;
-        }
-        if (rows == 8) {
-            dim3 g8(grid.x, (max_th + 31) / 32, ncam);
-            PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, 4, 8>), g8);
-            return;
-        }
+        if (labl == 1) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<1, 4, 1>), grid_lut); return; }
+        if (labl == 4) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<4, 4, 1>), grid_lut); return; }
+        if (labl == 8) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<8, 4, 1>), grid_lut); return; }
 #endif
         if (rows == 2) {
-            dim3 g2(grid.x, (max_th + 7) / 8, ncam);
+            dim3 g2(grid_lut.x, (max_th + 31) / 32, ncam);
             PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, 4, 2>), g2);
             return;
         }
-        PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, 4, 1>), grid);
+        PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, 4, 1>), grid_lut);
     }
     else {
 #ifdef PANO_DIAG
