@@ -70,6 +70,11 @@ struct pano_ctx {
     int frame_w = 0, frame_h = 0;   // size of the frames pano_compose takes (raw size with a front end)
     uint32_t* lut[kMaxCams] = {};   // static remap tables of K1 (frames <= 2048 x 2048)
     int lut_pitch[kMaxCams] = {};
+    uint2* lutc[kMaxCams] = {};     // packed form (8 bytes per 4 pixels) read by K1; escapes fall back to lut
+    long long lut_groups[kMaxCams] = {}, lut_escaped[kMaxCams] = {};
+    int4* box[kMaxCams] = {};       // source box of every 64x16-pixel workgroup of K1
+    long long box_blocks[kMaxCams] = {}, box_fallback[kMaxCams] = {};
+    bool k1_packed = false, k1_box = false;  // PANO_K1_FORM: optional forms of K1 (measured slower; kept for A/B)
     bool use_lut = true;
     uint8_t* owner[kMaxLevels] = {};
     float* wsum[kMaxLevels] = {};
@@ -172,7 +177,7 @@ void free_device(pano_ctx* c) {
     drop_graphs(c);
     for (int i = 0; i < kMaxCams; i++) {
         dfree(c->colA[i]); dfree(c->rowB[i]); dfree(c->colA_roi[i]); dfree(c->rowB_roi[i]);
-        dfree(c->mask[i]); dfree(c->gain[i]); dfree(c->mask0[i]); dfree(c->lut[i]); dfree(c->d_fe[i]);
+        dfree(c->mask[i]); dfree(c->gain[i]); dfree(c->mask0[i]); dfree(c->lut[i]); dfree(c->lutc[i]); dfree(c->box[i]); dfree(c->d_fe[i]);
         dfree(c->gcol[i]); dfree(c->grow[i]); dfree(c->gcol_roi[i]); dfree(c->grow_roi[i]);
         dfree(c->gcolw[i]); dfree(c->groww[i]); dfree(c->gcolw_roi[i]); dfree(c->groww_roi[i]);
         dfree(c->stage_in[i]);
@@ -234,6 +239,9 @@ WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t strid
         w.dst_plane = c->lvl_plane[i][0];
         w.lut = c->use_lut ? c->lut[i] : nullptr;
         w.lut_pitch = c->lut_pitch[i];
+        w.lutc = c->use_lut && c->k1_packed ? c->lutc[i] : nullptr;
+        w.lutc_pitch = c->lut_pitch[i] / 4;
+        w.box = c->use_lut && c->k1_box ? c->box[i] : nullptr;
         w.gcol = c->gcol[i]; w.gcolw = c->gcolw[i]; w.grow = c->grow[i]; w.groww = c->groww[i];
     }
     w.gain = c->gain[i];
@@ -661,6 +669,38 @@ pano_status pano_prepare(pano_ctx* c) {
             WarpCam w = make_warp_cam(c, i, nullptr, (size_t)c->frame_w * 3, false);
             launch_build_warp_lut(w, c->lut[i], c->lut_pitch[i], nullptr);
         }
+        const char* form = getenv("PANO_K1_FORM");
+        c->k1_packed = form && std::strstr(form, "packed");
+        c->k1_box = form && std::strstr(form, "box");
+        unsigned* d_esc = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&d_esc, n * sizeof(unsigned)));
+        HIP_TRY(c, hipMemset(d_esc, 0, n * sizeof(unsigned)));
+        for (int i = 0; i < n && c->k1_packed; i++) {
+            const FeedTile& t = P.tile[i];
+            const int gp = c->lut_pitch[i] / 4;
+            hipError_t e = hipMalloc((void**)&c->lutc[i], (size_t)gp * t.rect.h * sizeof(uint2));
+            if (e != hipSuccess) { (void)hipFree(d_esc); HIP_TRY(c, e); }
+            launch_pack_warp_lut(c->lut[i], c->lut_pitch[i], t.rect.h, c->lutc[i], gp, d_esc + i, nullptr);
+            c->lut_groups[i] = (long long)gp * t.rect.h;
+        }
+        unsigned h_esc[kMaxCams] = {};
+        hipError_t e = hipMemcpy(h_esc, d_esc, n * sizeof(unsigned), hipMemcpyDeviceToHost);
+        for (int i = 0; i < n; i++) c->lut_escaped[i] = h_esc[i];
+        if (e == hipSuccess) e = hipMemset(d_esc, 0, n * sizeof(unsigned));
+        for (int i = 0; i < n && e == hipSuccess && c->k1_box; i++) {
+            const FeedTile& t = P.tile[i];
+            const size_t nb = (size_t)((t.rect.w + 63) / 64) * ((t.rect.h + 15) / 16);
+            e = hipMalloc((void**)&c->box[i], nb * sizeof(int4));
+            if (e != hipSuccess) break;
+            // boxes are in pixels of the frame K1 samples (the RAW frame when a front end is set), like the table
+            launch_build_warp_boxes(c->lut[i], c->lut_pitch[i], t.rect.w, t.rect.h, c->frame_w, c->frame_h, c->box[i],
+                                    d_esc + i, nullptr);
+            c->box_blocks[i] = (long long)nb;
+        }
+        if (e == hipSuccess) e = hipMemcpy(h_esc, d_esc, n * sizeof(unsigned), hipMemcpyDeviceToHost);
+        (void)hipFree(d_esc);
+        HIP_TRY(c, e);
+        for (int i = 0; i < n; i++) c->box_fallback[i] = h_esc[i];
         HIP_TRY(c, hipDeviceSynchronize());
     }
     // kernel parameter blocks
@@ -683,8 +723,9 @@ pano_status pano_prepare(pano_ctx* c) {
         c->cv.img[l] = c->canvas[l];
         // the vector blend kernel needs every tile box of the level on a 4 x 2 grid
         // ... and only pays on big levels: small ones are latency bound and want one pixel per thread
+        static const size_t vec_min_px = getenv("PANO_VEC_MIN_PIXELS") ? (size_t)atol(getenv("PANO_VEC_MIN_PIXELS")) : 600000;
         bool fast = P.bands >= 0 && ((P.canvas.w >> l) % 4 == 0) && ((P.canvas.h >> l) % 2 == 0) &&
-                    (size_t)(P.canvas.w >> l) * (P.canvas.h >> l) >= 600000;
+                    (size_t)(P.canvas.w >> l) * (P.canvas.h >> l) >= vec_min_px;
         for (int i = 0; i < n && fast; i++) {
             const Rect& r = P.tile[i].rect;
             fast = ((r.x >> l) % 4 == 0) && ((r.y >> l) % 2 == 0) && ((r.w >> l) % 4 == 0) && ((r.h >> l) % 2 == 0) &&
@@ -1348,6 +1389,27 @@ pano_status pano_get_warp_bytes(const pano_ctx* c, uint64_t* src_bytes, uint64_t
     }
     *src_bytes = s;
     *dst_bytes = d;
+    return PANO_OK;
+}
+
+pano_status pano_get_warp_table_stats(const pano_ctx* c, uint64_t* table_bytes, uint64_t* groups, uint64_t* escaped,
+                                      uint64_t* blocks, uint64_t* blocks_global) {
+    if (!c || !c->prepared || !table_bytes || !groups || !escaped || !blocks || !blocks_global) return PANO_EINVAL;
+    uint64_t g = 0, e = 0;
+    if (c->use_lut)
+        for (int i = 0; i < c->plan.n; i++) {
+            // K1 reads the groups of the tile proper (the row pad up to lut_pitch is never touched)
+            g += (uint64_t)((c->plan.tile[i].rect.w + 3) / 4) * c->plan.tile[i].rect.h;
+            e += (uint64_t)c->lut_escaped[i];
+        }
+    uint64_t nb = 0, nf = 0;
+    if (c->use_lut)
+        for (int i = 0; i < c->plan.n; i++) { nb += (uint64_t)c->box_blocks[i]; nf += (uint64_t)c->box_fallback[i]; }
+    *blocks = nb;
+    *blocks_global = nf;
+    *groups = g;
+    *escaped = e;
+    *table_bytes = c->k1_packed ? g * 8 + e * 16 : g * 16;
     return PANO_OK;
 }
 

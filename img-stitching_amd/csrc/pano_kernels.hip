@@ -357,9 +357,10 @@ __global__ __launch_bounds__(256) void build_warp_lut_kernel(WarpCam c, uint32_t
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= lut_pitch || y >= c.th) return;
     uint32_t code = 0xffffffffu;
-    if (x < c.tw) {
+    {
+        // the pad columns (x >= tw, never read downstream) repeat the last pixel so that they compress like it
         float fx, fy;
-        map_source(c, c.m, c.colA[x], c.rowB[y], fx, fy);
+        map_source(c, c.m, c.colA[min(x, c.tw - 1)], c.rowB[y], fx, fy);
         const int isx = cv_round_dev(fx * 32.f), isy = cv_round_dev(fy * 32.f);
         const int ix = sat16i(isx >> 5), iy = sat16i(isy >> 5);
         int xs, a1, ys, b1;
@@ -378,11 +379,119 @@ void launch_build_warp_lut(const WarpCam& c, uint32_t* lut, int lut_pitch, hipSt
     hipLaunchKernelGGL(build_warp_lut_kernel, grid, block, 0, s, c, lut, lut_pitch);
 }
 
-// NPX = pixels per lane, ROWS = tile rows per lane (rows y, y+4, y+8, ...: a block covers 4*ROWS rows).
-// The table entries of all ROWS rows are fetched up front; more work per wave amortises the per-wave
-// start-up (kernarg fetch, address setup) and keeps more loads in flight.
-template <int ABL, int NPX, int ROWS>
+// Packed table: the map is smooth, so inside a 4-pixel group the steps between neighbouring codes are a group constant
+// plus a rounding wobble.  8 bytes per group (2 per pixel) instead of 16:
+//   word 0         the code of pixel 0 (format above)
+//   word 1  0.. 8  Db  signed 9   x step base (negative in mirrored BORDER_REFLECT regions)
+//           9..13  Eb  signed 5   y step base
+//          14..31  three fields {cx signed 3, cy signed 3} for pixels 1..3:
+//                  X[j] = X[j-1] + Db + cx[j],  Y[j] = Y[j-1] + Eb + cy[j]     (X = xs*32+a', Y = ys*32+b')
+// A group whose steps do not fit (a reflect fold inside the group, marked pixels, extreme magnification) stores
+// word 0 = 0xffffffff and is read from the dense table instead - an exact format with an exact escape, no approximation.
+__global__ __launch_bounds__(256) void pack_warp_lut_kernel(const uint32_t* lut, int lut_pitch, int th, uint2* lutc,
+                                                            int lutc_pitch, unsigned* escaped) {
+    const int g = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (g >= lutc_pitch || y >= th) return;
+    const uint4 m = *reinterpret_cast<const uint4*>(lut + (size_t)y * lut_pitch + 4 * g);
+    const unsigned code[4] = {m.x, m.y, m.z, m.w};
+    uint2 e = make_uint2(0xffffffffu, 0u);
+    bool ok = true;
+    int dx[3], dy[3];
+#pragma unroll
+    for (int j = 0; j < 4; j++) ok &= code[j] != 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        dx[j] = (int)(code[j + 1] & 0xffffu) - (int)(code[j] & 0xffffu);
+        dy[j] = (int)(code[j + 1] >> 16) - (int)(code[j] >> 16);
+    }
+    const int Db = min(dx[0], min(dx[1], dx[2])) + 4, Eb = min(dy[0], min(dy[1], dy[2])) + 4;
+    ok &= Db >= -256 && Db <= 255 && Eb >= -16 && Eb <= 15;
+    unsigned w1 = ((unsigned)Db & 0x1ffu) | (((unsigned)Eb & 0x1fu) << 9);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int cx = dx[j] - Db, cy = dy[j] - Eb;
+        ok &= cx >= -4 && cx <= 3 && cy >= -4 && cy <= 3;
+        w1 |= (((unsigned)cx & 7u) << (14 + 6 * j)) | (((unsigned)cy & 7u) << (17 + 6 * j));
+    }
+    if (ok) e = make_uint2(code[0], w1);
+    else if (escaped) atomicAdd(escaped, 1u);
+    lutc[(size_t)y * lutc_pitch + g] = e;
+}
+void launch_pack_warp_lut(const uint32_t* lut, int lut_pitch, int th, uint2* lutc, int lutc_pitch, unsigned* escaped,
+                          hipStream_t s) {
+    dim3 block(64, 4, 1), grid((lutc_pitch + 63) / 64, (th + 3) / 4, 1);
+    hipLaunchKernelGGL(pack_warp_lut_kernel, grid, block, 0, s, lut, lut_pitch, th, lutc, lutc_pitch, escaped);
+}
+__device__ __forceinline__ int sbits(unsigned w, int off, int n) { return (int)(w << (32 - off - n)) >> (32 - n); }
+
+// Source boxes.  The table is static, so the set of frame bytes a 64 x 16 pixel workgroup taps is static too: its
+// bounding box {xmin, ymin, chunks per row, rows} is computed once here.  K1 copies the box into LDS with coalesced
+// 16-byte loads (issued together with the table load - no dependent global round trip) and takes the 8 taps of every
+// pixel from LDS.  Boxes that do not fit kBoxBytes (far outside the frame, where BORDER_REFLECT folds pile up), that
+// touch the last bytes of the frame, or blocks without a valid pixel get rows == 0 and keep the global-memory taps.
+constexpr int kBoxBytes = 16 * 1024;
+constexpr int kBoxIters = kBoxBytes / 16 / 256;
+__global__ __launch_bounds__(256) void build_warp_boxes_kernel(const uint32_t* lut, int lut_pitch, int tw, int th, int sw,
+                                                               int sh, int4* boxes, int gx, unsigned* fallback) {
+    __shared__ int lim[4];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if (tid == 0) { lim[0] = INT_MAX; lim[1] = -1; lim[2] = INT_MAX; lim[3] = -1; }
+    __syncthreads();
+    const int x0 = (blockIdx.x * 16 + (threadIdx.x & 15)) * 4;
+    const int y = blockIdx.y * 16 + threadIdx.y * 4 + (threadIdx.x >> 4);
+    if (x0 < tw && y < th) {
+        const uint4 m = *reinterpret_cast<const uint4*>(lut + (size_t)y * lut_pitch + x0);
+        const unsigned code[4] = {m.x, m.y, m.z, m.w};
+        int xa = INT_MAX, xb = -1, ya = INT_MAX, yb = -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (code[j] == 0xffffffffu) continue;
+            const int xs = (int)((code[j] & 0xffffu) >> 5), ys = min((int)(code[j] >> 21), sh - 1);
+            xa = min(xa, xs); xb = max(xb, xs);
+            ya = min(ya, ys); yb = max(yb, min(ys + 1, sh - 1));
+        }
+        if (xb >= 0) {
+            atomicMin(&lim[0], xa); atomicMax(&lim[1], xb);
+            atomicMin(&lim[2], ya); atomicMax(&lim[3], yb);
+        }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    int4 box = make_int4(0, 0, 0, 0);
+    if (lim[1] >= 0) {
+        const int xmin = lim[0], ymin = lim[2], h = lim[3] - lim[2] + 1;
+        // bytes 3*xmin .. 3*xmax+5 of each row, fetched from the enclosing 16-byte boundary (phase <= 15)
+        const int cpr = (3 * (lim[1] - xmin) + 21 + 15) / 16;
+        bool ok = h * (cpr + 1) * 16 <= kBoxBytes && cpr <= 63;
+        // the chunks of the last frame row must end inside the frame
+        ok &= !(lim[3] == sh - 1 && 3 * xmin + cpr * 16 > 3 * sw);
+        if (ok) box = make_int4(xmin, ymin, (h << 8) | cpr, (65536 + cpr - 1) / cpr);
+    }
+    if (box.z == 0 && fallback) atomicAdd(fallback, 1u);
+    boxes[blockIdx.y * gx + blockIdx.x] = box;
+}
+void launch_build_warp_boxes(const uint32_t* lut, int lut_pitch, int tw, int th, int sw, int sh, int4* boxes,
+                             unsigned* fallback, hipStream_t s) {
+    dim3 block(64, 4, 1), grid((tw + 63) / 64, (th + 15) / 16, 1);
+    hipLaunchKernelGGL(build_warp_boxes_kernel, grid, block, 0, s, lut, lut_pitch, tw, th, sw, sh, boxes, (int)grid.x,
+                       fallback);
+}
+
+// 6 bytes at byte offset o of the LDS box, from the enclosing dwords (the same realignment as load_taps6)
+__device__ __forceinline__ uint2 lds_taps6(const unsigned* __restrict__ sb, unsigned o) {
+    const unsigned* w = sb + (o >> 2);
+    const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
+    return make_uint2(__builtin_amdgcn_alignbyte(d1, d0, o & 3u), __builtin_amdgcn_alignbyte(d2, d1, o & 3u));
+}
+
+// K1, table form: one lane = 4 pixels of one tile row.
+// PACKED reads the 8-byte table groups, BOX stages the source box in LDS.  Both are exact and both are slower than the
+// plain form on MI355X (8-camera launch: dense+global 33 us, packed+global 35 us, dense+box 39 us, packed+box 43 us):
+// the kernel is bound by instruction issue and dependent-load latency, not by the bytes either one saves.  They stay
+// selectable (PANO_K1_FORM=packed|box|packed+box at pano_prepare) so the measurement can be repeated.
+template <int ABL, bool PACKED, bool BOX>
 __global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
+    __shared__ uint4 sbox[BOX ? kBoxBytes / 16 : 1];
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (ABL != 9) {
         // One camera per XCD.  Linear workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2); send
@@ -397,75 +506,130 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
         bx = b - by * gridDim.x;
     }
     const WarpCam& c = P.cam[bz];
-    // XCD-aware order is available but NOT used: it cut this kernel's fetched bytes by 36 % (FETCH_SIZE 42.8 ->
-    // 27.3 MB raw) and still ran 15 % slower (23.8 vs 20.5 us, A/B in one process) - the kernel is bound by
-    // tap-fetch issue and latency, not by DRAM bandwidth.  ABL == 8 (diagnostic build) turns it on.
+    // Tried and rejected: XCD-aware order of the blocks WITHIN a camera (fewer fetched bytes, 15 % slower).
     if (ABL == 8) xcd_remap(gridDim.x, gridDim.y, bx, by);
+    const int gxc = (c.tw + 63) >> 6;
+    if (bx >= gxc || by * 16 >= c.th) return;  // the whole workgroup leaves: nobody waits at the barrier below
     // Wave shape: 16 lanes x 4 rows = a 64 x 4 pixel patch (a block = 64 x 16 pixels), not a 256-pixel strip.  Where
-    // the projection tilts rows (towards the tile edges) a long strip drags in dozens of source rows that many other
-    // workgroups - on other XCDs, with their own L2 - need too; compact patches keep the footprint local.
-    // Measured per 4-camera launch: 256x1 21.7 us, 128x2 19.2, 64x4 19.2, 32x8 21.4, 16x16 36.6.
-    const int x0 = (bx * 16 + (threadIdx.x & 15)) * NPX;
-    const int ybase = by * (16 * ROWS) + threadIdx.y * 4 + (threadIdx.x >> 4);
-    if (x0 >= c.tw || ybase >= c.th) return;
-    static_assert(NPX == 4, "one 16-byte table load per row");
-    uint4 mm[ROWS];
+    // the projection tilts rows (towards the tile edges) a long strip drags in dozens of source rows; compact patches
+    // keep the footprint (and the LDS box) small.
+    // Measured per 4-camera launch (global taps): 256x1 21.7 us, 128x2 19.2, 64x4 19.2, 32x8 21.4, 16x16 36.6.
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int x0 = (bx * 16 + (threadIdx.x & 15)) * 4;
+    const int y = by * 16 + threadIdx.y * 4 + (threadIdx.x >> 4);
+    const bool active = x0 < c.tw && y < c.th;
+    const int stride = c.src_stride, sh1 = c.src_h - 1;
+    const unsigned src_lo = (unsigned)(size_t)c.src & 15u;
+
+    // 1. table entry of this lane's 4 pixels (plain cached loads: non-temporal ones measured 15 % slower)
+    uint4 mm = make_uint4(0u, 0u, 0u, 0u);
+    if (active) {
+        if (!PACKED) {
+            mm = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0);
+        } else if (ABL == 6) {  // diagnostic: no table bytes
+            const unsigned cc = (unsigned)((x0 * 7 / 8) * 32 + 5) | ((unsigned)((y * 7 / 8) * 32 + 9) << 16);
+            mm = make_uint4(cc, cc + 28, cc + 56, cc + 84);
+        } else {
+            uint2 e = c.lutc[(size_t)y * c.lutc_pitch + (x0 >> 2)];
+            if (ABL == 10 && e.x == 0xffffffffu) e = make_uint2(0u, 0u);  // diagnostic: escapes not served
+            if (e.x != 0xffffffffu) {
+                const int Db = sbits(e.y, 0, 9), Eb = sbits(e.y, 9, 5);
+                int X = (int)(e.x & 0xffffu), Y = (int)(e.x >> 16);
+                unsigned cd[4];
+                cd[0] = e.x;
 #pragma unroll
-    for (int r = 0; r < ROWS; r++) {
-        const int y = min(ybase + 16 * r, c.th - 1);
-        // plain (cached) loads and stores: non-temporal ones for the streamed table and tile measured 15 % slower
-        mm[r] = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0);
-    }
-    const int sh1 = c.src_h - 1, stride = c.src_stride;
-    const unsigned src_lo = (unsigned)(size_t)c.src & 3u;
-#pragma unroll
-    for (int r = 0; r < ROWS; r++) {
-        const int y = ybase + 16 * r;
-        if (y >= c.th) break;
-        const unsigned code[4] = {mm[r].x, mm[r].y, mm[r].z, mm[r].w};
-        int v[NPX][3];
-        uint2 t[NPX], u[NPX];
-        int fa[NPX], fb[NPX];
-        bool marked = false;
-#pragma unroll
-        for (int j = 0; j < NPX; j++) {
-            const bool mk = code[j] == 0xffffffffu;
-            const unsigned m = mk ? 0u : code[j];  // a marked pixel fetches (0,0) and is recomputed below
-            marked |= mk;
-            const unsigned mx = m & 0xffffu, my = m >> 16;
-            fa[j] = mx & 31; fb[j] = my & 31;
-            const int xs = mx >> 5, ys = min((int)(my >> 5), sh1), ys1 = min(ys + 1, sh1);
-            if (ABL == 1) {  // diagnostic: no tap loads
-                t[j] = make_uint2(xs * 0x01010101u, ys);
-                u[j] = make_uint2(ys * 0x01010101u, xs);
+                for (int j = 0; j < 3; j++) {
+                    X += Db + sbits(e.y, 14 + 6 * j, 3);
+                    Y += Eb + sbits(e.y, 17 + 6 * j, 3);
+                    cd[j + 1] = (unsigned)X | ((unsigned)Y << 16);
+                }
+                mm = make_uint4(cd[0], cd[1], cd[2], cd[3]);
             } else {
-                t[j] = load_taps6(c.src, src_lo, (unsigned)(ys * stride) + 3 * xs);
-                u[j] = load_taps6(c.src, src_lo, (unsigned)(ys1 * stride) + 3 * xs);
+                mm = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0);
             }
         }
+    }
+
+    // 2. this workgroup's source box -> LDS
+    const int4 bb = (!BOX || ABL == 6) ? make_int4(0, 0, 0, 0) : c.box[by * gxc + bx];
+    const int bh = bb.z >> 8, cpr = bb.z & 255, lpitch = (cpr + 1) * 16;
+    const unsigned q = src_lo + (unsigned)(bb.y * stride + 3 * bb.x);  // byte phase of the box origin
+    if (BOX && bh) {
+        const int total = bh * cpr;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 chunk[kBoxIters];
 #pragma unroll
-        for (int j = 0; j < NPX; j++) bilinear_packed(t[j], u[j], fa[j], fb[j], v[j]);
-        if (marked && ABL == 0) {
-            // rare: the bottom-right corner of the frame; project these pixels on the fly
-#pragma unroll
-            for (int j = 0; j < NPX; j++)
-                if (code[j] == 0xffffffffu) {
-                    float fx, fy;
-                    map_source(c, c.m, c.colA[min(x0 + j, c.tw - 1)], c.rowB[y], fx, fy);
-                    sample_bilinear_reflect<0>(c.src, c.src_w, c.src_h, stride, fx, fy, v[j]);
-                }
+        for (int it = 0; it < kBoxIters; it++) {
+            const int k = tid + 256 * it;
+            chunk[it] = (u32x4)(0u);
+            if (k < total) {
+                const int r = (k * bb.w) >> 16, ci = k - r * cpr;
+                const unsigned o = (unsigned)((bb.y + r) * stride + 3 * bb.x);
+                chunk[it] = *reinterpret_cast<const u32x4*>(c.src + (o - ((o + src_lo) & 15u)) + ci * 16);
+            }
         }
-        if (c.gain) {
+        u32x4* sb4 = reinterpret_cast<u32x4*>(sbox);
 #pragma unroll
-            for (int j = 0; j < NPX; j++) apply_gain(c, min(x0 + j, c.tw - 1), y, v[j]);
+        for (int it = 0; it < kBoxIters; it++) {
+            const int k = tid + 256 * it;
+            if (k < total) {
+                const int r = (k * bb.w) >> 16, ci = k - r * cpr;
+                sb4[r * (cpr + 1) + ci] = chunk[it];
+            }
         }
-        uint8_t* d = (uint8_t*)c.dst + (size_t)y * c.dst_pitch + x0;
+        __syncthreads();
+    }
+    if (!active) return;
+
+    // 3. taps + the fixed-point bilinear of cv::remap
+    const unsigned code[4] = {mm.x, mm.y, mm.z, mm.w};
+    int v[4][3];
+    uint2 t[4], u[4];
+    int fa[4], fb[4];
+    bool marked = false;
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            const unsigned pk = (unsigned)v[0][ch] | ((unsigned)v[1][ch] << 8) | ((unsigned)v[2][ch] << 16) | ((unsigned)v[3][ch] << 24);
-            if (ABL == 4 && pk != 0x12345678u) continue;  // diagnostic: no stores
-            *reinterpret_cast<unsigned*>(d + (size_t)ch * c.dst_plane) = pk;  // rows are padded to 16 bytes
+    for (int j = 0; j < 4; j++) {
+        const bool mk = code[j] == 0xffffffffu;
+        const unsigned m = mk ? 0u : code[j];  // a marked pixel is recomputed below
+        marked |= mk;
+        const unsigned mx = m & 0xffffu, my = m >> 16;
+        fa[j] = mx & 31; fb[j] = my & 31;
+        const int xs = mx >> 5, ys = min((int)(my >> 5), sh1), ys1 = min(ys + 1, sh1);
+        if (ABL == 1) {  // diagnostic: no tap loads
+            t[j] = make_uint2(xs * 0x01010101u, ys);
+            u[j] = make_uint2(ys * 0x01010101u, xs);
+        } else if (BOX && bh) {
+            const int r0 = mk ? 0 : ys - bb.y, r1 = mk ? 0 : ys1 - bb.y, dx3 = mk ? 0 : 3 * (xs - bb.x);
+            const unsigned* sb = reinterpret_cast<const unsigned*>(sbox);
+            t[j] = lds_taps6(sb, (unsigned)(r0 * lpitch + dx3) + ((q + (unsigned)(r0 * stride)) & 15u));
+            u[j] = lds_taps6(sb, (unsigned)(r1 * lpitch + dx3) + ((q + (unsigned)(r1 * stride)) & 15u));
+        } else {
+            t[j] = load_taps6(c.src, src_lo & 3u, (unsigned)(ys * stride) + 3 * xs);
+            u[j] = load_taps6(c.src, src_lo & 3u, (unsigned)(ys1 * stride) + 3 * xs);
         }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) bilinear_packed(t[j], u[j], fa[j], fb[j], v[j]);
+    if (marked && ABL == 0) {
+        // rare: the bottom-right corner of the frame; project these pixels on the fly
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (code[j] == 0xffffffffu) {
+                float fx, fy;
+                map_source(c, c.m, c.colA[min(x0 + j, c.tw - 1)], c.rowB[y], fx, fy);
+                sample_bilinear_reflect<0>(c.src, c.src_w, c.src_h, stride, fx, fy, v[j]);
+            }
+    }
+    if (c.gain) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) apply_gain(c, min(x0 + j, c.tw - 1), y, v[j]);
+    }
+    uint8_t* d = (uint8_t*)c.dst + (size_t)y * c.dst_pitch + x0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const unsigned pk = (unsigned)v[0][ch] | ((unsigned)v[1][ch] << 8) | ((unsigned)v[2][ch] << 16) | ((unsigned)v[3][ch] << 24);
+        if (ABL == 4 && pk != 0x12345678u) continue;  // diagnostic: no stores
+        *reinterpret_cast<unsigned*>(d + (size_t)ch * c.dst_plane) = pk;  // rows are padded to 16 bytes
     }
 }
 
@@ -487,21 +651,24 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
         else hipLaunchKernelGGL(K, G, block, 0, s, p);                                        \
     } while (0)
     if (all_lut) {
-        int rows = 1;
+        bool packed = true, box = true;
+        for (int i = 0; i < ncam; i++) { packed &= p.cam[i].lutc != nullptr; box &= p.cam[i].box != nullptr; }
 #ifdef PANO_DIAG
         static const int labl = getenv("PANO_LUT_ABL") ? atoi(getenv("PANO_LUT_ABL")) : 0;
-        if (getenv("PANO_LUT_ROWS")) rows = atoi(getenv("PANO_LUT_ROWS"));
-        if (labl == 1) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<1, 4, 1>), grid_lut); return; }
-        if (labl == 4) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<4, 4, 1>), grid_lut); return; }
-        if (labl == 8) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<8, 4, 1>), grid_lut); return; }
-        if (labl == 9) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<9, 4, 1>), grid_lut); return; }
-#endif
-        if (rows == 2) {
-            dim3 g2(grid_lut.x, (max_th + 31) / 32, ncam);
-            PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, 4, 2>), g2);
-            return;
+        if (!packed && !box) switch (labl) {
+            case 1: PANO_LAUNCH_K1((warp_tiles_lut_kernel<1, false, false>), grid_lut); return;
+            case 4: PANO_LAUNCH_K1((warp_tiles_lut_kernel<4, false, false>), grid_lut); return;
+            case 8: PANO_LAUNCH_K1((warp_tiles_lut_kernel<8, false, false>), grid_lut); return;
+            case 9: PANO_LAUNCH_K1((warp_tiles_lut_kernel<9, false, false>), grid_lut); return;
+            default: break;
         }
-        PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, 4, 1>), grid_lut);
+        if (packed && !box && labl == 6) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<6, true, false>), grid_lut); return; }
+        if (packed && !box && labl == 10) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<10, true, false>), grid_lut); return; }
+#endif
+        if (packed && box) PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, true, true>), grid_lut);
+        else if (packed) PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, true, false>), grid_lut);
+        else if (box) PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, false, true>), grid_lut);
+        else PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, false, false>), grid_lut);
     }
     else {
 #ifdef PANO_DIAG

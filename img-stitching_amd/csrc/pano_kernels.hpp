@@ -33,6 +33,9 @@ struct WarpCam {
     // static remap table (frames up to 2048 x 2048): one dword per tile pixel, see build_warp_lut_kernel
     const uint32_t* lut;  // nullptr -> project on the fly
     int lut_pitch;        // dwords per row (multiple of 4)
+    const uint2* lutc;    // packed table, 8 bytes per 4-pixel group (see pack_warp_lut_kernel); escapes read lut
+    int lutc_pitch;       // groups per row = lut_pitch / 4
+    const int4* box;      // per 64x16-pixel workgroup: {xmin, ymin, rows<<8 | chunks per row, ceil(2^16/chunks)}; rows 0 = global taps
     const FrontEndDev* fe; // nullptr, or the undistort front end: src is then the RAW frame (src_w x src_h raw)
     int out_w, out_h;     // the stitcher's frame size (mask warp inside test); == src_w x src_h without a front end
     const float* gain;    // [gh][gw] block gains or nullptr
@@ -95,6 +98,10 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // builds the static remap table of one camera tile (run once per pano_prepare)
 void launch_build_warp_lut(const WarpCam& c, uint32_t* lut, int lut_pitch, hipStream_t s);
+void launch_build_warp_boxes(const uint32_t* lut, int lut_pitch, int tw, int th, int sw, int sh, int4* boxes,
+                             unsigned* fallback, hipStream_t s);
+void launch_pack_warp_lut(const uint32_t* lut, int lut_pitch, int th, uint2* lutc, int lutc_pitch, unsigned* escaped,
+                          hipStream_t s);
 // stage entry: plain RotationWarper::warp to an 8UC3 image
 void launch_warp_image(const WarpCam& c, hipStream_t s);
 // RotationWarper::warp(mask255, INTER_NEAREST, BORDER_CONSTANT)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic: K1 as an 8-camera launch (pano_compose_pair), timed by its dispatch events."""
+"""Diagnostic: per-kernel durations of one compose_pair (C2) under different vector/small level splits."""
 import importlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch
+import time, torch
 from helpers import c2_group, synth_frame
 pano = importlib.import_module("img-stitching_amd")
 g = c2_group()
@@ -17,14 +17,21 @@ frames = [[torch.from_numpy(synth_frame(g["w"], g["h"], 42 + 4 * k + i)).cuda() 
 ow, oh = ctxs[0].output_size()
 outs = [torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
 st = torch.cuda.current_stream().cuda_stream
-ctxs[0].set_profiling(True)
 def step():
     ctxs[0].compose_pair(ctxs[1], [t.data_ptr() for t in frames[0]], [g["w"] * 3] * 4, outs[0].data_ptr(), ow * 3,
                          [t.data_ptr() for t in frames[1]], [g["w"] * 3] * 4, outs[1].data_ptr(), ow * 3, st)
-for _ in range(10): step()
+for _ in range(20): step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+N = 300
+for _ in range(N): step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / N
+ctxs[0].set_profiling(True)
 ctxs[0].stage_stats(True)
-for _ in range(100): step()
+for _ in range(50): step()
 torch.cuda.synchronize()
 ms, n = ctxs[0].stage_stats(True)
-print(json.dumps({"abl": os.environ.get("PANO_LUT_ABL", "0"), "warp8_us": round(ms[0] / n[0] * 1e3, 2), "pyr_us": round(ms[1] / n[1] * 1e3, 2), "blend_us": round(ms[2] / n[2] * 1e3, 2)}))
-print(json.dumps({"table": [c.warp_table_stats() for c in ctxs]}))
+print(json.dumps({"vec_min_px": os.environ.get("PANO_VEC_MIN_PIXELS"), "pair_us": round(dt * 1e6, 1), "pano_per_s": round(2 / dt, 1),
+                  "warp8_us": round(ms[0] / n[0] * 1e3, 2), "pyr_us": round(ms[1] / n[1] * 1e3, 2), "blend_us": round(ms[2] / n[2] * 1e3, 2),
+                  "sum": hex(int(outs[0].sum().item()) ^ int(outs[1].sum().item()))}))
