@@ -294,9 +294,9 @@ class Context:
         self._ck(self.lib.pano_get_warp_bytes(self.h, C.byref(a), C.byref(b))); return a.value, b.value
 
     def warp_table_stats(self):
-        a = C.c_uint64(); b = C.c_uint64(); e = C.c_uint64(); nb = C.c_uint64(); nf = C.c_uint64()
-        self._ck(self.lib.pano_get_warp_table_stats(self.h, C.byref(a), C.byref(b), C.byref(e), C.byref(nb), C.byref(nf)))
-        return {"table_bytes": a.value, "groups": b.value, "escaped": e.value, "blocks": nb.value, "blocks_global": nf.value}
+        a = C.c_uint64(); nb = C.c_uint64(); nf = C.c_uint64()
+        self._ck(self.lib.pano_get_warp_table_stats(self.h, C.byref(a), C.byref(nb), C.byref(nf)))
+        return {"table_bytes": a.value, "blocks": nb.value, "blocks_checked": nf.value}
 
     # -- stage inspection
     def debug_level(self, i, level):

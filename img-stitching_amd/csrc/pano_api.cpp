@@ -70,11 +70,11 @@ struct pano_ctx {
     int frame_w = 0, frame_h = 0;   // size of the frames pano_compose takes (raw size with a front end)
     uint32_t* lut[kMaxCams] = {};   // static remap tables of K1 (frames <= 2048 x 2048)
     int lut_pitch[kMaxCams] = {};
-    uint2* lutc[kMaxCams] = {};     // packed form (8 bytes per 4 pixels) read by K1; escapes fall back to lut
-    long long lut_groups[kMaxCams] = {}, lut_escaped[kMaxCams] = {};
-    int4* box[kMaxCams] = {};       // source box of every 64x16-pixel workgroup of K1
-    long long box_blocks[kMaxCams] = {}, box_fallback[kMaxCams] = {};
-    bool k1_packed = false, k1_box = false;  // PANO_K1_FORM: optional forms of K1 (measured slower; kept for A/B)
+    uint2* lutc[kMaxCams] = {};         // packed form of lut (8 bytes per 4 pixels), read by unflagged workgroups
+    int4* box[kMaxCams] = {};           // source box of every 64x16-pixel workgroup of K1
+    long long box_global[kMaxCams] = {}; // workgroups whose box does not fit LDS (global taps)
+    uint32_t* k1_flags[kMaxCams] = {};  // per K1 workgroup: the table holds marked pixels there
+    long long k1_blocks[kMaxCams] = {}, k1_flagged[kMaxCams] = {};
     bool use_lut = true;
     uint8_t* owner[kMaxLevels] = {};
     float* wsum[kMaxLevels] = {};
@@ -177,7 +177,7 @@ void free_device(pano_ctx* c) {
     drop_graphs(c);
     for (int i = 0; i < kMaxCams; i++) {
         dfree(c->colA[i]); dfree(c->rowB[i]); dfree(c->colA_roi[i]); dfree(c->rowB_roi[i]);
-        dfree(c->mask[i]); dfree(c->gain[i]); dfree(c->mask0[i]); dfree(c->lut[i]); dfree(c->lutc[i]); dfree(c->box[i]); dfree(c->d_fe[i]);
+        dfree(c->mask[i]); dfree(c->gain[i]); dfree(c->mask0[i]); dfree(c->lut[i]); dfree(c->lutc[i]); dfree(c->box[i]); dfree(c->k1_flags[i]); dfree(c->d_fe[i]);
         dfree(c->gcol[i]); dfree(c->grow[i]); dfree(c->gcol_roi[i]); dfree(c->grow_roi[i]);
         dfree(c->gcolw[i]); dfree(c->groww[i]); dfree(c->gcolw_roi[i]); dfree(c->groww_roi[i]);
         dfree(c->stage_in[i]);
@@ -239,9 +239,9 @@ WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t strid
         w.dst_plane = c->lvl_plane[i][0];
         w.lut = c->use_lut ? c->lut[i] : nullptr;
         w.lut_pitch = c->lut_pitch[i];
-        w.lutc = c->use_lut && c->k1_packed ? c->lutc[i] : nullptr;
+        w.lutc = c->use_lut ? c->lutc[i] : nullptr;
+        w.box = c->use_lut ? c->box[i] : nullptr;
         w.lutc_pitch = c->lut_pitch[i] / 4;
-        w.box = c->use_lut && c->k1_box ? c->box[i] : nullptr;
         w.gcol = c->gcol[i]; w.gcolw = c->gcolw[i]; w.grow = c->grow[i]; w.groww = c->groww[i];
     }
     w.gain = c->gain[i];
@@ -669,38 +669,31 @@ pano_status pano_prepare(pano_ctx* c) {
             WarpCam w = make_warp_cam(c, i, nullptr, (size_t)c->frame_w * 3, false);
             launch_build_warp_lut(w, c->lut[i], c->lut_pitch[i], nullptr);
         }
-        const char* form = getenv("PANO_K1_FORM");
-        c->k1_packed = form && std::strstr(form, "packed");
-        c->k1_box = form && std::strstr(form, "box");
-        unsigned* d_esc = nullptr;
-        HIP_TRY(c, hipMalloc((void**)&d_esc, n * sizeof(unsigned)));
-        HIP_TRY(c, hipMemset(d_esc, 0, n * sizeof(unsigned)));
-        for (int i = 0; i < n && c->k1_packed; i++) {
-            const FeedTile& t = P.tile[i];
-            const int gp = c->lut_pitch[i] / 4;
-            hipError_t e = hipMalloc((void**)&c->lutc[i], (size_t)gp * t.rect.h * sizeof(uint2));
-            if (e != hipSuccess) { (void)hipFree(d_esc); HIP_TRY(c, e); }
-            launch_pack_warp_lut(c->lut[i], c->lut_pitch[i], t.rect.h, c->lutc[i], gp, d_esc + i, nullptr);
-            c->lut_groups[i] = (long long)gp * t.rect.h;
-        }
-        unsigned h_esc[kMaxCams] = {};
-        hipError_t e = hipMemcpy(h_esc, d_esc, n * sizeof(unsigned), hipMemcpyDeviceToHost);
-        for (int i = 0; i < n; i++) c->lut_escaped[i] = h_esc[i];
-        if (e == hipSuccess) e = hipMemset(d_esc, 0, n * sizeof(unsigned));
-        for (int i = 0; i < n && e == hipSuccess && c->k1_box; i++) {
+        for (int i = 0; i < n; i++) {
             const FeedTile& t = P.tile[i];
             const size_t nb = (size_t)((t.rect.w + 63) / 64) * ((t.rect.h + 15) / 16);
-            e = hipMalloc((void**)&c->box[i], nb * sizeof(int4));
-            if (e != hipSuccess) break;
+            const int gp = c->lut_pitch[i] / 4;
+            HIP_TRY(c, hipMalloc((void**)&c->k1_flags[i], nb * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemset(c->k1_flags[i], 0, nb * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void**)&c->lutc[i], (size_t)gp * t.rect.h * sizeof(uint2)));
+            launch_pack_warp_lut(c->lut[i], c->lut_pitch[i], t.rect.w, t.rect.h, c->lutc[i], gp, c->k1_flags[i], nullptr);
+            std::vector<uint32_t> hf(nb);
+            HIP_TRY(c, hipMemcpy(hf.data(), c->k1_flags[i], nb * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            c->k1_blocks[i] = (long long)nb;
+            c->k1_flagged[i] = 0;
+            for (uint32_t f : hf) c->k1_flagged[i] += f != 0;
+            unsigned* d_cnt = nullptr;
+            HIP_TRY(c, hipMalloc((void**)&d_cnt, sizeof(unsigned)));
+            HIP_TRY(c, hipMemset(d_cnt, 0, sizeof(unsigned)));
+            HIP_TRY(c, hipMalloc((void**)&c->box[i], nb * sizeof(int4)));
             // boxes are in pixels of the frame K1 samples (the RAW frame when a front end is set), like the table
-            launch_build_warp_boxes(c->lut[i], c->lut_pitch[i], t.rect.w, t.rect.h, c->frame_w, c->frame_h, c->box[i],
-                                    d_esc + i, nullptr);
-            c->box_blocks[i] = (long long)nb;
+            launch_build_warp_boxes(c->lut[i], c->lut_pitch[i], t.rect.w, t.rect.h, c->frame_w, c->frame_h, c->box[i], d_cnt, nullptr);
+            unsigned h_cnt = 0;
+            hipError_t ce = hipMemcpy(&h_cnt, d_cnt, sizeof(unsigned), hipMemcpyDeviceToHost);
+            (void)hipFree(d_cnt);
+            HIP_TRY(c, ce);
+            c->box_global[i] = h_cnt;
         }
-        if (e == hipSuccess) e = hipMemcpy(h_esc, d_esc, n * sizeof(unsigned), hipMemcpyDeviceToHost);
-        (void)hipFree(d_esc);
-        HIP_TRY(c, e);
-        for (int i = 0; i < n; i++) c->box_fallback[i] = h_esc[i];
         HIP_TRY(c, hipDeviceSynchronize());
     }
     // kernel parameter blocks
@@ -1392,24 +1385,21 @@ pano_status pano_get_warp_bytes(const pano_ctx* c, uint64_t* src_bytes, uint64_t
     return PANO_OK;
 }
 
-pano_status pano_get_warp_table_stats(const pano_ctx* c, uint64_t* table_bytes, uint64_t* groups, uint64_t* escaped,
-                                      uint64_t* blocks, uint64_t* blocks_global) {
-    if (!c || !c->prepared || !table_bytes || !groups || !escaped || !blocks || !blocks_global) return PANO_EINVAL;
-    uint64_t g = 0, e = 0;
+pano_status pano_get_warp_table_stats(const pano_ctx* c, uint64_t* table_bytes, uint64_t* blocks, uint64_t* blocks_checked) {
+    if (!c || !c->prepared || !table_bytes || !blocks || !blocks_checked) return PANO_EINVAL;
+    uint64_t g = 0, nb = 0, nf = 0;
     if (c->use_lut)
         for (int i = 0; i < c->plan.n; i++) {
-            // K1 reads the groups of the tile proper (the row pad up to lut_pitch is never touched)
-            g += (uint64_t)((c->plan.tile[i].rect.w + 3) / 4) * c->plan.tile[i].rect.h;
-            e += (uint64_t)c->lut_escaped[i];
+            // unflagged workgroups read 2 bytes per pixel (packed groups), flagged ones 4 (dense table)
+            const uint64_t px = (uint64_t)c->plan.tile[i].rect.w * c->plan.tile[i].rect.h;
+            const uint64_t fpx = std::min<uint64_t>(px, (uint64_t)c->k1_flagged[i] * 64 * 16);
+            g += (px - fpx) * 2 + fpx * 4;
+            nb += (uint64_t)c->k1_blocks[i];
+            nf += (uint64_t)c->k1_flagged[i];
         }
-    uint64_t nb = 0, nf = 0;
-    if (c->use_lut)
-        for (int i = 0; i < c->plan.n; i++) { nb += (uint64_t)c->box_blocks[i]; nf += (uint64_t)c->box_fallback[i]; }
+    *table_bytes = g;
     *blocks = nb;
-    *blocks_global = nf;
-    *groups = g;
-    *escaped = e;
-    *table_bytes = c->k1_packed ? g * 8 + e * 16 : g * 16;
+    *blocks_checked = nf;
     return PANO_OK;
 }
 

@@ -379,22 +379,22 @@ void launch_build_warp_lut(const WarpCam& c, uint32_t* lut, int lut_pitch, hipSt
     hipLaunchKernelGGL(build_warp_lut_kernel, grid, block, 0, s, c, lut, lut_pitch);
 }
 
-// Packed table: the map is smooth, so inside a 4-pixel group the steps between neighbouring codes are a group constant
-// plus a rounding wobble.  8 bytes per group (2 per pixel) instead of 16:
+// Packed table.  The map is smooth, so inside a 4-pixel group the steps between neighbouring codes are a group
+// constant plus a rounding wobble: 8 bytes per group (2 per pixel) instead of 16.
 //   word 0         the code of pixel 0 (format above)
-//   word 1  0.. 8  Db  signed 9   x step base (negative in mirrored BORDER_REFLECT regions)
-//           9..13  Eb  signed 5   y step base
+//   word 1  0.. 7  Db  signed 8   x step base (negative in mirrored BORDER_REFLECT regions)
+//           8..13  Eb  signed 6   y step base
 //          14..31  three fields {cx signed 3, cy signed 3} for pixels 1..3:
 //                  X[j] = X[j-1] + Db + cx[j],  Y[j] = Y[j-1] + Eb + cy[j]     (X = xs*32+a', Y = ys*32+b')
-// A group whose steps do not fit (a reflect fold inside the group, marked pixels, extreme magnification) stores
-// word 0 = 0xffffffff and is read from the dense table instead - an exact format with an exact escape, no approximation.
-__global__ __launch_bounds__(256) void pack_warp_lut_kernel(const uint32_t* lut, int lut_pitch, int th, uint2* lutc,
-                                                            int lutc_pitch, unsigned* escaped) {
+// Exact or not at all: a group whose steps do not fit (a reflect fold inside the group, a marked pixel, > 4x
+// magnification) stores word 0 = 0xffffffff and K1 reads its four codes from the dense table instead (on the 1080p rig
+// about one group in 300; `flags` marks the 64 x 16 pixel workgroups that hold one, for the statistics).
+__global__ __launch_bounds__(256) void pack_warp_lut_kernel(const uint32_t* lut, int lut_pitch, int tw, int th, uint2* lutc,
+                                                            int lutc_pitch, uint32_t* flags, int gx) {
     const int g = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (g >= lutc_pitch || y >= th) return;
     const uint4 m = *reinterpret_cast<const uint4*>(lut + (size_t)y * lut_pitch + 4 * g);
     const unsigned code[4] = {m.x, m.y, m.z, m.w};
-    uint2 e = make_uint2(0xffffffffu, 0u);
     bool ok = true;
     int dx[3], dy[3];
 #pragma unroll
@@ -405,32 +405,31 @@ __global__ __launch_bounds__(256) void pack_warp_lut_kernel(const uint32_t* lut,
         dy[j] = (int)(code[j + 1] >> 16) - (int)(code[j] >> 16);
     }
     const int Db = min(dx[0], min(dx[1], dx[2])) + 4, Eb = min(dy[0], min(dy[1], dy[2])) + 4;
-    ok &= Db >= -256 && Db <= 255 && Eb >= -16 && Eb <= 15;
-    unsigned w1 = ((unsigned)Db & 0x1ffu) | (((unsigned)Eb & 0x1fu) << 9);
+    ok &= Db >= -128 && Db <= 127 && Eb >= -32 && Eb <= 31;
+    unsigned w1 = ((unsigned)Db & 0xffu) | (((unsigned)Eb & 0x3fu) << 8);
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int cx = dx[j] - Db, cy = dy[j] - Eb;
         ok &= cx >= -4 && cx <= 3 && cy >= -4 && cy <= 3;
         w1 |= (((unsigned)cx & 7u) << (14 + 6 * j)) | (((unsigned)cy & 7u) << (17 + 6 * j));
     }
-    if (ok) e = make_uint2(code[0], w1);
-    else if (escaped) atomicAdd(escaped, 1u);
-    lutc[(size_t)y * lutc_pitch + g] = e;
+    lutc[(size_t)y * lutc_pitch + g] = ok ? make_uint2(code[0], w1) : make_uint2(0xffffffffu, 0u);
+    if (!ok && 4 * g < tw) flags[(y >> 4) * gx + (g >> 4)] = 1u;  // same value from every writer
 }
-void launch_pack_warp_lut(const uint32_t* lut, int lut_pitch, int th, uint2* lutc, int lutc_pitch, unsigned* escaped,
+void launch_pack_warp_lut(const uint32_t* lut, int lut_pitch, int tw, int th, uint2* lutc, int lutc_pitch, uint32_t* flags,
                           hipStream_t s) {
     dim3 block(64, 4, 1), grid((lutc_pitch + 63) / 64, (th + 3) / 4, 1);
-    hipLaunchKernelGGL(pack_warp_lut_kernel, grid, block, 0, s, lut, lut_pitch, th, lutc, lutc_pitch, escaped);
+    hipLaunchKernelGGL(pack_warp_lut_kernel, grid, block, 0, s, lut, lut_pitch, tw, th, lutc, lutc_pitch, flags,
+                       (tw + 63) / 64);
 }
 __device__ __forceinline__ int sbits(unsigned w, int off, int n) { return (int)(w << (32 - off - n)) >> (32 - n); }
 
-// Source boxes.  The table is static, so the set of frame bytes a 64 x 16 pixel workgroup taps is static too: its
-// bounding box {xmin, ymin, chunks per row, rows} is computed once here.  K1 copies the box into LDS with coalesced
-// 16-byte loads (issued together with the table load - no dependent global round trip) and takes the 8 taps of every
-// pixel from LDS.  Boxes that do not fit kBoxBytes (far outside the frame, where BORDER_REFLECT folds pile up), that
-// touch the last bytes of the frame, or blocks without a valid pixel get rows == 0 and keep the global-memory taps.
-constexpr int kBoxBytes = 16 * 1024;
-constexpr int kBoxIters = kBoxBytes / 16 / 256;
+// Source boxes.  The table is static, so the set of frame bytes a 64 x 16 pixel workgroup of K1 taps is static too:
+// its bounding box {xmin, ymin, rows << 8 | 16-byte chunks per row, ceil(2^16 / chunks)} is computed once here.
+// Boxes that do not fit kBoxBytes (far outside the frame, where BORDER_REFLECT folds pile up), that would read past
+// the last bytes of the frame, or workgroups without a valid pixel get rows == 0 and tap global memory instead.
+constexpr int kBoxBytes = 16 * 1024;            // LDS per workgroup, one spare row included
+constexpr int kBoxIters = kBoxBytes / 16 / 256;  // 16-byte chunk loads per lane, at most
 __global__ __launch_bounds__(256) void build_warp_boxes_kernel(const uint32_t* lut, int lut_pitch, int tw, int th, int sw,
                                                                int sh, int4* boxes, int gx, unsigned* fallback) {
     __shared__ int lim[4];
@@ -446,9 +445,9 @@ __global__ __launch_bounds__(256) void build_warp_boxes_kernel(const uint32_t* l
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (code[j] == 0xffffffffu) continue;
-            const int xs = (int)((code[j] & 0xffffu) >> 5), ys = min((int)(code[j] >> 21), sh - 1);
+            const int xs = (int)((code[j] & 0xffffu) >> 5), ys = (int)(code[j] >> 21);
             xa = min(xa, xs); xb = max(xb, xs);
-            ya = min(ya, ys); yb = max(yb, min(ys + 1, sh - 1));
+            ya = min(ya, ys); yb = max(yb, ys);
         }
         if (xb >= 0) {
             atomicMin(&lim[0], xa); atomicMax(&lim[1], xb);
@@ -459,12 +458,15 @@ __global__ __launch_bounds__(256) void build_warp_boxes_kernel(const uint32_t* l
     if (tid != 0) return;
     int4 box = make_int4(0, 0, 0, 0);
     if (lim[1] >= 0) {
-        const int xmin = lim[0], ymin = lim[2], h = lim[3] - lim[2] + 1;
-        // bytes 3*xmin .. 3*xmax+5 of each row, fetched from the enclosing 16-byte boundary (phase <= 15)
+        const int xmin = lim[0], ymin = lim[2];
+        // rows ymin .. min(ymax + 1, sh - 1) are loaded; the taps of row ymax + 1 == sh (weight 0) read the spare row
+        const int h = min(lim[3] + 1, sh - 1) - ymin + 1;
+        // bytes 3*xmin .. 3*xmax+5 of each row, fetched from the enclosing 16-byte boundary (phase <= 15); the
+        // realigning tap read touches up to 6 bytes more, which the spare chunk of the LDS pitch absorbs
         const int cpr = (3 * (lim[1] - xmin) + 21 + 15) / 16;
-        bool ok = h * (cpr + 1) * 16 <= kBoxBytes && cpr <= 63;
+        bool ok = (h + 1) * (cpr + 1) * 16 <= kBoxBytes && cpr <= 63 && h * cpr <= 256 * kBoxIters;
         // the chunks of the last frame row must end inside the frame
-        ok &= !(lim[3] == sh - 1 && 3 * xmin + cpr * 16 > 3 * sw);
+        ok &= !(ymin + h - 1 == sh - 1 && 3 * xmin + cpr * 16 > 3 * sw);
         if (ok) box = make_int4(xmin, ymin, (h << 8) | cpr, (65536 + cpr - 1) / cpr);
     }
     if (box.z == 0 && fallback) atomicAdd(fallback, 1u);
@@ -477,140 +479,59 @@ void launch_build_warp_boxes(const uint32_t* lut, int lut_pitch, int tw, int th,
                        fallback);
 }
 
-// 6 bytes at byte offset o of the LDS box, from the enclosing dwords (the same realignment as load_taps6)
-__device__ __forceinline__ uint2 lds_taps6(const unsigned* __restrict__ sb, unsigned o) {
-    const unsigned* w = sb + (o >> 2);
-    const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
-    return make_uint2(__builtin_amdgcn_alignbyte(d1, d0, o & 3u), __builtin_amdgcn_alignbyte(d2, d1, o & 3u));
+// v_pk_mul_lo_u16 / v_pk_mad_u16 with the SAME half of the weight register feeding both 16-bit lanes (op_sel), so a
+// weight pair (32-a) | a << 16 serves both products without being splatted first.
+__device__ __forceinline__ unsigned pk_mul_whi(unsigned x, unsigned w) {
+    unsigned d;
+    asm("v_pk_mul_lo_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "v"(w));
+    return d;
+}
+__device__ __forceinline__ unsigned pk_mad_wlo(unsigned x, unsigned w, unsigned acc) {
+    unsigned d;
+    asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "v"(w), "v"(acc));
+    return d;
+}
+// The bilinear of one pixel, result left in byte 2 of r[c] (bits 16..23): the vertical weights carry a factor 64, so
+//   r = ((32-b)*64*h_top + b*64*h_bot + 512*64)  =  ((sum + 512) >> 10) << 16  +  (low 16 bits of no interest)
+// and four pixels are packed into a plane dword with byte permutes instead of shifts.
+__device__ __forceinline__ void bilinear_b2(uint2 t, uint2 u, unsigned a, unsigned b, unsigned r[3]) {
+    const unsigned WA = a * 0xffffu + 32u;        // (32-a) | a << 16
+    const unsigned WB = b * 0x3fffc0u + 2048u;    // (32-b)*64 | b*64 << 16
+    const unsigned l0 = __builtin_amdgcn_perm(u.x, t.x, 0x0c040c00u), r0 = __builtin_amdgcn_perm(u.x, t.x, 0x0c070c03u);
+    const unsigned l1 = __builtin_amdgcn_perm(u.x, t.x, 0x0c050c01u), r1 = __builtin_amdgcn_perm(u.y, t.y, 0x0c040c00u);
+    const unsigned l2 = __builtin_amdgcn_perm(u.x, t.x, 0x0c060c02u), r2 = __builtin_amdgcn_perm(u.y, t.y, 0x0c050c01u);
+    const unsigned h0 = pk_mad_wlo(l0, WA, pk_mul_whi(r0, WA));
+    const unsigned h1 = pk_mad_wlo(l1, WA, pk_mul_whi(r1, WA));
+    const unsigned h2 = pk_mad_wlo(l2, WA, pk_mul_whi(r2, WA));
+    const us2_t wb = __builtin_bit_cast(us2_t, WB);
+    r[0] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, h0), wb, 32768u, false);
+    r[1] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, h1), wb, 32768u, false);
+    r[2] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, h2), wb, 32768u, false);
 }
 
-// K1, table form: one lane = 4 pixels of one tile row.
-// PACKED reads the 8-byte table groups, BOX stages the source box in LDS.  Both are exact and both are slower than the
-// plain form on MI355X (8-camera launch: dense+global 33 us, packed+global 35 us, dense+box 39 us, packed+box 43 us):
-// the kernel is bound by instruction issue and dependent-load latency, not by the bytes either one saves.  They stay
-// selectable (PANO_K1_FORM=packed|box|packed+box at pano_prepare) so the measurement can be repeated.
-template <int ABL, bool PACKED, bool BOX>
-__global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
-    __shared__ uint4 sbox[BOX ? kBoxBytes / 16 : 1];
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (ABL != 9) {
-        // One camera per XCD.  Linear workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2); send
-        // id L to camera L % ncam, block L / ncam: with 8 (or 4, 2) cameras an XCD's L2 only ever holds one camera's
-        // frame, and every camera still advances top to bottom with all XCDs busy.  A bijection for any ncam - the
-        // placement is speed only.  Measured on the 8-camera launch: 33.1 vs 36.0 us (ABL 9 = dispatch order).
-        const int ncam = gridDim.z;
-        const int L = (bz * gridDim.y + by) * gridDim.x + bx;
-        bz = L % ncam;
-        const int b = L / ncam;
-        by = b / gridDim.x;
-        bx = b - by * gridDim.x;
-    }
-    const WarpCam& c = P.cam[bz];
-    // Tried and rejected: XCD-aware order of the blocks WITHIN a camera (fewer fetched bytes, 15 % slower).
-    if (ABL == 8) xcd_remap(gridDim.x, gridDim.y, bx, by);
-    const int gxc = (c.tw + 63) >> 6;
-    if (bx >= gxc || by * 16 >= c.th) return;  // the whole workgroup leaves: nobody waits at the barrier below
-    // Wave shape: 16 lanes x 4 rows = a 64 x 4 pixel patch (a block = 64 x 16 pixels), not a 256-pixel strip.  Where
-    // the projection tilts rows (towards the tile edges) a long strip drags in dozens of source rows; compact patches
-    // keep the footprint (and the LDS box) small.
-    // Measured per 4-camera launch (global taps): 256x1 21.7 us, 128x2 19.2, 64x4 19.2, 32x8 21.4, 16x16 36.6.
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int x0 = (bx * 16 + (threadIdx.x & 15)) * 4;
-    const int y = by * 16 + threadIdx.y * 4 + (threadIdx.x >> 4);
-    const bool active = x0 < c.tw && y < c.th;
+// The per-lane body of the general kernel: marked pixels, frames or strides of any alignment.
+template <int ABL>
+__device__ __forceinline__ void warp_lane_checked(const WarpCam& c, int x0, int y, uint4 mm, int v[4][3]) {
     const int stride = c.src_stride, sh1 = c.src_h - 1;
-    const unsigned src_lo = (unsigned)(size_t)c.src & 15u;
-
-    // 1. table entry of this lane's 4 pixels (plain cached loads: non-temporal ones measured 15 % slower)
-    uint4 mm = make_uint4(0u, 0u, 0u, 0u);
-    if (active) {
-        if (!PACKED) {
-            mm = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0);
-        } else if (ABL == 6) {  // diagnostic: no table bytes
-            const unsigned cc = (unsigned)((x0 * 7 / 8) * 32 + 5) | ((unsigned)((y * 7 / 8) * 32 + 9) << 16);
-            mm = make_uint4(cc, cc + 28, cc + 56, cc + 84);
-        } else {
-            uint2 e = c.lutc[(size_t)y * c.lutc_pitch + (x0 >> 2)];
-            if (ABL == 10 && e.x == 0xffffffffu) e = make_uint2(0u, 0u);  // diagnostic: escapes not served
-            if (e.x != 0xffffffffu) {
-                const int Db = sbits(e.y, 0, 9), Eb = sbits(e.y, 9, 5);
-                int X = (int)(e.x & 0xffffu), Y = (int)(e.x >> 16);
-                unsigned cd[4];
-                cd[0] = e.x;
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    X += Db + sbits(e.y, 14 + 6 * j, 3);
-                    Y += Eb + sbits(e.y, 17 + 6 * j, 3);
-                    cd[j + 1] = (unsigned)X | ((unsigned)Y << 16);
-                }
-                mm = make_uint4(cd[0], cd[1], cd[2], cd[3]);
-            } else {
-                mm = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0);
-            }
-        }
-    }
-
-    // 2. this workgroup's source box -> LDS
-    const int4 bb = (!BOX || ABL == 6) ? make_int4(0, 0, 0, 0) : c.box[by * gxc + bx];
-    const int bh = bb.z >> 8, cpr = bb.z & 255, lpitch = (cpr + 1) * 16;
-    const unsigned q = src_lo + (unsigned)(bb.y * stride + 3 * bb.x);  // byte phase of the box origin
-    if (BOX && bh) {
-        const int total = bh * cpr;
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 chunk[kBoxIters];
-#pragma unroll
-        for (int it = 0; it < kBoxIters; it++) {
-            const int k = tid + 256 * it;
-            chunk[it] = (u32x4)(0u);
-            if (k < total) {
-                const int r = (k * bb.w) >> 16, ci = k - r * cpr;
-                const unsigned o = (unsigned)((bb.y + r) * stride + 3 * bb.x);
-                chunk[it] = *reinterpret_cast<const u32x4*>(c.src + (o - ((o + src_lo) & 15u)) + ci * 16);
-            }
-        }
-        u32x4* sb4 = reinterpret_cast<u32x4*>(sbox);
-#pragma unroll
-        for (int it = 0; it < kBoxIters; it++) {
-            const int k = tid + 256 * it;
-            if (k < total) {
-                const int r = (k * bb.w) >> 16, ci = k - r * cpr;
-                sb4[r * (cpr + 1) + ci] = chunk[it];
-            }
-        }
-        __syncthreads();
-    }
-    if (!active) return;
-
-    // 3. taps + the fixed-point bilinear of cv::remap
+    const unsigned src_lo = (unsigned)(size_t)c.src & 3u;
     const unsigned code[4] = {mm.x, mm.y, mm.z, mm.w};
-    int v[4][3];
     uint2 t[4], u[4];
     int fa[4], fb[4];
     bool marked = false;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const bool mk = code[j] == 0xffffffffu;
-        const unsigned m = mk ? 0u : code[j];  // a marked pixel is recomputed below
+        const unsigned m = mk ? 0u : code[j];  // a marked pixel fetches (0,0) and is recomputed below
         marked |= mk;
         const unsigned mx = m & 0xffffu, my = m >> 16;
         fa[j] = mx & 31; fb[j] = my & 31;
         const int xs = mx >> 5, ys = min((int)(my >> 5), sh1), ys1 = min(ys + 1, sh1);
-        if (ABL == 1) {  // diagnostic: no tap loads
-            t[j] = make_uint2(xs * 0x01010101u, ys);
-            u[j] = make_uint2(ys * 0x01010101u, xs);
-        } else if (BOX && bh) {
-            const int r0 = mk ? 0 : ys - bb.y, r1 = mk ? 0 : ys1 - bb.y, dx3 = mk ? 0 : 3 * (xs - bb.x);
-            const unsigned* sb = reinterpret_cast<const unsigned*>(sbox);
-            t[j] = lds_taps6(sb, (unsigned)(r0 * lpitch + dx3) + ((q + (unsigned)(r0 * stride)) & 15u));
-            u[j] = lds_taps6(sb, (unsigned)(r1 * lpitch + dx3) + ((q + (unsigned)(r1 * stride)) & 15u));
-        } else {
-            t[j] = load_taps6(c.src, src_lo & 3u, (unsigned)(ys * stride) + 3 * xs);
-            u[j] = load_taps6(c.src, src_lo & 3u, (unsigned)(ys1 * stride) + 3 * xs);
-        }
+        t[j] = load_taps6(c.src, src_lo, (unsigned)(ys * stride) + 3 * xs);
+        u[j] = load_taps6(c.src, src_lo, (unsigned)(ys1 * stride) + 3 * xs);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) bilinear_packed(t[j], u[j], fa[j], fb[j], v[j]);
-    if (marked && ABL == 0) {
+    if (marked) {
         // rare: the bottom-right corner of the frame; project these pixels on the fly
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -620,6 +541,34 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
                 sample_bilinear_reflect<0>(c.src, c.src_w, c.src_h, stride, fx, fy, v[j]);
             }
     }
+}
+
+// Marked pixels of one lane (taps next to the last bytes of the frame: a handful of pixels per camera) projected on
+// the fly and stored over what the straight-line body wrote for them.  Deliberately NOT inlined: inlined, its
+// register needs would be paid by every wave of the kernel below.
+__device__ __attribute__((noinline)) void warp_fix_marked(const WarpCam* c, int x0, int y, uint4 mm) {
+    const unsigned code[4] = {mm.x, mm.y, mm.z, mm.w};
+    for (int j = 0; j < 4; j++) {
+        if (code[j] != 0xffffffffu) continue;
+        float fx, fy;
+        int v[3];
+        map_source(*c, c->m, c->colA[min(x0 + j, c->tw - 1)], c->rowB[y], fx, fy);
+        sample_bilinear_reflect<0>(c->src, c->src_w, c->src_h, c->src_stride, fx, fy, v);
+        uint8_t* d = (uint8_t*)c->dst + (size_t)y * c->dst_pitch + x0 + j;
+        for (int ch = 0; ch < 3; ch++) d[(size_t)ch * c->dst_plane] = (uint8_t)v[ch];
+    }
+}
+
+// K1, table form, the general kernel: any frame alignment, exposure gains, dense table, global taps.
+template <int ABL>
+__global__ __launch_bounds__(256) void warp_tiles_lut_checked_kernel(WarpParams P) {
+    const WarpCam& c = P.cam[blockIdx.x];
+    const int x0 = (blockIdx.y * 16 + (threadIdx.x & 15)) * 4;
+    const int y = blockIdx.z * 16 + threadIdx.y * 4 + (threadIdx.x >> 4);
+    if (x0 >= c.tw || y >= c.th) return;
+    const uint4 mm = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0);
+    int v[4][3];
+    warp_lane_checked<ABL>(c, x0, y, mm, v);
     if (c.gain) {
 #pragma unroll
         for (int j = 0; j < 4; j++) apply_gain(c, min(x0 + j, c.tw - 1), y, v[j]);
@@ -628,16 +577,201 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_kernel(WarpParams P) {
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         const unsigned pk = (unsigned)v[0][ch] | ((unsigned)v[1][ch] << 8) | ((unsigned)v[2][ch] << 16) | ((unsigned)v[3][ch] << 24);
-        if (ABL == 4 && pk != 0x12345678u) continue;  // diagnostic: no stores
         *reinterpret_cast<unsigned*>(d + (size_t)ch * c.dst_plane) = pk;  // rows are padded to 16 bytes
     }
+}
+
+// K1, table form: one lane = 4 pixels of one tile row, one workgroup = a 64 x 16 pixel patch (4 waves of 64 x 4).
+// What bounds it (measured on the 8-camera launch, SQ counters + ablations):
+//   * not bytes: halving the table (packed form) or serving every tap from one L1-resident corner of the frame
+//     changes nothing;
+//   * the texture-address unit: a 64-lane gather costs the same ~19 cycles per CU whether it fetches 1, 2, 3 or
+//     4 dwords per lane, and eight tap gathers per wave (2 rows x 4 pixels) were 16 of the kernel's 33 us;
+//   * VALU issue: 223 instructions per wave kept the vector ALUs 70 % busy.
+// So the taps do not come from global memory: the static table fixes the set of frame bytes a workgroup touches (its
+// source box, see build_warp_boxes_kernel); the workgroup copies that box into LDS with coalesced 16-byte loads -
+// 1 to 2 gathers per wave instead of 8, issued together with the table load - and reads the taps from LDS.
+// Workgroups whose box does not fit keep the global taps.  Needs 4-byte aligned frames and strides % 16 == 0
+// (checked by the launcher; anything else runs warp_tiles_lut_checked_kernel).
+template <int ABL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void warp_tiles_lut_kernel(WarpParams P) {
+    __shared__ uint4 sbox[kBoxBytes / 16];
+    // grid = (ncam, ceil(tw/64), ceil(th/16)): the camera is the FASTEST workgroup coordinate.  Linear workgroup ids
+    // are dealt round-robin over the 8 XCDs (each with its own L2), so with 8 (or 4, 2) cameras an XCD's L2 only ever
+    // holds one camera's frame, and every camera still advances top to bottom with all XCDs busy.  Measured on the
+    // 8-camera launch against camera-major dispatch order: 33.1 vs 36.0 us, FETCH_SIZE 50.8 vs 77.8 MB.
+    // Tried and rejected: XCD-aware order of the blocks WITHIN a camera (fewer fetched bytes, 15 % slower).
+    const int bx = blockIdx.y, by = blockIdx.z;
+    // Prologue: an empty body over this grid (53 K workgroups) costs 9.4 us when the camera block is read field by
+    // field behind branches - a chain of dependent scalar loads per wave, which the compiler is free to build by
+    // sinking kernarg loads below the bounds test.  Fetch the 64-byte hot part with ONE s_load_dwordx16.
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    struct Hot {
+        const uint8_t* src; uint8_t* dst; const uint2* lutc; const int4* box;
+        int tw, th, src_w, src_h, src_stride, dst_pitch, dst_plane, lutc_pitch;
+    };
+    static_assert(sizeof(Hot) == 64 && offsetof(WarpCam, lutc_pitch) == 60 && offsetof(WarpCam, src) == 0 &&
+                      offsetof(WarpCam, box) == 24, "hot part layout");
+    union { i32x16 v; Hot h; } hot;
+    // WarpParams is the only kernel argument: P.cam[i] sits at kernarg + i * sizeof(WarpCam)
+    const char __attribute__((address_space(4)))* ka =
+        (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.x * sizeof(WarpCam);
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hot.v) : "s"(ka) : "memory");
+    // the camera block as a plain pointer for the rare out-of-line paths (a reference to the by-value kernel argument
+    // would make the compiler copy all of WarpParams to scratch)
+    const WarpCam* const cg = (const WarpCam*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.x * sizeof(WarpCam));
+    // the pointers come out of the asm block without an address space: say "global", or every access is a flat_load
+#define PANO_GLOBAL __attribute__((address_space(1)))
+    const uint8_t PANO_GLOBAL* const src = (const uint8_t PANO_GLOBAL*)hot.h.src;
+    uint8_t PANO_GLOBAL* const dst = (uint8_t PANO_GLOBAL*)hot.h.dst;
+    const u32x2 PANO_GLOBAL* const lutc = (const u32x2 PANO_GLOBAL*)hot.h.lutc;
+    const int tw = hot.h.tw, th = hot.h.th, src_w = hot.h.src_w, src_h = hot.h.src_h;
+    const unsigned stride = (unsigned)hot.h.src_stride;
+    const unsigned dst_pitch = (unsigned)hot.h.dst_pitch, dst_plane = (unsigned)hot.h.dst_plane, lutc_pitch = (unsigned)hot.h.lutc_pitch;
+    const int gxc = (tw + 63) >> 6;
+    if (bx >= gxc || by * 16 >= th) return;  // the whole workgroup leaves: nobody waits at the barrier below
+    // this workgroup's source box: one more scalar load
+    i32x4 bb;
+    {
+        const char __attribute__((address_space(4)))* bp =
+            (const char __attribute__((address_space(4)))*)hot.h.box + (unsigned)(by * gxc + bx) * 16u;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(bb) : "s"(bp) : "memory");
+    }
+    // Wave shape: 16 lanes x 4 rows = a 64 x 4 pixel patch, not a 256-pixel strip.  Where the projection tilts rows
+    // (towards the tile edges) a long strip drags in dozens of source rows; compact patches keep the box small.
+    // Measured per 4-camera launch (global taps): 256x1 21.7 us, 128x2 19.2, 64x4 19.2, 32x8 21.4, 16x16 36.6.
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int x0 = (bx * 16 + (threadIdx.x & 15)) * 4;
+    const int y = by * 16 + threadIdx.y * 4 + (threadIdx.x >> 4);
+    const bool active = x0 < tw && y < th;
+    // plain (cached) loads and stores: non-temporal ones for the streamed table and tile measured 15 % slower
+    u32x2 e = u32x2{0u, 0u};
+    if (active) e = lutc[(unsigned)y * lutc_pitch + (unsigned)(x0 >> 2)];
+    if (ABL == 6 || ABL == 17) e = u32x2{(unsigned)((x0 * 7 / 8) * 32 + 5) | ((unsigned)((y * 7 / 8) * 32 + 9) << 16), 32u};
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bb) : : "memory");  // bb is only valid past this point
+    if (ABL == 12 || ABL == 6 || ABL == 17) bb.z = 0;  // diagnostic: global taps everywhere
+    const int bh = bb.z >> 8, cpr = bb.z & 255;
+    const unsigned lpitch = (unsigned)(cpr + 1) * 16u;
+    // byte phase of the box origin inside its first 16-byte chunk; the same for every row because stride % 16 == 0
+    const unsigned lo16 = (unsigned)(size_t)hot.h.src & 15u;
+    const unsigned og = (unsigned)bb.y * stride + 3u * (unsigned)bb.x + lo16;  // from the 16-byte boundary below src
+    const unsigned ph = og & 15u;
+    if (bh) {
+        const int total = bh * cpr;
+        u32x4 chunk[kBoxIters];
+#pragma unroll
+        for (int it = 0; it < kBoxIters; it++) {
+            const int k = tid + 256 * it;
+            chunk[it] = u32x4{0u, 0u, 0u, 0u};
+            if (k < total) {
+                const unsigned r = (unsigned)(k * bb.w) >> 16, ci = (unsigned)k - r * (unsigned)cpr;
+                chunk[it] = *reinterpret_cast<const u32x4 PANO_GLOBAL*>((src - lo16) + (og - ph + r * stride + ci * 16u));
+            }
+        }
+        u32x4* sb4 = reinterpret_cast<u32x4*>(sbox);
+#pragma unroll
+        for (int it = 0; it < kBoxIters; it++) {
+            const int k = tid + 256 * it;
+            if (k < total) {
+                const unsigned r = (unsigned)(k * bb.w) >> 16, ci = (unsigned)k - r * (unsigned)cpr;
+                sb4[r * (unsigned)(cpr + 1) + ci] = chunk[it];
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    uint8_t PANO_GLOBAL* d = dst + ((unsigned)y * dst_pitch + (unsigned)x0);  // 32-bit offsets: a tile is far below 4 GB
+    if (ABL == 18) {  // diagnostic: dispatch + prologue + table + box load only
+        if (e.x == 0x7ffffff0u) *reinterpret_cast<unsigned PANO_GLOBAL*>(d) = e.y;
+        return;
+    }
+    unsigned X[4], Y[4];
+    {
+        const int Db = sbits(e.y, 0, 8), Eb = sbits(e.y, 8, 6);
+        X[0] = e.x & 0xffffu; Y[0] = e.x >> 16;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            X[j + 1] = X[j] + (unsigned)(Db + sbits(e.y, 14 + 6 * j, 3));
+            Y[j + 1] = Y[j] + (unsigned)(Eb + sbits(e.y, 17 + 6 * j, 3));
+        }
+    }
+    // an escaped group (a BORDER_REFLECT fold inside it, a marked pixel) reads its four codes from the dense table:
+    // one more dependent load for the waves that hold one (about one in eight)
+    uint4 mm = make_uint4(0u, 0u, 0u, 0u);
+    bool marked = false;
+    if (e.x == 0xffffffffu) {
+        mm = *reinterpret_cast<const uint4*>(cg->lut + ((unsigned)y * (4u * lutc_pitch) + (unsigned)x0));
+        const unsigned code[4] = {mm.x, mm.y, mm.z, mm.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool mk = code[j] == 0xffffffffu;  // taps the box origin (or (0,0)), recomputed by warp_fix_marked
+            marked |= mk;
+            X[j] = mk ? (unsigned)bb.x << 5 : code[j] & 0xffffu;
+            Y[j] = mk ? (unsigned)bb.y << 5 : code[j] >> 16;
+        }
+    }
+    uint2 t[4], u[4];
+    if (bh) {
+        // LDS byte offset of pixel (xs, ys): (ys - ymin) * lpitch + 3 * (xs - xmin) + ph.  Three aligned dwords and
+        // v_alignbyte, like the global taps: 8-byte ds reads at odd addresses work but run the kernel at half speed.
+        const unsigned cst = ph - (unsigned)bb.y * lpitch - 3u * (unsigned)bb.x;
+        const unsigned* sb = reinterpret_cast<const unsigned*>(sbox);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned off = __umul24(Y[j] >> 5, lpitch) + __umul24(X[j] >> 5, 3u) + cst;
+            const unsigned k = off & 3u;
+            const unsigned* wt = sb + (off >> 2);
+            const unsigned* wu = wt + (lpitch >> 2);  // row ys + 1; for ys == sh - 1 (weight 0) the spare row
+            if (ABL == 1) {  // diagnostic: no tap reads
+                t[j] = make_uint2(off, k); u[j] = make_uint2(k, off);
+            } else {
+                t[j] = make_uint2(__builtin_amdgcn_alignbyte(wt[1], wt[0], k), __builtin_amdgcn_alignbyte(wt[2], wt[1], k));
+                u[j] = make_uint2(__builtin_amdgcn_alignbyte(wu[1], wu[0], k), __builtin_amdgcn_alignbyte(wu[2], wu[1], k));
+            }
+        }
+    } else {
+        // last aligned offset a 12-byte fetch may start at.  Row ys + 1 of a pixel on the last frame row lands beyond
+        // it and is clamped: that row always carries weight b' = 0 (see lut_axis), any readable bytes do.
+        const unsigned o_last = ((unsigned)(src_h - 1) * stride + 3u * (unsigned)src_w - 12u) & ~3u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned ot = __umul24(Y[j] >> 5, stride) + __umul24(X[j] >> 5, 3u);
+            const unsigned k = ot & 3u, oa = ot & ~3u;
+            const unsigned ob = min(oa + stride, o_last);
+            if (ABL == 1 || ABL == 17) {  // diagnostic: no tap loads
+                t[j] = make_uint2(oa, ob); u[j] = make_uint2(ob, oa);
+            } else {
+                const u32x3 dt = *reinterpret_cast<const u32x3 PANO_GLOBAL*>(src + oa);
+                const u32x3 du = *reinterpret_cast<const u32x3 PANO_GLOBAL*>(src + ob);
+                t[j] = make_uint2(__builtin_amdgcn_alignbyte(dt.y, dt.x, k), __builtin_amdgcn_alignbyte(dt.z, dt.y, k));
+                u[j] = make_uint2(__builtin_amdgcn_alignbyte(du.y, du.x, k), __builtin_amdgcn_alignbyte(du.z, du.y, k));
+            }
+        }
+    }
+    unsigned r[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++) bilinear_b2(t[j], u[j], X[j] & 31u, Y[j] & 31u, r[j]);
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        // byte 2 of r[0..3][ch] -> bytes 0..3
+        const unsigned lo = __builtin_amdgcn_perm(r[1][ch], r[0][ch], 0x0c0c0602u);
+        const unsigned hi = __builtin_amdgcn_perm(r[3][ch], r[2][ch], 0x06020c0cu);
+        const unsigned pk = lo | hi;
+        if ((ABL == 4 || ABL == 17) && pk != 0x12345678u) continue;  // diagnostic: no stores
+        *reinterpret_cast<unsigned PANO_GLOBAL*>(d + (unsigned)ch * dst_plane) = pk;  // rows are padded to 16 bytes
+    }
+    if (marked && ABL == 0) warp_fix_marked(cg, x0, y, mm);
 }
 
 void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hipStream_t s, hipEvent_t ev_start,
                        hipEvent_t ev_stop) {
     dim3 block(64, 4, 1);
     dim3 grid((max_tw + 255) / 256, (max_th + 3) / 4, ncam);      // projecting kernel: 256 x 4 pixel blocks
-    const dim3 grid_lut((max_tw + 63) / 64, (max_th + 15) / 16, ncam);  // table kernel: 64 x 16 pixel blocks
+    const dim3 grid_lut(ncam, (max_tw + 63) / 64, (max_th + 15) / 16);  // table kernels: 64 x 16 pixel workgroups, camera fastest
     // Tried and rejected (A/B in one process, same outputs): (1) XCD-aware block order and (2) padding the column
     // blocks to a multiple of 8 so that each XCD owns a 256-pixel column stripe.  Both cut the fetched bytes to the
     // minimum (FETCH_SIZE 42.8 -> 27 MB raw) and both ran SLOWER (23.8 / 27.1 us vs 21.8 us): concentrating an XCD
@@ -651,24 +785,27 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
         else hipLaunchKernelGGL(K, G, block, 0, s, p);                                        \
     } while (0)
     if (all_lut) {
-        bool packed = true, box = true;
-        for (int i = 0; i < ncam; i++) { packed &= p.cam[i].lutc != nullptr; box &= p.cam[i].box != nullptr; }
+        // the LDS kernel wants 4-byte aligned frames, strides % 16 == 0 and no exposure gains; anything else takes the
+        // general kernel (same table, global taps, per-pixel checked body)
+        bool fast = true;
+        for (int i = 0; i < ncam; i++)
+            fast &= ((size_t)p.cam[i].src & 3u) == 0 && (p.cam[i].src_stride & 15) == 0 && p.cam[i].gain == nullptr &&
+                    p.cam[i].lutc != nullptr && p.cam[i].box != nullptr;
 #ifdef PANO_DIAG
         static const int labl = getenv("PANO_LUT_ABL") ? atoi(getenv("PANO_LUT_ABL")) : 0;
-        if (!packed && !box) switch (labl) {
-            case 1: PANO_LAUNCH_K1((warp_tiles_lut_kernel<1, false, false>), grid_lut); return;
-            case 4: PANO_LAUNCH_K1((warp_tiles_lut_kernel<4, false, false>), grid_lut); return;
-            case 8: PANO_LAUNCH_K1((warp_tiles_lut_kernel<8, false, false>), grid_lut); return;
-            case 9: PANO_LAUNCH_K1((warp_tiles_lut_kernel<9, false, false>), grid_lut); return;
+        if (fast) switch (labl) {
+            case 1: PANO_LAUNCH_K1(warp_tiles_lut_kernel<1>, grid_lut); return;
+            case 4: PANO_LAUNCH_K1(warp_tiles_lut_kernel<4>, grid_lut); return;
+            case 6: PANO_LAUNCH_K1(warp_tiles_lut_kernel<6>, grid_lut); return;
+            case 12: PANO_LAUNCH_K1(warp_tiles_lut_kernel<12>, grid_lut); return;
+            case 17: PANO_LAUNCH_K1(warp_tiles_lut_kernel<17>, grid_lut); return;
+            case 18: PANO_LAUNCH_K1(warp_tiles_lut_kernel<18>, grid_lut); return;
+            case 13: fast = false; break;  // the general kernel
             default: break;
         }
-        if (packed && !box && labl == 6) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<6, true, false>), grid_lut); return; }
-        if (packed && !box && labl == 10) { PANO_LAUNCH_K1((warp_tiles_lut_kernel<10, true, false>), grid_lut); return; }
 #endif
-        if (packed && box) PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, true, true>), grid_lut);
-        else if (packed) PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, true, false>), grid_lut);
-        else if (box) PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, false, true>), grid_lut);
-        else PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, false, false>), grid_lut);
+        if (fast) PANO_LAUNCH_K1(warp_tiles_lut_kernel<0>, grid_lut);
+        else PANO_LAUNCH_K1(warp_tiles_lut_checked_kernel<0>, grid_lut);
     }
     else {
 #ifdef PANO_DIAG

@@ -18,27 +18,29 @@ struct FrontEndDev {
 };
 
 // one camera's slice of the fused warp launch (K1)
-struct WarpCam {
+struct alignas(64) WarpCam {
+    // --- the 64 bytes the table form of K1 needs, together so that a wave fetches them with one scalar load
     const uint8_t* src;   // BGR8 interleaved frame
+    void* dst;            // pipeline: plane B of the level-0 tile (planar u8); stage warp: uint8x3 image
+    const uint2* lutc;    // packed remap table, 8 bytes per 4-pixel group (see pack_warp_lut_kernel)
+    const int4* box;      // per 64x16-pixel workgroup: its source box {xmin, ymin, rows<<8 | chunks, ceil(2^16/chunks)}
+    int tw, th;           // tile width/height in pixels
     int src_w, src_h;
     int src_stride;       // bytes
+    int dst_pitch;        // bytes per row
+    int dst_plane;        // pipeline: bytes between the B, G, R planes
+    int lutc_pitch;       // groups per row = lut_pitch / 4
+    // --- everything else
+    // static remap table (frames up to 2048 x 2048): one dword per tile pixel, see build_warp_lut_kernel
+    const uint32_t* lut;  // dense form, read where the packed form escapes; nullptr -> project on the fly
+    int lut_pitch;        // dwords per row of lut (multiple of 8)
+    const float* gain;    // [gh][gw] block gains (BlocksGainCompensator::apply) or nullptr
     float m[9];           // k_rinv = K * R^-1 (Projector::k_rinv)
     const float2* colA;   // [tw] {sin(u/s), cos(u/s)} with the REFLECT border of feed() folded in
     const float2* rowB;   // [th] {sin(pi - v/s) | 1, cos(pi - v/s) | v/s}
-    void* dst;            // pipeline: plane B of the level-0 tile (planar u8); stage warp: uint8x3 image
-    int tw, th;           // tile width/height in pixels
-    int dst_pitch;        // bytes per row
-    int dst_plane;        // pipeline: bytes between the B, G, R planes
-    // optional exposure gain (BlocksGainCompensator::apply): bilinear resize of a block map on the fly
-    // static remap table (frames up to 2048 x 2048): one dword per tile pixel, see build_warp_lut_kernel
-    const uint32_t* lut;  // nullptr -> project on the fly
-    int lut_pitch;        // dwords per row (multiple of 4)
-    const uint2* lutc;    // packed table, 8 bytes per 4-pixel group (see pack_warp_lut_kernel); escapes read lut
-    int lutc_pitch;       // groups per row = lut_pitch / 4
-    const int4* box;      // per 64x16-pixel workgroup: {xmin, ymin, rows<<8 | chunks per row, ceil(2^16/chunks)}; rows 0 = global taps
     const FrontEndDev* fe; // nullptr, or the undistort front end: src is then the RAW frame (src_w x src_h raw)
     int out_w, out_h;     // the stitcher's frame size (mask warp inside test); == src_w x src_h without a front end
-    const float* gain;    // [gh][gw] block gains or nullptr
+    // optional exposure gain: bilinear resize of the block map on the fly
     const int2* gcol;     // [tw] {sx, sx1}   (REFLECT folded like colA)
     const float2* gcolw;  // [tw] {1-fx, fx}
     const int2* grow;     // [th] {sy0, sy1}
@@ -100,7 +102,7 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
 void launch_build_warp_lut(const WarpCam& c, uint32_t* lut, int lut_pitch, hipStream_t s);
 void launch_build_warp_boxes(const uint32_t* lut, int lut_pitch, int tw, int th, int sw, int sh, int4* boxes,
                              unsigned* fallback, hipStream_t s);
-void launch_pack_warp_lut(const uint32_t* lut, int lut_pitch, int th, uint2* lutc, int lutc_pitch, unsigned* escaped,
+void launch_pack_warp_lut(const uint32_t* lut, int lut_pitch, int tw, int th, uint2* lutc, int lutc_pitch, uint32_t* flags,
                           hipStream_t s);
 // stage entry: plain RotationWarper::warp to an 8UC3 image
 void launch_warp_image(const WarpCam& c, hipStream_t s);

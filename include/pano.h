@@ -212,13 +212,11 @@ pano_status pano_get_stage_stats(pano_ctx* ctx, double total_ms[PANO_NUM_STAGES]
  * in registers downstream) */
 pano_status pano_get_warp_bytes(const pano_ctx* ctx, uint64_t* src_bytes, uint64_t* dst_bytes);
 /* the warp's static remap table (the constant part of cv::detail::RotationWarper::buildMaps + cv::remap's index
- * arithmetic, ocvstitcher.hpp:1163): bytes one compose reads from it (16 per 4-pixel group).  The other numbers
- * describe the optional forms of the kernel (environment PANO_K1_FORM=packed|box|packed+box at pano_prepare, both
- * measured slower than the default on MI355X): groups stored packed (8 bytes) vs. escaped to the dense form
- * (8 + 16 bytes), and 64x16-pixel workgroups that stage their source box in LDS vs. tap global memory.
- * Zeros when the warp projects on the fly. */
-pano_status pano_get_warp_table_stats(const pano_ctx* ctx, uint64_t* table_bytes, uint64_t* groups, uint64_t* escaped,
-                                      uint64_t* blocks, uint64_t* blocks_global);
+ * arithmetic, ocvstitcher.hpp:1163): bytes one compose reads from it (2 per tile pixel in the packed form, 4 in the
+ * dense form), the number of 64x16-pixel workgroups of the warp kernel, and how many of them hold pixels the packed
+ * form cannot express (a BORDER_REFLECT fold inside a 4-pixel group, taps next to the last bytes of the frame) and
+ * read the dense form with the per-pixel checked body.  Zeros when the warp projects on the fly. */
+pano_status pano_get_warp_table_stats(const pano_ctx* ctx, uint64_t* table_bytes, uint64_t* blocks, uint64_t* blocks_checked);
 
 /* ---- stage inspection (parity tests) ------------------------------------------------------- */
 /* Gaussian level `level` of camera i's bordered tile, int16 x3 interleaved, tight rows */
