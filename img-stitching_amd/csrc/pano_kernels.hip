@@ -588,6 +588,9 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_checked_kernel(WarpParams 
 //   * the texture-address unit: a 64-lane gather costs the same ~19 cycles per CU whether it fetches 1, 2, 3 or
 //     4 dwords per lane, and eight tap gathers per wave (2 rows x 4 pixels) were 16 of the kernel's 33 us;
 //   * VALU issue: 223 instructions per wave kept the vector ALUs 70 % busy.
+// Tried on top of this and rejected: walking 4 patches per workgroup with the next box loaded straight into a second
+// LDS buffer (global_load_lds_dwordx4) while the current one is computed - exact, 35 us instead of 31 (two buffers
+// and 89 VGPRs leave 5 waves per SIMD); 8-byte ds reads at odd addresses instead of 3 dwords + v_alignbyte - 55 us.
 // So the taps do not come from global memory: the static table fixes the set of frame bytes a workgroup touches (its
 // source box, see build_warp_boxes_kernel); the workgroup copies that box into LDS with coalesced 16-byte loads -
 // 1 to 2 gathers per wave instead of 8, issued together with the table load - and reads the taps from LDS.
@@ -650,7 +653,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     const bool active = x0 < tw && y < th;
     // plain (cached) loads and stores: non-temporal ones for the streamed table and tile measured 15 % slower
     u32x2 e = u32x2{0u, 0u};
-    if (active) e = lutc[(unsigned)y * lutc_pitch + (unsigned)(x0 >> 2)];
+    if (active)  // 32-bit byte offset: scalar base + vector offset addressing, no 64-bit multiply
+        e = *reinterpret_cast<const u32x2 PANO_GLOBAL*>((const uint8_t PANO_GLOBAL*)lutc + (((unsigned)y * lutc_pitch + (unsigned)(x0 >> 2)) << 3));
     if (ABL == 6 || ABL == 17) e = u32x2{(unsigned)((x0 * 7 / 8) * 32 + 5) | ((unsigned)((y * 7 / 8) * 32 + 9) << 16), 32u};
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bb) : : "memory");  // bb is only valid past this point
     if (ABL == 12 || ABL == 6 || ABL == 17) bb.z = 0;  // diagnostic: global taps everywhere
@@ -661,26 +665,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     const unsigned og = (unsigned)bb.y * stride + 3u * (unsigned)bb.x + lo16;  // from the 16-byte boundary below src
     const unsigned ph = og & 15u;
     if (bh) {
+        // chunk k = tid + 256 * it -> (row r = k / cpr, column ci = k % cpr); whole iterations a wave does not reach
+        // are skipped by a scalar branch, the surplus lanes of its last one re-read the last chunk (no predication)
         const int total = bh * cpr;
+        const int wave0 = tid & ~63;
+        const uint8_t PANO_GLOBAL* const srca = (src - lo16) + (og - ph);  // 16-byte aligned
         u32x4 chunk[kBoxIters];
+        unsigned loff[kBoxIters];
 #pragma unroll
         for (int it = 0; it < kBoxIters; it++) {
-            const int k = tid + 256 * it;
-            chunk[it] = u32x4{0u, 0u, 0u, 0u};
-            if (k < total) {
-                const unsigned r = (unsigned)(k * bb.w) >> 16, ci = (unsigned)k - r * (unsigned)cpr;
-                chunk[it] = *reinterpret_cast<const u32x4 PANO_GLOBAL*>((src - lo16) + (og - ph + r * stride + ci * 16u));
+            if (wave0 + 256 * it < total) {
+                const unsigned k = (unsigned)min(tid + 256 * it, total - 1);
+                const unsigned r = __umul24(k, (unsigned)bb.w) >> 16, ci = k - __umul24(r, (unsigned)cpr);
+                chunk[it] = *reinterpret_cast<const u32x4 PANO_GLOBAL*>(srca + (__umul24(r, stride) + ci * 16u));
+                loff[it] = __umul24(r, lpitch) + ci * 16u;
             }
         }
-        u32x4* sb4 = reinterpret_cast<u32x4*>(sbox);
+        uint8_t* sb1 = reinterpret_cast<uint8_t*>(sbox);
 #pragma unroll
-        for (int it = 0; it < kBoxIters; it++) {
-            const int k = tid + 256 * it;
-            if (k < total) {
-                const unsigned r = (unsigned)(k * bb.w) >> 16, ci = (unsigned)k - r * (unsigned)cpr;
-                sb4[r * (unsigned)(cpr + 1) + ci] = chunk[it];
-            }
-        }
+        for (int it = 0; it < kBoxIters; it++)
+            if (wave0 + 256 * it < total) *reinterpret_cast<u32x4*>(sb1 + loff[it]) = chunk[it];
         __syncthreads();
     }
     if (!active) return;
