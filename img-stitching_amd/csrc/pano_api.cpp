@@ -82,6 +82,11 @@ struct pano_ctx {
 
     PyrParams pyr{};
     CanvasParams cv{};
+    // frame slots (pano_set_frame_slots): extra sets of the per-frame buffers - pyramid slots and blend canvas - so
+    // that several frames can be in flight on several streams.  Slot 0 is pyr_base / canvas[] above.
+    int nslots = 1, cur_slot = 0;
+    char* slot_pyr[PANO_MAX_FRAME_SLOTS] = {};
+    int16_t* slot_canvas[PANO_MAX_FRAME_SLOTS][kMaxLevels] = {};
 
     // host-buffer entry point staging
     uint8_t* stage_in[kMaxCams] = {};
@@ -175,6 +180,21 @@ void drop_graphs(pano_ctx* c) {
 
 void free_device(pano_ctx* c) {
     drop_graphs(c);
+    // slot 0 owns what pyr_base / canvas[] were allocated as; the current slot may be another one
+    if (c->nslots > 1) {
+        c->pyr_base = c->slot_pyr[0];
+        for (int l = 0; l < kMaxLevels; l++) c->canvas[l] = c->slot_canvas[0][l];
+        for (int k = 1; k < c->nslots; k++) {
+            dfree(c->slot_pyr[k]);
+            for (int l = 0; l < kMaxLevels; l++) dfree(c->slot_canvas[k][l]);
+        }
+    }
+    for (int k = 0; k < PANO_MAX_FRAME_SLOTS; k++) {
+        c->slot_pyr[k] = nullptr;
+        for (int l = 0; l < kMaxLevels; l++) c->slot_canvas[k][l] = nullptr;
+    }
+    c->nslots = 1;
+    c->cur_slot = 0;
     for (int i = 0; i < kMaxCams; i++) {
         dfree(c->colA[i]); dfree(c->rowB[i]); dfree(c->colA_roi[i]); dfree(c->rowB_roi[i]);
         dfree(c->mask[i]); dfree(c->gain[i]); dfree(c->mask0[i]); dfree(c->lut[i]); dfree(c->lutc[i]); dfree(c->box[i]); dfree(c->k1_flags[i]); dfree(c->d_fe[i]);
@@ -330,6 +350,8 @@ pano_status ensure_weights(pano_ctx* c, hipStream_t s) {
     for (int l = 0; l <= P.bands; l++)
         if (c->cv.fast[l]) launch_build_owner(c->pyr, c->cv, l, c->owner[l], s);
     HIP_TRY(c, hipGetLastError());
+    // one-time: later frames may run on other streams (frame slots) and must find the weights complete
+    HIP_TRY(c, hipStreamSynchronize(s));
     c->weights_dirty = false;
     return PANO_OK;
 }
@@ -748,6 +770,57 @@ pano_status pano_prepare(pano_ctx* c) {
     for (auto& sl : c->ring)
         for (auto& e : sl.e) HIP_TRY(c, hipEventCreate(&e));
     c->ev_valid = true;
+    return PANO_OK;
+}
+
+// point the kernel parameter blocks at the buffers of frame slot k
+static void bind_slot(pano_ctx* c, int k) {
+    c->cur_slot = k;
+    c->pyr_base = c->slot_pyr[k];
+    for (int l = 0; l < c->levels; l++) {
+        c->canvas[l] = c->slot_canvas[k][l];
+        c->cv.img[l] = c->canvas[l];
+    }
+    for (int i = 0; i < c->plan.n; i++)
+        for (int l = 0; l < c->levels; l++)
+            c->pyr.cam[i].lvl[l] = (uint8_t*)(c->pyr_base + (size_t)i * c->slot_bytes + c->lvl_off[i][l]);
+}
+
+pano_status pano_set_frame_slots(pano_ctx* c, int n) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (n < 1 || n > PANO_MAX_FRAME_SLOTS) return fail(c, PANO_EINVAL, "frame slots: 1 .. PANO_MAX_FRAME_SLOTS");
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (c->nslots == 1) {  // slot 0 = the buffers pano_prepare allocated
+        c->slot_pyr[0] = c->pyr_base;
+        for (int l = 0; l < kMaxLevels; l++) c->slot_canvas[0][l] = c->canvas[l];
+    }
+    bind_slot(c, 0);
+    for (int k = n; k < c->nslots; k++) {  // shrink
+        dfree(c->slot_pyr[k]);
+        for (int l = 0; l < kMaxLevels; l++) dfree(c->slot_canvas[k][l]);
+    }
+    const int have = std::min(c->nslots, n);
+    c->nslots = have;
+    for (int k = have; k < n; k++) {  // grow
+        HIP_TRY(c, hipMalloc((void**)&c->slot_pyr[k], c->slot_bytes * c->plan.n + 256));
+        c->nslots = k + 1;  // free_device releases what exists if a later allocation fails
+        HIP_TRY(c, hipMemset(c->slot_pyr[k], 0, c->slot_bytes * c->plan.n));
+        for (int l = 1; l < c->levels; l++)
+            HIP_TRY(c, hipMalloc((void**)&c->slot_canvas[k][l], (size_t)c->cv.cplane[l] * 3 * sizeof(int16_t) + 256));
+    }
+    drop_graphs(c);
+    return PANO_OK;
+}
+
+pano_status pano_select_frame_slot(pano_ctx* c, int k) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (k < 0 || k >= c->nslots) return fail(c, PANO_EINVAL, "frame slot out of range");
+    if (c->nslots > 1 && k != c->cur_slot) {
+        bind_slot(c, k);
+        drop_graphs(c);  // captured graphs hold the pointers of the slot they were captured on
+    }
     return PANO_OK;
 }
 

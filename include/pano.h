@@ -162,6 +162,20 @@ pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b,
                               const uint8_t* const* d_frames_b, const size_t* strides_b, uint8_t* d_out_b, size_t out_stride_b,
                               void* hip_stream);
 
+/* ---- frames in flight --------------------------------------------------------------------------------------
+ * The reference's loop composes one frame at a time (src/master.cpp:302-411: pop, process(), show).  One frame is a
+ * chain of ten dependent launches, several of them far too small to fill the GPU, so the GPU idles between them.
+ * Frame slots are extra sets of the per-frame buffers (camera pyramids, blend canvas; everything static - remap
+ * tables, masks, weight pyramids - is shared): with n slots, frame k is composed into slot k % n on stream k % n and
+ * the chains of consecutive frames overlap.  Results per frame are unchanged.
+ *   pano_set_frame_slots(ctx, n)    after pano_prepare; 1 <= n <= PANO_MAX_FRAME_SLOTS; synchronises the device
+ *   pano_select_frame_slot(ctx, k)  the slot the following feed / blend / compose calls work in (a host-side switch)
+ * The caller keeps one stream per slot and does not reuse a slot before its previous frame is done (stream order
+ * guarantees that when slot k always runs on stream k).  pano_compose_host and the pano_stream_* calls use slot 0. */
+#define PANO_MAX_FRAME_SLOTS 4
+pano_status pano_set_frame_slots(pano_ctx* ctx, int n);
+pano_status pano_select_frame_slot(pano_ctx* ctx, int k);
+
 /* ---- streaming form for a capture loop (BASELINE config 5: frames arrive in host memory at camera rate) ------
  * The reference's loop (src/master.cpp:302-411) pops one cv::Mat per camera from the capture queues and calls
  * process().  Here the library owns PINNED host buffers in PANO_STREAM_SLOTS slots: the producer writes camera i's

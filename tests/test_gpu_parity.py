@@ -532,3 +532,44 @@ def test_cut_alignment_on_vector_path(pano, po, rig_r):
         ctx.set_cut(cut)
         got = ctx.compose_host(frames)
         assert np.array_equal(got, full[cut[1]:cut[1] + cut[3], cut[0]:cut[0] + cut[2]]), cut
+
+
+def test_frame_slots_overlapping_frames(pano, po, torch):
+    """pano_set_frame_slots / pano_select_frame_slot: frames composed into different slots on different streams
+    (the launch chains of consecutive frames overlap on the GPU) give the same bytes as one frame at a time"""
+    d = c2_group(w=640, h=360, f=334.0)
+    ctx = make_ctx(pano, d, 0, num_bands=4)
+    ctx.build_masks_voronoi()
+    n, nslot = d["n"], 3
+    frames = [[synth_frame(d["w"], d["h"], 500 + 10 * k + i) for i in range(n)] for k in range(6)]
+    frames_d = [[torch.from_numpy(f).cuda() for f in fr] for fr in frames]
+    ow, oh = ctx.output_size()
+    s0 = torch.cuda.current_stream().cuda_stream
+    ref = []
+    for fr in frames_d:  # one frame at a time, slot 0
+        out = torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda")
+        ctx.compose([t.data_ptr() for t in fr], [d["w"] * 3] * n, out.data_ptr(), ow * 3, s0)
+        torch.cuda.synchronize()
+        ref.append(out.cpu().numpy())
+    masks = [ctx.get_mask(i) for i in range(n)]
+    assert np.array_equal(ref[0], po.compose(frames[0], d["K"], d["R"], d["scale"], masks, 4)[0])
+    ctx.set_frame_slots(nslot)
+    streams = [torch.cuda.Stream() for _ in range(nslot)]
+    outs = [torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in frames]
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for k, fr in enumerate(frames_d):
+            ctx.select_frame_slot(k % nslot)
+            ctx.compose([t.data_ptr() for t in fr], [d["w"] * 3] * n, outs[k].data_ptr(), ow * 3, streams[k % nslot].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(len(frames)):
+            assert np.array_equal(outs[k].cpu().numpy(), ref[k]), (rep, k)
+            outs[k].zero_()
+    # back to one slot
+    ctx.set_frame_slots(1)
+    out = torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda")
+    ctx.compose([t.data_ptr() for t in frames_d[1]], [d["w"] * 3] * n, out.data_ptr(), ow * 3, s0)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref[1])
+    with pytest.raises(Exception):
+        ctx.select_frame_slot(2)
