@@ -13,9 +13,16 @@ spherical warp + 5-band multi-band blend per group, fixed K/R (imx390-derived f=
   fixed -> "scaling": "strong".  (`replicas_panoramas_per_s` reports, as extra information, the same ranks each
   composing their own rig with no exchange.)
 
+At N = 1 the K steps are dealt round-robin over --frames-in-flight frame slots / streams (default 2): one frame is a
+chain of ten dependent launches, several too small to fill the GPU, and the chains of consecutive frames overlap the
+way they do behind a capture loop.  --frames-in-flight 1 composes one frame at a time.
+
 Prints ONE JSON line (rank 0).  `roofline` is the warp kernel (K1): algorithmic bytes
-sum_cams(W*H*3 read once + Wt*Ht*6 written once) per launch / mean launch duration from HIP events
-recorded on the launch stream inside the timed region.  `cpu_baseline` is the CPU oracle
+sum_cams(W*H*3 read once + Wt*Ht*3 written once) per launch / mean launch duration from the kernel's own dispatch
+events.  A roofline fraction describes the kernel, so it is taken over K steps composed one frame at a time, where a
+launch has the GPU to itself (the figure rocprofv3 reports for `bench.py --frames-in-flight 1`, profiles/);
+`roofline.in_timed_region` is the same measurement over K steps with the frames in flight of the timed region, where a
+launch shares the GPU with the other frame's kernels and takes correspondingly longer.  `cpu_baseline` is the CPU oracle
 (OpenCV-3.4-semantics restatement, kind "port") on a bounded sample of the same workload.
 """
 import argparse
@@ -50,6 +57,10 @@ def main():
     ap.add_argument("--bands", type=int, default=5)
     ap.add_argument("--one-stream", action="store_true", help="both groups on one stream (no overlap)")
     ap.add_argument("--force-sharded-path", action="store_true", help="diagnostic: run the N>1 step code at N=1")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="N=1: frame slots / streams the K steps are dealt over round-robin (1 = one frame at a time)")
+    ap.add_argument("--no-isolated-pass", action="store_true",
+                    help="N=1: skip the K steps composed one frame at a time (kernel durations without overlap)")
     args = ap.parse_args()
 
     import torch
@@ -97,16 +108,34 @@ def main():
         base, slot = ctx.pyramid_slots()
         slot_views.append((torch.as_tensor(DevView(base, slot * NC), device="cuda"), slot))
 
-    def step_single():
+    # frames in flight (N = 1): one frame is a chain of ten dependent launches, several too small to fill the GPU.
+    # With F frame slots (per-frame buffers replicated, everything static shared) step k runs in slot k % F on
+    # stream k % F and the chains of consecutive frames overlap - what a capture loop feeding frames back to back does.
+    F = max(1, min(args.frames_in_flight, pano.MAX_FRAME_SLOTS)) if world == 1 and not args.force_sharded_path else 1
+    flight = [stream]
+    outs_f = [outs]
+    if F > 1:
+        for c in ctxs:
+            c.set_frame_slots(F)
+        flight_streams = [torch.cuda.Stream() for _ in range(F)]
+        flight = [st.cuda_stream for st in flight_streams]
+        outs_f = [outs] + [[torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in range(NG)] for _ in range(F - 1)]
+
+    def step_single(k=0, slots=None):
         # both stitchers of the rig in one launch sequence (the reference: two threads, src/master.cpp:314-318)
-        ctxs[0].compose_pair(ctxs[1], fptr[0], strides, outs[0].data_ptr(), ow * 3, fptr[1], strides, outs[1].data_ptr(),
-                             ow * 3, stream)
+        f = k % (slots or F)
+        if F > 1:
+            ctxs[0].select_frame_slot(f)
+            ctxs[1].select_frame_slot(f)
+        o = outs_f[f]
+        ctxs[0].compose_pair(ctxs[1], fptr[0], strides, o[0].data_ptr(), ow * 3, fptr[1], strides, o[1].data_ptr(),
+                             ow * 3, flight[f] if slots is None else stream)
 
     def step_serial():
         for grp in range(NG):
             ctxs[grp].compose(fptr[grp], strides, outs[grp].data_ptr(), ow * 3, stream)
 
-    def step_sharded():
+    def step_sharded(k=0):
         for grp, plan in enumerate(plans):
             if plan["bits"]:
                 ctxs[grp].feed_cameras(plan["bits"], fptr[grp], strides, stream)
@@ -123,15 +152,15 @@ def main():
     step = step_single if (world == 1 and not args.force_sharded_path) else step_sharded
     assert int(slot_views[0][0].numel()) == slot_views[0][1] * NC
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -143,10 +172,22 @@ def main():
         c.set_profiling(True)
         c.stage_stats(reset=True)
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     torch.cuda.synchronize()
     dt_profiled = time.perf_counter() - t1
+    stats_timed = None
+    if world == 1:
+        stats_timed = [c.stage_stats(reset=True) for c in ctxs]
+    # optional: the same K steps one frame at a time on one stream (kernel durations without overlap)
+    stats_iso, dt_iso = None, None
+    if world == 1 and F > 1 and not args.no_isolated_pass:
+        ti = time.perf_counter()
+        for k in range(args.steps):
+            step_single(k, slots=1)
+        torch.cuda.synchronize()
+        dt_iso = time.perf_counter() - ti
+        stats_iso = [c.stage_stats(reset=True) for c in ctxs]
     # N > 1 only, extra information: the same K steps with every rank composing its OWN whole rig (replicas, no
     # exchange).  One MI355X composes a panorama in ~0.16 ms, less than it takes to move one half panorama (11.6 MB)
     # over an xGMI link, so sharding ONE rig over GPUs cannot raise throughput; independent rigs scale linearly.
@@ -158,8 +199,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
             tr = time.perf_counter()
-            for _ in range(args.steps):
-                step_single()
+            for k in range(args.steps):
+                step_single(k)
             torch.cuda.synchronize()
             trt = torch.tensor([time.perf_counter() - tr], dtype=torch.float64, device="cuda")
             dist.all_reduce(trt, op=dist.ReduceOp.MAX)
@@ -177,16 +218,21 @@ def main():
         # per K1 launch: at N=1 one launch warps all 8 cameras (both stitchers), when sharded one group of 4
         launches_per_step = 1 if world == 1 and not args.force_sharded_path else NG
         alg_bytes = (src_b + dst_b) * (NG // launches_per_step)
-        roofline = None
-        stage_ms, stage_n = [0.0] * 3, [0] * 3
-        for c in ctxs:
-            ms, n = c.stage_stats(reset=True)
-            stage_ms = [a + b for a, b in zip(stage_ms, ms)]
-            stage_n = [a + b for a, b in zip(stage_n, n)]
-        warp_ms, warp_launches = stage_ms[0], stage_n[0]
-        if world == 1 and warp_launches:
-            avg_ms = warp_ms / warp_launches
+        def fold(stats):
+            ms3, n3 = [0.0] * 3, [0] * 3
+            for ms, n in stats:
+                ms3 = [a + b for a, b in zip(ms3, ms)]
+                n3 = [a + b for a, b in zip(n3, n)]
+            return ms3, n3
+
+        def k1_roofline(ms3, n3):
+            avg_ms = ms3[0] / n3[0]
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            return {"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_launch_us": round(avg_ms * 1e3, 2)}
+
+        roofline = None
+        stage_ms, stage_n = fold(stats_timed if stats_timed is not None else [c.stage_stats(reset=True) for c in ctxs])
+        if world == 1 and stage_n[0]:
             traffic = None
             tp = os.path.join(ROOT, "profiles", "warp_traffic.json")
             if os.path.exists(tp):
@@ -194,10 +240,24 @@ def main():
                     traffic = json.load(open(tp)).get("hbm_bytes_per_launch_8cam")
                 except Exception:
                     traffic = None
-            roofline = {"kernel": "warp_tiles_lut_kernel", "bound": "hbm", "achieved": round(achieved, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            # the kernel's roofline fraction is taken where its launches have the GPU to themselves (one frame at a
+            # time); what a launch takes while it shares the GPU with the other frame in flight is reported beside it
+            timed = k1_roofline(stage_ms, stage_n)
+            alone, alone_stage, alone_rate = timed, None, None
+            if stats_iso is not None:
+                ims, inn = fold(stats_iso)
+                alone = k1_roofline(ims, inn)
+                alone_stage = {k: round(ims[i] / max(inn[i], 1) * 1e3, 2) for i, k in enumerate(("warp", "pyramid", "blend"))}
+                alone_rate = round(args.steps / dt_iso, 1)
+            roofline = {"kernel": "warp_tiles_lut_kernel", "bound": "hbm", "achieved": alone["achieved"],
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alone["frac"],
                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                        "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": launches_per_step}
+                        "avg_launch_us": alone["avg_launch_us"], "launches_per_step": launches_per_step,
+                        "measured": "K steps, one frame at a time, dispatch events of the kernel" if stats_iso is not None
+                                    else "K steps under the conditions of the timed region, dispatch events of the kernel",
+                        "in_timed_region": dict(timed, frames_in_flight=F),
+                        "one_frame_at_a_time_panoramas_per_s": alone_rate,
+                        "one_frame_at_a_time_stage_us": alone_stage}
         result = {
             "metric": "stitched panoramas/sec (8x1080p->pano)", "value": round(args.steps / dt, 2),
             "unit": "panoramas/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -206,7 +266,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C2: 8x1920x1080 BGR8 -> 2 groups x 4 cameras, spherical warp + %d-band "
                                    "multi-band blend, Voronoi seams, pano 2 x %dx%d" % (args.bands, ow, oh),
-                       "parallelism": "single GPU" if world == 1 else "cameras sharded %d/rank, RCCL gather to rank 0" % per_rank},
+                       "parallelism": ("single GPU, %d frames in flight" % F) if world == 1 else "cameras sharded %d/rank, RCCL gather to rank 0" % per_rank},
             "roofline": roofline,
             "ms_per_step_event_pass": round(dt_profiled / args.steps * 1e3, 4),
             "replicas_panoramas_per_s": replicas_rate,
@@ -216,6 +276,9 @@ def main():
         if world == 1:
             # the reference-shaped entry (host cv::Mat in, host cv::Mat out; H2D + compose + D2H, synchronous):
             # reported for DESIGN.md, never the `value`
+            for c in ctxs:
+                c.set_profiling(False)
+                c.select_frame_slot(0)
             hframes = [[f.cpu().numpy() for f in fr] for fr in frames]
             for grp in range(NG):
                 ctxs[grp].compose_host(hframes[grp])

@@ -80,6 +80,8 @@ def load_library():
 
 
 # every symbol include/pano.h declares (checked by tests/test_abi.py against the header text)
+MAX_FRAME_SLOTS = 4  # PANO_MAX_FRAME_SLOTS
+
 EXPORTS = [
     "pano_create", "pano_destroy", "pano_last_error", "pano_version", "pano_set_camera",
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
