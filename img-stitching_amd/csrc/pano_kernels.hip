@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(256) void blend_level_kernel(PyrParams P, CanvasSet
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         // W == 1.0f: (short)(n / 1.00001f) == n - sign(n), see the vector kernel
-        if (W == 1.0f) v[k] = acc[k] - (acc[k] > 0) + (acc[k] < 0);
+        if (W == 1.0f) v[k] = acc[k] - max(min(acc[k], 1), -1);
         else v[k] = (int16_t)(int)((float)acc[k] / den);
         if (l < C.bands) v[k] = sat16i(v[k] + cup[k]);
     }
@@ -1298,8 +1298,8 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
                 for (int k = 0; k < 4; k++) {
                     const int l0 = (int)((g0[pl] >> (8 * k)) & 0xffu) - up[0][k];  // |lap| <= 255: no saturation possible
                     const int l1 = (int)((g1[pl] >> (8 * k)) & 0xffu) - up[1][k];
-                    v[pl][0][k] = l0 - (l0 > 0) + (l0 < 0);
-                    v[pl][1][k] = l1 - (l1 > 0) + (l1 < 0);
+                    v[pl][0][k] = l0 - max(min(l0, 1), -1);  // l - sign(l): v_med3_i32 + v_sub
+                    v[pl][1][k] = l1 - max(min(l1, 1), -1);
                 }
             }
         } else {
@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
             for (int k = 0; k < 4; k++) {
                 const int a = acc[pl][r][k];
                 int nrm;
-                if (unitW) nrm = a - (a > 0) + (a < 0);
+                if (unitW) nrm = a - max(min(a, 1), -1);
                 else nrm = (int16_t)(int)((float)a / (W[r][k] + 1e-5f));
                 v[pl][r][k] = l < C.bands ? sat16i(nrm + up[r][k]) : nrm;
             }
@@ -1564,7 +1564,7 @@ __global__ __launch_bounds__(256) void norm_small_kernel(PyrParams P, CanvasSet 
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         int v;
-        if (W == 1.0f) v = acc[k] - (acc[k] > 0) + (acc[k] < 0);
+        if (W == 1.0f) v = acc[k] - max(min(acc[k], 1), -1);
         else v = (int16_t)(int)((float)acc[k] / (W + 1e-5f));
         C.img[l][(size_t)k * C.cplane[l] + (size_t)Y * C.cpitch[l] + X] = (int16_t)v;
     }
