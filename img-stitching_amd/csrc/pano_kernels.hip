@@ -885,8 +885,11 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam
     const int sw = c.w0 >> l, sh = c.h0 >> l;
     const int dw = sw >> 1, dh = sh >> 1;
     const int t = blockIdx.x * 64 + threadIdx.x;      // group of 4 output columns
-    const int y0 = (blockIdx.y * 4 + threadIdx.y) * 2;  // pair of output rows
-    if (t * 4 >= dw || y0 >= dh) return;
+    // a wave is one threadIdx.y: tell the compiler, and the row indices, the REFLECT_101 of the seven source rows and
+    // their addresses are scalar work (a quarter of this kernel's vector instructions otherwise)
+    const int y0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * 2;  // pair of output rows
+    if (y0 >= dh) return;
+    if (t * 4 >= dw) return;
     const uint8_t* __restrict__ src = c.lvl[l] + (size_t)pl * c.plane[l];
     const int sp = c.pitch[l];
     // Every lane does seven 16-byte loads (columns 8t-4 .. 8t+11; lane 0 loads columns 0..15 and shifts).
