@@ -128,6 +128,7 @@ struct pano_ctx {
         size_t strides[kMaxCams];
         uint8_t* out;
         size_t out_stride;
+        int slot;  // the frame slot whose buffers the captured launches point at
         hipGraph_t graph;
         hipGraphExec_t exec;
     };
@@ -817,10 +818,7 @@ pano_status pano_select_frame_slot(pano_ctx* c, int k) {
     pano_status st = check_compute(c);
     if (st != PANO_OK) return st;
     if (k < 0 || k >= c->nslots) return fail(c, PANO_EINVAL, "frame slot out of range");
-    if (c->nslots > 1 && k != c->cur_slot) {
-        bind_slot(c, k);
-        drop_graphs(c);  // captured graphs hold the pointers of the slot they were captured on
-    }
+    if (c->nslots > 1 && k != c->cur_slot) bind_slot(c, k);  // captured graphs are keyed by slot
     return PANO_OK;
 }
 
@@ -1137,7 +1135,7 @@ pano_status pano_compose(pano_ctx* c, const uint8_t* const* d_frames, const size
     // caller buffers (a capture needs a real stream; the legacy null stream and profiled runs launch directly).
     if (c->use_graph && !c->profiling && s != nullptr && d_frames && strides && d_out) {
         for (auto& g : c->graphs) {
-            bool same = g.out == d_out && g.out_stride == out_stride;
+            bool same = g.out == d_out && g.out_stride == out_stride && g.slot == c->cur_slot;
             for (int i = 0; i < n && same; i++) same = g.frames[i] == d_frames[i] && g.strides[i] == strides[i];
             if (same) {
                 HIP_TRY(c, hipGraphLaunch(g.exec, s));
@@ -1151,6 +1149,7 @@ pano_status pano_compose(pano_ctx* c, const uint8_t* const* d_frames, const size
         }
         g.out = d_out;
         g.out_stride = out_stride;
+        g.slot = c->cur_slot;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             pano_status st1 = pano_feed_cameras(c, (1u << n) - 1u, d_frames, strides, stream);
             pano_status st2 = st1 == PANO_OK ? pano_blend(c, d_out, out_stride, stream) : st1;

@@ -131,6 +131,15 @@ def test_graph_replay(pano, po, torch, c1, monkeypatch):
     ctx.compose([t.data_ptr() for t in d], [480 * 3] * 4, out.data_ptr(), 1333 * 3, st.cuda_stream)
     st.synchronize()
     assert np.array_equal(out.cpu().numpy(), want2)
+    # graphs are keyed by frame slot: the same caller buffers composed in another slot capture their own graph
+    ctx.set_frame_slots(2)
+    for slot in (0, 1, 0, 1):
+        out.zero_()
+        torch.cuda.synchronize()
+        ctx.select_frame_slot(slot)
+        ctx.compose([t.data_ptr() for t in d], [480 * 3] * 4, out.data_ptr(), 1333 * 3, st.cuda_stream)
+        st.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want2), slot
 
 
 def test_on_the_fly_warp_kernel(pano, po, c1, monkeypatch):
