@@ -739,7 +739,10 @@ pano_status pano_prepare(pano_ctx* c) {
         c->cv.img[l] = c->canvas[l];
         // the vector blend kernel needs every tile box of the level on a 4 x 2 grid
         // ... and only pays on big levels: small ones are latency bound and want one pixel per thread
-        static const size_t vec_min_px = getenv("PANO_VEC_MIN_PIXELS") ? (size_t)atol(getenv("PANO_VEC_MIN_PIXELS")) : 600000;
+        // 200 K pixels: on the 1080p rig levels 0..2 run the vector kernel, 3..5 the fused small-level pair.  Measured with
+        // two frames in flight (the GPU is VALU-issue bound there and the small-level kernels spend 3x the instructions
+        // per pixel): 600 K -> 8860, 200 K -> 9200, 50 K -> 9080 panoramas/s
+        static const size_t vec_min_px = getenv("PANO_VEC_MIN_PIXELS") ? (size_t)atol(getenv("PANO_VEC_MIN_PIXELS")) : 200000;
         bool fast = P.bands >= 0 && ((P.canvas.w >> l) % 4 == 0) && ((P.canvas.h >> l) % 2 == 0) &&
                     (size_t)(P.canvas.w >> l) * (P.canvas.h >> l) >= vec_min_px;
         for (int i = 0; i < n && fast; i++) {
