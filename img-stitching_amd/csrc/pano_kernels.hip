@@ -869,14 +869,13 @@ void launch_warp_mask(const WarpCam& c, uint8_t* dst, int dst_stride, hipStream_
 // v_dot4_u32_u8 on byte windows, the vertical pass in registers.  grid.z = camera * 3 + plane.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pyr_down_hrow(const uint4 q, int h[4]) {
-    // q = 16 bytes starting at column 8t-4; the four outputs are centred on columns 8t, 8t+2, 8t+4, 8t+6
-    const unsigned w0 = __builtin_amdgcn_alignbyte(q.y, q.x, 2);  // bytes 2..5
-    const unsigned w2 = __builtin_amdgcn_alignbyte(q.z, q.y, 2);  // bytes 6..9
-    const unsigned K = 0x04060401u;                               // taps 1,4,6,4 (little endian) + the 5th tap
-    h[0] = (int)__builtin_amdgcn_udot4(w0, K, (q.y >> 16) & 0xffu, false);
-    h[1] = (int)__builtin_amdgcn_udot4(q.y, K, q.z & 0xffu, false);
-    h[2] = (int)__builtin_amdgcn_udot4(w2, K, (q.z >> 16) & 0xffu, false);
-    h[3] = (int)__builtin_amdgcn_udot4(q.z, K, q.w & 0xffu, false);
+    // q = 16 bytes starting at column 8t-4; the four outputs are centred on columns 8t, 8t+2, 8t+4, 8t+6, i.e. on
+    // bytes 4, 6, 8, 10 of the window.  Each 5-tap window (1 4 6 4 1) straddles two dwords: two chained dot products
+    // with the taps placed on the right bytes - no realignment, no byte extraction.
+    h[0] = (int)__builtin_amdgcn_udot4(q.y, 0x00010406u, __builtin_amdgcn_udot4(q.x, 0x04010000u, 0u, false), false);  // bytes 2..6
+    h[1] = (int)__builtin_amdgcn_udot4(q.z, 0x00000001u, __builtin_amdgcn_udot4(q.y, 0x04060401u, 0u, false), false);  // bytes 4..8
+    h[2] = (int)__builtin_amdgcn_udot4(q.z, 0x00010406u, __builtin_amdgcn_udot4(q.y, 0x04010000u, 0u, false), false);  // bytes 6..10
+    h[3] = (int)__builtin_amdgcn_udot4(q.w, 0x00000001u, __builtin_amdgcn_udot4(q.z, 0x04060401u, 0u, false), false);  // bytes 8..12
 }
 __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam_bits, int l) {
     const int ci = blockIdx.z / 3, pl = blockIdx.z - ci * 3;
@@ -896,12 +895,12 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam
     // REFLECT_101 at the two row ends touches at most three bytes, patched in registers:
     //   left  (t == 0): columns -2, -1 are columns 2, 1
     //   right (8t+8 == sw, the last group): column sw is column sw-2
-    int acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
+    int acc0[4] = {128, 128, 128, 128}, acc1[4] = {128, 128, 128, 128};  // the rounding term of (v + 128) >> 8
     const int off = t == 0 ? 0 : 8 * t - 4;
     uint4 q[7];
 #pragma unroll
     for (int r = 0; r < 7; r++)
-        q[r] = *reinterpret_cast<const uint4*>(src + (size_t)reflect101_idx(2 * y0 - 2 + r, sh) * sp + off);
+        q[r] = *reinterpret_cast<const uint4*>(src + ((unsigned)(reflect101_idx(2 * y0 - 2 + r, sh) * sp) + (unsigned)off));  // scalar row + lane offset
     if (t == 0) {
 #pragma unroll
         for (int r = 0; r < 7; r++) {
@@ -946,8 +945,9 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam
     unsigned p0 = 0, p1 = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        p0 |= (unsigned)min((acc0[j] + 128) >> 8, 255) << (8 * j);
-        p1 |= (unsigned)min((acc1[j] + 128) >> 8, 255) << (8 * j);
+        // no saturate_cast: the taps sum to 256, so (256 * 255 + 128) >> 8 = 255 is the largest value there is
+        p0 |= (unsigned)(acc0[j] >> 8) << (8 * j);
+        p1 |= (unsigned)(acc1[j] >> 8) << (8 * j);
     }
     *reinterpret_cast<unsigned*>(d) = p0;  // rows are padded to 16 bytes
     if (y0 + 1 < dh) *reinterpret_cast<unsigned*>(d + c.pitch[l + 1]) = p1;
