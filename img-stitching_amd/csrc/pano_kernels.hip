@@ -1117,7 +1117,7 @@ __device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int 
         const unsigned sel = sh0 | (sh1 << 8) | (sh2 << 16) | (sh3 << 24);
         uint2 d[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint2*>(S + (unsigned)(yi[r] * pitch + ab));
+        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint2*>(S + (unsigned)(__mul24(yi[r], pitch) + ab));  // v_mul_lo_u32 is quarter rate
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const unsigned win = __builtin_amdgcn_alignbyte(d[r].y, d[r].x, (unsigned)(base - ab));
@@ -1132,7 +1132,7 @@ __device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int 
         const unsigned selB = (2 * sh2) | ((2 * sh2 + 1) << 8) | ((2 * sh3) << 16) | ((2 * sh3 + 1) << 24);
         uint3 d[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint3*>(S + (unsigned)(yi[r] * pitch + ab));
+        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint3*>(S + (unsigned)(__mul24(yi[r], pitch) + ab));
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const unsigned w0 = __builtin_amdgcn_alignbyte(d[r].y, d[r].x, bs);
@@ -1188,7 +1188,7 @@ __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0
                 uint2 pk;
                 pk.x = ((unsigned)v[pl][r][0] & 0xffffu) | ((unsigned)v[pl][r][1] << 16);
                 pk.y = ((unsigned)v[pl][r][2] & 0xffffu) | ((unsigned)v[pl][r][3] << 16);
-                *reinterpret_cast<uint2*>(C.img[l] + (size_t)pl * C.cplane[l] + (unsigned)((Y0 + r) * C.cpitch[l] + X0)) = pk;
+                *reinterpret_cast<uint2*>(C.img[l] + (size_t)pl * C.cplane[l] + (unsigned)(__mul24(Y0 + r, C.cpitch[l]) + X0)) = pk;
             }
     } else {
         const bool on[2][4] = {{o00, o01, o02, o03}, {o10, o11, o12, o13}};
@@ -1202,7 +1202,7 @@ __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++) b[3 * k + pl] = on[r][k] ? (unsigned)sat8i(v[pl][r][k]) : 0u;
             // signed: a block that starts left of the cut has a negative column offset (its bytes are masked below)
-            uint8_t* d = C.out + (int)((Y - C.cut_y) * C.out_stride + 3 * (X0 - C.cut_x));
+            uint8_t* d = C.out + (int)(__mul24(Y - C.cut_y, C.out_stride) + 3 * (X0 - C.cut_x));
             const bool whole = X0 >= C.cut_x && X0 + 4 <= C.cut_x + C.cut_w;
             if (whole && (((size_t)d) & 3) == 0) {
                 uint3 pk;
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     // Away from the seams a block belongs to exactly one camera with weight 1.0f everywhere (or to none):
     // the static owner map says so in one byte, and the block needs no weights, no float math and no division:
     //   acc = lap, W = 1  =>  norm = lap - sign(lap)  (see below)
-    const unsigned code = C.owner[l][(size_t)(Y0 >> 1) * C.opitch[l] + (X0 >> 2)];
+    const unsigned code = C.owner[l][(unsigned)(__mul24(Y0 >> 1, C.opitch[l]) + (X0 >> 2))];
     const unsigned ucode = __builtin_amdgcn_readfirstlane(code);
     if (ucode != 0xffu && __builtin_amdgcn_ballot_w64(code != ucode) == 0) {
         // the whole wave (a 256 x 2 strip) has one owner: its parameters are scalar, the code is straight-line
@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
             unsigned p[3][3][2];
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) {
-                const uint8_t* g = c.lvl[l] + (size_t)pl * c.plane[l] + (unsigned)(y * c.pitch[l] + x);
+                const uint8_t* g = c.lvl[l] + (size_t)pl * c.plane[l] + (unsigned)(__mul24(y, c.pitch[l]) + x);
                 if (ABL == 3) {  // diagnostic: no level-l tile loads
                     g0[pl] = x * 0x01010101u; g1[pl] = y * 0x01010101u;
                 } else {
