@@ -56,6 +56,14 @@ __device__ __forceinline__ int reflect101_idx(int p, int n) {
     return min(p, n - 1);  // only reached by the out-of-image outputs of a partial last group (values unused)
 }
 
+// n - sign(n): the normalisation where the summed weight is exactly 1.0f (see blend_level_vec_kernel).  Spelled as
+// v_med3_i32 + v_sub: the compiler turns every C spelling of sign() back into two compares and two selects.
+__device__ __forceinline__ int toward_zero_by_one(int n) {
+    int sgn;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(sgn) : "v"(n));
+    return n - sgn;
+}
+
 // Spherical/CylindricalProjector::mapBackward from the separable factors, then the 1/32-pixel
 // quantisation of cv::remap (INTER_BITS = 5)
 __device__ __forceinline__ void map_backward(const float* __restrict__ m, float2 A, float2 B, float& x, float& y) {
@@ -1069,7 +1077,7 @@ __global__ __launch_bounds__(256) void blend_level_kernel(PyrParams P, CanvasSet
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         // W == 1.0f: (short)(n / 1.00001f) == n - sign(n), see the vector kernel
-        if (W == 1.0f) v[k] = acc[k] - max(min(acc[k], 1), -1);
+        if (W == 1.0f) v[k] = toward_zero_by_one(acc[k]);
         else v[k] = (int16_t)(int)((float)acc[k] / den);
         if (l < C.bands) v[k] = sat16i(v[k] + cup[k]);
     }
@@ -1301,8 +1309,8 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
                 for (int k = 0; k < 4; k++) {
                     const int l0 = (int)((g0[pl] >> (8 * k)) & 0xffu) - up[0][k];  // |lap| <= 255: no saturation possible
                     const int l1 = (int)((g1[pl] >> (8 * k)) & 0xffu) - up[1][k];
-                    v[pl][0][k] = l0 - max(min(l0, 1), -1);  // l - sign(l): v_med3_i32 + v_sub
-                    v[pl][1][k] = l1 - max(min(l1, 1), -1);
+                    v[pl][0][k] = toward_zero_by_one(l0);
+                    v[pl][1][k] = toward_zero_by_one(l1);
                 }
             }
         } else {
@@ -1467,7 +1475,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
             for (int k = 0; k < 4; k++) {
                 const int a = acc[pl][r][k];
                 int nrm;
-                if (unitW) nrm = a - max(min(a, 1), -1);
+                if (unitW) nrm = toward_zero_by_one(a);
                 else nrm = (int16_t)(int)((float)a / (W[r][k] + 1e-5f));
                 v[pl][r][k] = l < C.bands ? sat16i(nrm + up[r][k]) : nrm;
             }
@@ -1567,7 +1575,7 @@ __global__ __launch_bounds__(256) void norm_small_kernel(PyrParams P, CanvasSet 
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         int v;
-        if (W == 1.0f) v = acc[k] - max(min(acc[k], 1), -1);
+        if (W == 1.0f) v = toward_zero_by_one(acc[k]);
         else v = (int16_t)(int)((float)acc[k] / (W + 1e-5f));
         C.img[l][(size_t)k * C.cplane[l] + (size_t)Y * C.cpitch[l] + X] = (int16_t)v;
     }
