@@ -1185,7 +1185,8 @@ __device__ __forceinline__ void up_block(const unsigned q[3][2], int up[2][4]) {
 }
 
 // store a finished 4 x 2 block: canvas level (planar int16) or, at level 0, dst_mask + convertTo(8U) + cut
-template <bool L0>
+// ALLON: every pixel of the block carries weight (dst_mask set) - the caller's guarantee, no per-pixel select
+template <bool L0, bool ALLON = false>
 __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0, int Y0, const int v[3][2][4], bool o00,
                                             bool o01, bool o02, bool o03, bool o10, bool o11, bool o12, bool o13) {
     if (!L0) {
@@ -1208,7 +1209,7 @@ __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0
 #pragma unroll
             for (int k = 0; k < 4; k++)
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) b[3 * k + pl] = on[r][k] ? (unsigned)sat8i(v[pl][r][k]) : 0u;
+                for (int pl = 0; pl < 3; pl++) b[3 * k + pl] = (ALLON || on[r][k]) ? (unsigned)sat8i(v[pl][r][k]) : 0u;
             // signed: a block that starts left of the cut has a negative column offset (its bytes are masked below)
             uint8_t* d = C.out + (int)(__mul24(Y - C.cut_y, C.out_stride) + 3 * (X0 - C.cut_x));
             const bool whole = X0 >= C.cut_x && X0 + 4 <= C.cut_x + C.cut_w;
@@ -1332,9 +1333,17 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
                     for (int k = 0; k < 4; k++) v[pl][r][k] += up[r][k];  // bounded by 9*255+9: see up_block
             }
         }
-        const bool on = ucode < 8u;  // W == 1 > eps; an unowned block has W == 0
         if (ABL == 4 && v[0][0][0] != 0x7fffffff) return;  // diagnostic: no stores
-        store_block<L0>(C, l, X0, Y0, v, on, on, on, on, on, on, on, on);
+        if (L0 && ucode >= 8u) {
+            // an unowned block has W == 0: dst_mask is clear and the pixel is black whatever the coarser levels hold
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[pl][r][k] = 0;
+        }
+        store_block<L0, true>(C, l, X0, Y0, v, true, true, true, true, true, true, true, true);
         return;
     }
     if (ABL == 5) return;  // diagnostic: only the single-owner fast path
