@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -84,6 +85,10 @@ struct pano_ctx {
     CanvasParams cv{};
     // frame slots (pano_set_frame_slots): extra sets of the per-frame buffers - pyramid slots and blend canvas - so
     // that several frames can be in flight on several streams.  Slot 0 is pyr_base / canvas[] above.
+    // live rects: per camera and level the pixels {x0, y0, x1, y1} (inclusive, tile coordinates of the level) that the
+    // blend ever reads, directly or through the pyramid chain; K1 / K2 do not produce the rest (see live_rects)
+    int live[kMaxCams][kMaxLevels][4] = {};
+    bool full_tiles = false;  // PANO_FULL_TILES=1: produce every pixel of every level (stage inspection)
     int nslots = 1, cur_slot = 0;
     char* slot_pyr[PANO_MAX_FRAME_SLOTS] = {};
     int16_t* slot_canvas[PANO_MAX_FRAME_SLOTS][kMaxLevels] = {};
@@ -267,8 +272,82 @@ WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t strid
     }
     w.gain = c->gain[i];
     w.gw = c->gain_w[i];
+    w.live_bx0 = 0; w.live_bx1 = INT_MAX; w.live_by0 = 0; w.live_by1 = INT_MAX;
+    if (!roi_only) {  // the bordered feed() tile: only the 64 x 16 blocks that overlap the live rect of level 0
+        const int* L = c->live[i][0];
+        if (L[2] < L[0] || L[3] < L[1]) { w.live_bx0 = 1; w.live_bx1 = 0; w.live_by0 = 1; w.live_by1 = 0; }  // nothing
+        else { w.live_bx0 = L[0] >> 6; w.live_bx1 = L[2] >> 6; w.live_by0 = L[1] >> 4; w.live_by1 = L[3] >> 4; }
+    }
     return w;
 }
+
+// Which pixels of which pyramid level does anything ever read?  MultiBandBlender::feed weighs the Laplacian of camera
+// i with its weight pyramid, and those weights are zero away from the camera's blend mask: per level l
+//   R_l   = support of w_l                           (R_0 = bounding box of the mask, R_{l+1} = pyrDown footprint of R_l)
+//   N_l   = R_l  U  the pyrUp windows the blend opens at level l for the blocks of R_{l-1}
+//   S_top = N_top,   S_l = N_l  U  the 5x5 pyrDown footprint of S_{l+1}
+// S_l is what K1 (l = 0) and K2 (l >= 1) have to produce; the rest of the bordered tile (on config 2 a quarter of it)
+// is never read by anything and is not produced.  Bounding boxes, all conservative; recomputed with the weights.
+static void live_rects(pano_ctx* c, const std::vector<std::vector<uint8_t>>& masks) {
+    const Plan& P = c->plan;
+    const int top = std::max(P.bands, 0);
+    for (int i = 0; i < P.n; i++) {
+        const FeedTile& t = P.tile[i];
+        auto full = [&](int l, int* r) { r[0] = 0; r[1] = 0; r[2] = (t.rect.w >> l) - 1; r[3] = (t.rect.h >> l) - 1; };
+        if (c->full_tiles || masks.empty() || P.bands < 0) {
+            for (int l = 0; l < c->levels; l++) full(l, c->live[i][l]);
+            continue;
+        }
+        // R_0: bounding box of the mask, in tile coordinates
+        const int mw = P.roi[i].w, mh = P.roi[i].h;
+        int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
+        const uint8_t* m = masks[i].data();
+        for (int y = 0; y < mh; y++)
+            for (int x = 0; x < mw; x++)
+                if (m[(size_t)y * mw + x]) { x0 = std::min(x0, x); x1 = std::max(x1, x); y0 = std::min(y0, y); y1 = std::max(y1, y); }
+        int R[kMaxLevels][4], N[kMaxLevels][4];
+        const bool empty = x1 < 0;
+        auto clampl = [&](int l, int* r) {
+            const int w = t.rect.w >> l, h = t.rect.h >> l;
+            r[0] = std::max(r[0], 0); r[1] = std::max(r[1], 0); r[2] = std::min(r[2], w - 1); r[3] = std::min(r[3], h - 1);
+        };
+        auto uni = [](int* a, const int* b) { a[0] = std::min(a[0], b[0]); a[1] = std::min(a[1], b[1]); a[2] = std::max(a[2], b[2]); a[3] = std::max(a[3], b[3]); };
+        if (empty) {
+            for (int l = 0; l < c->levels; l++) { c->live[i][l][0] = c->live[i][l][1] = 1; c->live[i][l][2] = c->live[i][l][3] = 0; }
+            continue;
+        }
+        R[0][0] = x0 + t.left; R[0][1] = y0 + t.top; R[0][2] = x1 + t.left; R[0][3] = y1 + t.top;
+        for (int l = 0; l < top; l++) {  // w_{l+1}(p) != 0 only if w_l is != 0 somewhere in [2p-2, 2p+2]
+            R[l + 1][0] = (R[l][0] - 1) >> 1; R[l + 1][1] = (R[l][1] - 1) >> 1;   // ceil((x0 - 2) / 2)
+            R[l + 1][2] = (R[l][2] + 2) >> 1; R[l + 1][3] = (R[l][3] + 2) >> 1;
+            clampl(l + 1, R[l + 1]);
+        }
+        for (int l = 0; l <= top; l++) {
+            for (int k = 0; k < 4; k++) N[l][k] = R[l][k];
+            if (l > 0) {
+                // the blend works on 4 x 2 blocks of level l-1 and opens the coarse window columns (X0>>1)-1 .. +2,
+                // rows (Y0>>1)-1 .. +1 around each (load_coarse); the scalar kernels' pyr_up_px windows lie inside
+                const int W[4] = {((R[l - 1][0] >> 2) << 1) - 1, (R[l - 1][1] >> 1) - 1, ((R[l - 1][2] >> 2) << 1) + 2, (R[l - 1][3] >> 1) + 1};
+                uni(N[l], W);
+                clampl(l, N[l]);
+            }
+        }
+        int S[4] = {N[top][0], N[top][1], N[top][2], N[top][3]};
+        for (int k = 0; k < 4; k++) c->live[i][top][k] = S[k];
+        for (int l = top - 1; l >= 0; l--) {
+            const int F[4] = {2 * S[0] - 2, 2 * S[1] - 2, 2 * S[2] + 2, 2 * S[3] + 2};  // REFLECT_101 stays inside this interval
+            for (int k = 0; k < 4; k++) S[k] = N[l][k];
+            uni(S, F);
+            clampl(l, S);
+            for (int k = 0; k < 4; k++) c->live[i][l][k] = S[k];
+        }
+        for (int l = top + 1; l < c->levels; l++) full(l, c->live[i][l]);
+    }
+    for (int i = 0; i < P.n; i++)
+        for (int l = 0; l < c->levels; l++)
+            for (int k = 0; k < 4; k++) c->pyr.cam[i].live[l][k] = c->live[i][l][k];
+}
+
 
 // cv::resize INTER_LINEAR (f32) coefficients of dst index d for ssize -> dsize
 inline void linear_coef(int d, int ssize, int dsize, int& s0, int& s1, float& a0, float& a1) {
@@ -353,6 +432,14 @@ pano_status ensure_weights(pano_ctx* c, hipStream_t s) {
     HIP_TRY(c, hipGetLastError());
     // one-time: later frames may run on other streams (frame slots) and must find the weights complete
     HIP_TRY(c, hipStreamSynchronize(s));
+    {
+        std::vector<std::vector<uint8_t>> hm(P.n);
+        for (int i = 0; i < P.n; i++) {
+            hm[i].resize((size_t)P.roi[i].w * P.roi[i].h);
+            HIP_TRY(c, hipMemcpy(hm[i].data(), c->mask[i], hm[i].size(), hipMemcpyDeviceToHost));
+        }
+        live_rects(c, hm);
+    }
     c->weights_dirty = false;
     return PANO_OK;
 }
@@ -616,6 +703,7 @@ pano_status pano_prepare(pano_ctx* c) {
         return fail(c, PANO_EINVAL, "cut rectangle outside the panorama");
     c->levels = P.bands < 0 ? 1 : P.bands + 1;
     c->prepared = true;
+    live_rects(c, {});  // no masks yet: every pixel of every level is live
     if (c->device < 0) return PANO_OK;  // plan-only
 
     HIP_TRY(c, hipSetDevice(c->device));
@@ -764,6 +852,8 @@ pano_status pano_prepare(pano_ctx* c) {
         while (k <= P.bands && c->cv.fast[k]) k++;
         if (k >= 1 && P.bands - k + 1 >= 2) c->cv.small_base = k;
     }
+    c->full_tiles = getenv("PANO_FULL_TILES") && atoi(getenv("PANO_FULL_TILES"));
+    live_rects(c, {});  // no masks yet: every pixel of every level is live
     c->cv.cam_lo = 0;
     c->cv.cam_n = n;
     c->cv.w0 = P.canvas.w; c->cv.h0 = P.canvas.h;
@@ -883,6 +973,7 @@ pano_status pano_set_mask(pano_ctx* c, int i, const uint8_t* h_mask, int w, int 
     HIP_TRY(c, hipMemcpy2D(c->mask[i], (size_t)w, h_mask, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice));
     c->mask_set[i] = true;
     c->weights_dirty = true;
+    live_rects(c, {});  // until the weights are rebuilt, produce every pixel
     drop_graphs(c);
     return PANO_OK;
 }
@@ -1016,6 +1107,7 @@ pano_status pano_build_masks_voronoi(pano_ctx* c) {
     if (e != hipSuccess) return fail(c, PANO_EHIP, hipGetErrorString(e));
     HIP_TRY(c, hipGetLastError());
     c->weights_dirty = true;
+    live_rects(c, {});  // until the weights are rebuilt, produce every pixel
     drop_graphs(c);
     return PANO_OK;
 }
@@ -1452,8 +1544,18 @@ pano_status pano_get_warp_bytes(const pano_ctx* c, uint64_t* src_bytes, uint64_t
     if (!c || !c->prepared || !src_bytes || !dst_bytes) return PANO_EINVAL;
     uint64_t s = 0, d = 0;
     for (int i = 0; i < c->plan.n; i++) {
-        s += (uint64_t)c->frame_w * c->frame_h * 3;
-        d += (uint64_t)c->plan.tile[i].rect.w * c->plan.tile[i].rect.h * 3;  // planar u8 tile, written once
+        // K1 produces the 64 x 16 blocks that overlap the live rect of level 0 (pano_get_live_rect): those tile bytes
+        // are written once (planar u8), and the same share of the frame is what they sample
+        const int tw = c->plan.tile[i].rect.w, th = c->plan.tile[i].rect.h;
+        const int* L = c->live[i][0];
+        uint64_t live_px = 0;
+        if (L[2] >= L[0] && L[3] >= L[1]) {
+            const int x0 = (L[0] >> 6) << 6, x1 = std::min(((L[2] >> 6) + 1) << 6, tw);
+            const int y0 = (L[1] >> 4) << 4, y1 = std::min(((L[3] >> 4) + 1) << 4, th);
+            live_px = (uint64_t)(x1 - x0) * (uint64_t)(y1 - y0);
+        }
+        d += live_px * 3;
+        s += (uint64_t)((double)c->frame_w * c->frame_h * 3 * ((double)live_px / ((double)tw * th)));
     }
     *src_bytes = s;
     *dst_bytes = d;
@@ -1475,6 +1577,15 @@ pano_status pano_get_warp_table_stats(const pano_ctx* c, uint64_t* table_bytes, 
     *table_bytes = g;
     *blocks = nb;
     *blocks_checked = nf;
+    return PANO_OK;
+}
+
+pano_status pano_get_live_rect(const pano_ctx* c, int i, int level, int rect[4]) {
+    if (!c || !c->prepared || !rect || i < 0 || i >= c->plan.n || level < 0 || level >= c->levels) return PANO_EINVAL;
+    const int* L = c->live[i][level];
+    rect[0] = L[0]; rect[1] = L[1];
+    rect[2] = L[2] >= L[0] ? L[2] - L[0] + 1 : 0;
+    rect[3] = L[3] >= L[1] ? L[3] - L[1] + 1 : 0;
     return PANO_OK;
 }
 

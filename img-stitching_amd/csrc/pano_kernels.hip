@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x0 >= c.tw || y >= c.th) return;
+    if ((x0 >> 6) < c.live_bx0 || (x0 >> 6) > c.live_bx1 || (y >> 4) < c.live_by0 || (y >> 4) > c.live_by1) return;
     float m[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) m[i] = c.m[i];
@@ -571,8 +572,10 @@ __device__ __attribute__((noinline)) void warp_fix_marked(const WarpCam* c, int 
 template <int ABL>
 __global__ __launch_bounds__(256) void warp_tiles_lut_checked_kernel(WarpParams P) {
     const WarpCam& c = P.cam[blockIdx.x];
-    const int x0 = (blockIdx.y * 16 + (threadIdx.x & 15)) * 4;
-    const int y = blockIdx.z * 16 + threadIdx.y * 4 + (threadIdx.x >> 4);
+    const int bx = c.live_bx0 + (int)blockIdx.y, by = c.live_by0 + (int)blockIdx.z;  // the grid is laid over the live blocks
+    if (bx > c.live_bx1 || by > c.live_by1) return;
+    const int x0 = (bx * 16 + (threadIdx.x & 15)) * 4;
+    const int y = by * 16 + threadIdx.y * 4 + (threadIdx.x >> 4);
     if (x0 >= c.tw || y >= c.th) return;
     const uint4 mm = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0);
     int v[4][3];
@@ -612,7 +615,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // holds one camera's frame, and every camera still advances top to bottom with all XCDs busy.  Measured on the
     // 8-camera launch against camera-major dispatch order: 33.1 vs 36.0 us, FETCH_SIZE 50.8 vs 77.8 MB.
     // Tried and rejected: XCD-aware order of the blocks WITHIN a camera (fewer fetched bytes, 15 % slower).
-    const int bx = blockIdx.y, by = blockIdx.z;
     // Prologue: an empty body over this grid (53 K workgroups) costs 9.4 us when the camera block is read field by
     // field behind branches - a chain of dependent scalar loads per wave, which the compiler is free to build by
     // sinking kernarg loads below the bounds test.  Fetch the 64-byte hot part with ONE s_load_dwordx16.
@@ -623,10 +625,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     struct Hot {
         const uint8_t* src; uint8_t* dst; const uint2* lutc; const int4* box;
-        int tw, th, src_w, src_h, src_stride, dst_pitch, dst_plane, lutc_pitch;
+        int tw, th, live_bx0, live_by0, src_stride, dst_pitch, dst_plane, lutc_pitch;
     };
     static_assert(sizeof(Hot) == 64 && offsetof(WarpCam, lutc_pitch) == 60 && offsetof(WarpCam, src) == 0 &&
-                      offsetof(WarpCam, box) == 24, "hot part layout");
+                      offsetof(WarpCam, box) == 24 && offsetof(WarpCam, live_bx0) == 40, "hot part layout");
     union { i32x16 v; Hot h; } hot;
     // WarpParams is the only kernel argument: P.cam[i] sits at kernarg + i * sizeof(WarpCam)
     const char __attribute__((address_space(4)))* ka =
@@ -640,12 +642,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     const uint8_t PANO_GLOBAL* const src = (const uint8_t PANO_GLOBAL*)hot.h.src;
     uint8_t PANO_GLOBAL* const dst = (uint8_t PANO_GLOBAL*)hot.h.dst;
     const u32x2 PANO_GLOBAL* const lutc = (const u32x2 PANO_GLOBAL*)hot.h.lutc;
-    const int tw = hot.h.tw, th = hot.h.th, src_w = hot.h.src_w, src_h = hot.h.src_h;
+    const int tw = hot.h.tw, th = hot.h.th;
+    // the grid is laid over the live blocks of the camera: workgroup (0, 0) is block (live_bx0, live_by0)
+    const int bx = hot.h.live_bx0 + (int)blockIdx.y, by = hot.h.live_by0 + (int)blockIdx.z;
     const unsigned stride = (unsigned)hot.h.src_stride;
     const unsigned dst_pitch = (unsigned)hot.h.dst_pitch, dst_plane = (unsigned)hot.h.dst_plane, lutc_pitch = (unsigned)hot.h.lutc_pitch;
     const int gxc = (tw + 63) >> 6;
     if (bx >= gxc || by * 16 >= th) return;  // the whole workgroup leaves: nobody waits at the barrier below
-    // this workgroup's source box: one more scalar load
+    // the blocks anything downstream reads (4 ints behind the hot part) and this workgroup's source box: two more
+    // scalar loads, issued together
+    i32x4 live;  // {live_bx1, live_by1, src_w, src_h}
+    asm volatile("s_load_dwordx4 %0, %1, 0x40" : "=s"(live) : "s"(ka) : "memory");
+    static_assert(offsetof(WarpCam, live_bx1) == 64 && offsetof(WarpCam, src_h) == 76, "second scalar load layout");
     i32x4 bb;
     {
         const char __attribute__((address_space(4)))* bp =
@@ -664,7 +672,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     if (active)  // 32-bit byte offset: scalar base + vector offset addressing, no 64-bit multiply
         e = *reinterpret_cast<const u32x2 PANO_GLOBAL*>((const uint8_t PANO_GLOBAL*)lutc + (((unsigned)y * lutc_pitch + (unsigned)(x0 >> 2)) << 3));
     if (ABL == 6 || ABL == 17) e = u32x2{(unsigned)((x0 * 7 / 8) * 32 + 5) | ((unsigned)((y * 7 / 8) * 32 + 9) << 16), 32u};
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bb) : : "memory");  // bb is only valid past this point
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bb), "+s"(live) : : "memory");  // bb, live are only valid past this point
+    if (bx > live.x || by > live.y) return;  // beyond this camera's live blocks (workgroup-uniform)
+    const int src_w = live.z, src_h = live.w;
     if (ABL == 12 || ABL == 6 || ABL == 17) bb.z = 0;  // diagnostic: global taps everywhere
     const int bh = bb.z >> 8, cpr = bb.z & 255;
     const unsigned lpitch = (unsigned)(cpr + 1) * 16u;
@@ -783,7 +793,16 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
                        hipEvent_t ev_stop) {
     dim3 block(64, 4, 1);
     dim3 grid((max_tw + 255) / 256, (max_th + 3) / 4, ncam);      // projecting kernel: 256 x 4 pixel blocks
-    const dim3 grid_lut(ncam, (max_tw + 63) / 64, (max_th + 15) / 16);  // table kernels: 64 x 16 pixel workgroups, camera fastest
+    // table kernels: 64 x 16 pixel workgroups laid over the live blocks of each camera, camera fastest
+    int lbx = 0, lby = 0;
+    for (int i = 0; i < ncam; i++) {
+        const WarpCam& c = p.cam[i];
+        const int nbx = (c.tw + 63) / 64, nby = (c.th + 15) / 16;
+        lbx = max(lbx, min(c.live_bx1, nbx - 1) - c.live_bx0 + 1);
+        lby = max(lby, min(c.live_by1, nby - 1) - c.live_by0 + 1);
+    }
+    lbx = max(lbx, 1); lby = max(lby, 1);  // nothing live (empty masks): one workgroup that leaves at once keeps the events valid
+    const dim3 grid_lut(ncam, lbx, lby);
     // Tried and rejected (A/B in one process, same outputs): (1) XCD-aware block order and (2) padding the column
     // blocks to a multiple of 8 so that each XCD owns a 256-pixel column stripe.  Both cut the fetched bytes to the
     // minimum (FETCH_SIZE 42.8 -> 27 MB raw) and both ran SLOWER (23.8 / 27.1 us vs 21.8 us): concentrating an XCD
@@ -891,12 +910,15 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam
     const PyrCam& c = P.cam[ci];
     const int sw = c.w0 >> l, sh = c.h0 >> l;
     const int dw = sw >> 1, dh = sh >> 1;
-    const int t = blockIdx.x * 64 + threadIdx.x;      // group of 4 output columns
+    // Outputs of level l + 1 that nothing downstream reads are not produced (their inputs may not exist either): the
+    // grid is laid over the live rect, so that whole waves - not lanes - fall off its far side.
+    const int lx0 = c.live[l + 1][0], ly0 = c.live[l + 1][1], lx1 = c.live[l + 1][2], ly1 = c.live[l + 1][3];
+    const int t = (lx0 >> 2) + blockIdx.x * 64 + threadIdx.x;  // group of 4 output columns
     // a wave is one threadIdx.y: tell the compiler, and the row indices, the REFLECT_101 of the seven source rows and
     // their addresses are scalar work (a quarter of this kernel's vector instructions otherwise)
-    const int y0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * 2;  // pair of output rows
-    if (y0 >= dh) return;
-    if (t * 4 >= dw) return;
+    const int y0 = ((ly0 >> 1) + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * 2;  // pair of output rows
+    if (y0 >= dh || y0 > ly1) return;
+    if (t * 4 >= dw || t * 4 > lx1) return;
     const uint8_t* __restrict__ src = c.lvl[l] + (size_t)pl * c.plane[l];
     const int sp = c.pitch[l];
     // Every lane does seven 16-byte loads (columns 8t-4 .. 8t+11; lane 0 loads columns 0..15 and shifts).

@@ -25,11 +25,16 @@ struct alignas(64) WarpCam {
     const uint2* lutc;    // packed remap table, 8 bytes per 4-pixel group (see pack_warp_lut_kernel)
     const int4* box;      // per 64x16-pixel workgroup: its source box {xmin, ymin, rows<<8 | chunks, ceil(2^16/chunks)}
     int tw, th;           // tile width/height in pixels
-    int src_w, src_h;
+    // Blocks of 64 x 16 tile pixels (inclusive block coordinates) that anything downstream ever reads (see
+    // pano_api.cpp live_rects): the K1 grid is laid over them.  {0, 0} .. {INT_MAX, INT_MAX} = everything.
+    int live_bx0, live_by0;
     int src_stride;       // bytes
     int dst_pitch;        // bytes per row
     int dst_plane;        // pipeline: bytes between the B, G, R planes
     int lutc_pitch;       // groups per row = lut_pitch / 4
+    // --- the next 16 bytes ride on a second scalar load
+    int live_bx1, live_by1;
+    int src_w, src_h;
     // --- everything else
     // static remap table (frames up to 2048 x 2048): one dword per tile pixel, see build_warp_lut_kernel
     const uint32_t* lut;  // dense form, read where the packed form escapes; nullptr -> project on the fly
@@ -63,6 +68,7 @@ struct PyrCam {
     int wpitch[kLevels];       // floats per row
     int w0, h0;                // level-0 tile size (multiples of 2^bands)
     int tx, ty;                // tile origin in the padded canvas (level 0)
+    int live[kLevels][4];      // per level {x0, y0, x1, y1} inclusive: the pixels of the level anything downstream reads
 };
 struct PyrParams {
     PyrCam cam[kCams];

@@ -221,9 +221,9 @@ pano_status pano_get_stage_ms(pano_ctx* ctx, float ms[PANO_NUM_STAGES]);
  * never waits for the GPU; launches[k] = number of stage-k intervals summed into total_ms[k] */
 pano_status pano_get_stage_stats(pano_ctx* ctx, double total_ms[PANO_NUM_STAGES],
                                  uint64_t launches[PANO_NUM_STAGES], int reset);
-/* algorithmic bytes of the warp kernel per compose: sum_cams (W*H*3 read once + Wt*Ht*3 written once:
- * the bordered level-0 tile is stored as planar u8, the 8U->16S widening of ocvstitcher.hpp:1180 happens
- * in registers downstream) */
+/* algorithmic bytes of the warp kernel per compose: sum_cams (live share of W*H*3 read once + live part of Wt*Ht*3
+ * written once: the bordered level-0 tile is stored as planar u8, the 8U->16S widening of ocvstitcher.hpp:1180
+ * happens in registers downstream; "live" = the 64x16 blocks over pano_get_live_rect(level 0)) */
 pano_status pano_get_warp_bytes(const pano_ctx* ctx, uint64_t* src_bytes, uint64_t* dst_bytes);
 /* the warp's static remap table (the constant part of cv::detail::RotationWarper::buildMaps + cv::remap's index
  * arithmetic, ocvstitcher.hpp:1163): bytes one compose reads from it (2 per tile pixel in the packed form, 4 in the
@@ -234,6 +234,14 @@ pano_status pano_get_warp_table_stats(const pano_ctx* ctx, uint64_t* table_bytes
 
 /* ---- stage inspection (parity tests) ------------------------------------------------------- */
 /* Gaussian level `level` of camera i's bordered tile, int16 x3 interleaved, tight rows */
+/* The part {x, y, w, h} of camera i's bordered tile at pyramid `level` that the library produces.
+ * MultiBandBlender::feed (ocvstitcher.hpp:1202) weighs every Laplacian with the camera's weight pyramid, which is zero
+ * away from the camera's blend mask; pixels of the tile that neither carry weight nor feed - through pyrDown / pyrUp -
+ * a pixel that does are never read by anything, and the warp / pyramid kernels skip them (about a quarter of the tile
+ * on the 8 x 1080p rig).  Follows the masks: the whole tile until the first compose after a mask change.  The
+ * panorama is unaffected; pano_debug_get_level is defined inside this rectangle.  PANO_FULL_TILES=1 (environment, at
+ * pano_prepare) produces whole tiles. */
+pano_status pano_get_live_rect(const pano_ctx* ctx, int i, int level, int rect[4]);
 pano_status pano_debug_get_level(pano_ctx* ctx, int i, int level, int16_t* h_dst, int* w, int* h);
 /* f32 weight level of camera i (pyrDown chain of mask/255 with constant border) */
 pano_status pano_debug_get_weights(pano_ctx* ctx, int i, int level, float* h_dst, int* w, int* h);
