@@ -1161,6 +1161,13 @@ pano_status pano_feed_cameras(pano_ctx* c, unsigned cam_bits, const uint8_t* con
     const Plan& P = c->plan;
     hipStream_t s = (hipStream_t)stream;
     cam_bits &= (1u << P.n) - 1u;
+    // the live rects follow the masks: once every mask is there, have them (and the weights) current, so that a rank
+    // that only feeds (camera sharding) skips the same dead pixels as the rank that blends
+    if (c->weights_dirty) {
+        bool all = true;
+        for (int i = 0; i < P.n; i++) all &= c->mask_set[i];
+        if (all && (st = ensure_weights(c, s)) != PANO_OK) return st;
+    }
     WarpParams wp{};
     int k = 0, mw = 0, mh = 0;
     for (int i = 0; i < P.n; i++) {
