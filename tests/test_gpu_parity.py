@@ -585,3 +585,45 @@ def test_frame_slots_overlapping_frames(pano, po, torch):
     assert np.array_equal(out.cpu().numpy(), ref[1])
     with pytest.raises(Exception):
         ctx.select_frame_slot(2)
+
+
+def test_live_rects_follow_the_masks(pano, po, c1, monkeypatch):
+    """pano_get_live_rect: the part of each pyramid level the library produces.  It follows the masks (whole tile
+    until the first compose after a change), PANO_FULL_TILES=1 switches the skipping off, and the panorama is the
+    oracle's either way"""
+    masks = oracle_masks(po, c1)
+    want, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 4)
+    ctx = make_ctx(pano, c1, 0, num_bands=4)
+    (tx, ty, tw, th), (top, bottom, left, right) = ctx.feed_tile(0)
+    assert ctx.live_rect(0, 0) == (0, 0, tw, th)          # no masks yet: everything
+    for i in range(4):
+        ctx.set_mask(i, masks[i])
+    assert np.array_equal(ctx.compose_host(c1["frames"]), want)
+    shrunk = 0
+    for i in range(4):
+        (tx, ty, tw, th), (top, bottom, left, right) = ctx.feed_tile(i)
+        ys, xs = np.nonzero(masks[i])
+        for l in range(5):
+            lx, ly, lw, lh = ctx.live_rect(i, l)
+            assert 0 <= lx and 0 <= ly and lx + lw <= (tw >> l) and ly + lh <= (th >> l)
+            # the pixels that carry weight at level 0 are inside, and so is their footprint at the coarser levels
+            assert lx <= (xs.min() + left) >> l and ((xs.max() + left) >> l) < lx + lw
+            assert ly <= (ys.min() + top) >> l and ((ys.max() + top) >> l) < ly + lh
+        shrunk += ctx.live_rect(i, 0)[2] < tw
+    assert shrunk >= 2                                     # the outer cameras lose a good part of their tiles
+    # a mask change resets to the whole tile until the next compose; the result follows the new masks
+    m0 = masks[0].copy(); m0[:, : m0.shape[1] // 2] = 0
+    ctx.set_mask(0, m0)
+    (tx, ty, tw, th), _ = ctx.feed_tile(0)
+    assert ctx.live_rect(0, 0) == (0, 0, tw, th)
+    want2, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], [m0] + masks[1:], 4)
+    assert np.array_equal(ctx.compose_host(c1["frames"]), want2)
+    assert ctx.live_rect(0, 0)[2] < tw
+    # whole tiles on request
+    monkeypatch.setenv("PANO_FULL_TILES", "1")
+    full = make_ctx(pano, c1, 0, num_bands=4)
+    for i in range(4):
+        full.set_mask(i, masks[i])
+    assert np.array_equal(full.compose_host(c1["frames"]), want)
+    (tx, ty, tw, th), _ = full.feed_tile(1)
+    assert full.live_rect(1, 0) == (0, 0, tw, th)
