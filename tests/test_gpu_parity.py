@@ -97,7 +97,7 @@ def test_stages_and_compose_c1_bit_exact(pano, po, c1, bands):
         for l in range(bands + 1):
             # the pyramid is only produced where something downstream reads it (pano_get_live_rect)
             lx, ly, lw, lh = ctx.live_rect(i, l)
-            assert lw > 0 and lh > 0 and (lw < g.shape[1] or l > 0)
+            assert lw > 0 and lh > 0
             assert np.array_equal(ctx.debug_level(i, l)[ly:ly + lh, lx:lx + lw], g[ly:ly + lh, lx:lx + lw]), (i, l)
             assert np.array_equal(ctx.debug_weights(i, l), wgt), (i, l)
             if l < bands:
@@ -591,6 +591,7 @@ def test_live_rects_follow_the_masks(pano, po, c1, monkeypatch):
     """pano_get_live_rect: the part of each pyramid level the library produces.  It follows the masks (whole tile
     until the first compose after a change), PANO_FULL_TILES=1 switches the skipping off, and the panorama is the
     oracle's either way"""
+    monkeypatch.delenv("PANO_FULL_TILES", raising=False)
     masks = oracle_masks(po, c1)
     want, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 4)
     ctx = make_ctx(pano, c1, 0, num_bands=4)
