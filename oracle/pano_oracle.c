@@ -952,8 +952,8 @@ void po_prepare_masks_voronoi(int n, int kind, int sw, int sh, const float* Ks, 
     int ssw = cv_round_d(sw * swa), ssh = cv_round_d(sh * swa);
     float seam_scale = (float)(wscale * swa);
     float swa_f = (float)swa;
-    int* corners = (int*)malloc(sizeof(int) * 2 * n);
-    int* sizes = (int*)malloc(sizeof(int) * 2 * n);
+    int* corners = (int*)calloc((size_t)2 * n, sizeof(int));
+    int* sizes = (int*)calloc((size_t)2 * n, sizeof(int));
     uint8_t** mw = (uint8_t**)malloc(sizeof(uint8_t*) * n);
     uint8_t* ones = (uint8_t*)malloc((size_t)(ssw > sw ? ssw : sw) * (ssh > sh ? ssh : sh));
     memset(ones, 255, (size_t)(ssw > sw ? ssw : sw) * (ssh > sh ? ssh : sh));
