@@ -173,18 +173,6 @@ __device__ __forceinline__ void apply_gain(const WarpCam& c, int x, int y, int v
 // ------------------------------------------------------------------------------------------------
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 
-// XCD-aware block order (MI355X: 8 XCDs, each with its own 4 MB L2; consecutive workgroup ids are dealt
-// round-robin over the XCDs).  Remap the linear id so that each XCD walks one contiguous band of tile rows:
-// neighbouring row blocks share source rows / stencil halos, which then hit in that XCD's L2 instead of being
-// fetched once per XCD.  Bijective for any block count (cdna_hip_programming.md, T1).  Speed only.
-__device__ __forceinline__ void xcd_remap(int gx, int gy, int& bx, int& by) {
-    const int nblk = gx * gy, id = by * gx + bx;
-    const int xcd = id & 7, q = nblk >> 3, r = nblk & 7;
-    const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-    by = nid / gx;
-    bx = nid - by * gx;
-}
-
 // The 6 tap bytes B0 G0 R0 B1 G1 R1 at byte offset o of the frame, returned in the low 6 bytes of a uint2.
 // An unaligned 8-byte load costs the texture-address unit roughly twice an aligned one (measured: the
 // table-form K1 runs 30 us with unaligned taps, 22 us aligned), so fetch the enclosing 4-byte-aligned
@@ -803,10 +791,11 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
     }
     lbx = max(lbx, 1); lby = max(lby, 1);  // nothing live (empty masks): one workgroup that leaves at once keeps the events valid
     const dim3 grid_lut(ncam, lbx, lby);
-    // Tried and rejected (A/B in one process, same outputs): (1) XCD-aware block order and (2) padding the column
-    // blocks to a multiple of 8 so that each XCD owns a 256-pixel column stripe.  Both cut the fetched bytes to the
-    // minimum (FETCH_SIZE 42.8 -> 27 MB raw) and both ran SLOWER (23.8 / 27.1 us vs 21.8 us): concentrating an XCD
-    // on a narrow address range loses more in channel spread than the L2 reuse gains.  Dispatch order is shipped.
+    // Tried and rejected on the blocks WITHIN a camera (A/B in one process, same outputs): (1) an XCD-aware block order
+    // and (2) padding the column blocks to a multiple of 8 so that each XCD owns a 256-pixel column stripe.  Both cut the
+    // fetched bytes to the minimum and both ran slower (23.8 / 27.1 us vs 21.8 us per 4-camera launch): concentrating
+    // an XCD on a narrow address range loses more in channel spread than the L2 reuse gains.  What ships is one camera
+    // per XCD (the camera is the fastest grid coordinate), which gets the same minimum without that cost.
     // the table form needs every camera of the launch to carry a table (frames <= 2048 x 2048)
     bool all_lut = true;
     for (int i = 0; i < ncam; i++) all_lut &= p.cam[i].lut != nullptr;
