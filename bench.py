@@ -72,9 +72,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # PANO_BENCH_BACKEND=gloo: rehearsal of the N > 1 flow on ONE GPU (every rank on cuda:0, slot ranges staged through
+    # host memory); the judged multi-GPU run uses RCCL, one GPU per rank
+    rehearsal = world > 1 and os.environ.get("PANO_BENCH_BACKEND", "nccl") == "gloo"
+    if rehearsal:
+        local = 0
+    red_dev = "cpu" if rehearsal else "cuda"  # where the scalar reductions of the timing live
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     pano = importlib.import_module("img-stitching_amd")
     g = c2_group()
@@ -140,14 +149,21 @@ def main():
             if plan["bits"]:
                 ctxs[grp].feed_cameras(plan["bits"], fptr[grp], strides, stream)
             buf, slot = slot_views[grp]
-            sh.exchange_slots(dist, rank, buf, slot, plan["moves"])   # RCCL p2p on the current stream
+            if rehearsal:
+                torch.cuda.synchronize()
+            sh.exchange_slots(dist, rank, buf, slot, plan["moves"], via_host=rehearsal)   # RCCL p2p on the current stream
             if plan["blend_here"]:
                 ctxs[grp].blend(outs[grp].data_ptr(), ow * 3, stream)
             if plan["pano_from"] != 0:
                 if rank == plan["pano_from"]:
-                    dist.send(outs[grp], dst=0)
+                    dist.send(outs[grp].cpu() if rehearsal else outs[grp], dst=0)
                 elif rank == 0:
-                    dist.recv(outs[grp], src=plan["pano_from"])
+                    if rehearsal:
+                        host = outs[grp].cpu()
+                        dist.recv(host, src=plan["pano_from"])
+                        outs[grp].copy_(host)
+                    else:
+                        dist.recv(outs[grp], src=plan["pano_from"])
 
     step = step_single if (world == 1 and not args.force_sharded_path) else step_sharded
     assert int(slot_views[0][0].numel()) == slot_views[0][1] * NC
@@ -161,7 +177,7 @@ def main():
             torch.cuda.synchronize()
         except Exception as exc:  # noqa: BLE001
             ok, sharded_failed = 0, repr(exc)[:200]
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             sharded_failed = sharded_failed or "another rank failed"
@@ -217,13 +233,13 @@ def main():
             for k in range(args.steps):
                 step_single(k)
             torch.cuda.synchronize()
-            trt = torch.tensor([time.perf_counter() - tr], dtype=torch.float64, device="cuda")
+            trt = torch.tensor([time.perf_counter() - tr], dtype=torch.float64, device=red_dev)
             dist.all_reduce(trt, op=dist.ReduceOp.MAX)
             replicas_rate = round(world * args.steps / float(trt.item()), 1)
         except Exception:  # never let the side measurement break the contract line
             replicas_rate = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -282,7 +298,8 @@ def main():
             "config": {"workload": "C2: 8x1920x1080 BGR8 -> 2 groups x 4 cameras, spherical warp + %d-band "
                                    "multi-band blend, Voronoi seams, pano 2 x %dx%d" % (args.bands, ow, oh),
                        "parallelism": ("single GPU, %d frames in flight" % F) if world == 1 else
-                                      ("cameras sharded %d/rank, RCCL gather to rank 0" % per_rank) if sharded_failed is None else
+                                      ("cameras sharded %d/rank, %s" % (per_rank, "gloo rehearsal on one GPU, slots staged through the host"
+                                                                          if rehearsal else "RCCL gather to rank 0")) if sharded_failed is None else
                                       ("replicas, one rig per GPU (camera-sharded path failed: %s)" % sharded_failed)},
             "roofline": roofline,
             "ms_per_step_event_pass": round(dt_profiled / args.steps * 1e3, 4),

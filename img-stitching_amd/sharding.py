@@ -39,12 +39,18 @@ def group_plan(total_cams, cams_per_group, world, rank):
     return plans
 
 
-def exchange_slots(dist, rank, slot_buffer, slot_bytes, moves):
+def exchange_slots(dist, rank, slot_buffer, slot_bytes, moves, via_host=False):
     """slot_buffer: 1-D uint8 tensor over all slots of the group's context.  Senders push their range to rank 0,
-    rank 0 receives each range where it belongs."""
+    rank 0 receives each range where it belongs.  via_host stages device tensors through host memory, for rehearsing
+    the path with the gloo backend (several ranks on one GPU); RCCL sends device memory directly."""
     for peer, first, count in moves:
         view = slot_buffer[first * slot_bytes:(first + count) * slot_bytes]
         if rank == peer:
-            dist.send(view, dst=0)
+            dist.send(view.cpu() if via_host else view, dst=0)
         elif rank == 0:
-            dist.recv(view, src=peer)
+            if via_host:
+                host = view.cpu()
+                dist.recv(host, src=peer)
+                view.copy_(host)
+            else:
+                dist.recv(view, src=peer)
