@@ -179,7 +179,8 @@ typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 // 12 bytes (global_load_dwordx3) and realign in registers (2 x v_alignbyte_b32).
 __device__ __forceinline__ uint2 load_taps6(const uint8_t* __restrict__ src, unsigned lo, unsigned o) {
     const unsigned k = (o + lo) & 3u;
-    const uint3 d = *reinterpret_cast<const uint3*>(src + (o - k));
+    // signed: with an unaligned frame pointer the dword under the first pixels starts up to 3 bytes BEFORE src
+    const uint3 d = *reinterpret_cast<const uint3*>(src + (int)(o - k));
     return make_uint2(__builtin_amdgcn_alignbyte(d.y, d.x, k), __builtin_amdgcn_alignbyte(d.z, d.y, k));
 }
 

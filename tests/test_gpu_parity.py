@@ -628,3 +628,29 @@ def test_live_rects_follow_the_masks(pano, po, c1, monkeypatch):
     assert np.array_equal(full.compose_host(c1["frames"]), want)
     (tx, ty, tw, th), _ = full.feed_tile(1)
     assert full.live_rect(1, 0) == (0, 0, tw, th)
+
+
+@pytest.mark.parametrize("offset,pad", [(0, 0), (4, 0), (8, 16), (1, 0), (2, 5), (4, 4)])
+def test_frame_pointer_alignment_and_strides(pano, po, torch, c1, offset, pad):
+    """cv::Mat views: frames that start at any byte offset with any row stride.  4-byte aligned frames with strides
+    that are a multiple of 16 take the LDS warp kernel (also when the pointer is not 16-byte aligned), everything else
+    the general kernel - same bytes either way"""
+    masks = oracle_masks(po, c1)
+    want, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 3)
+    ctx = make_ctx(pano, c1, 0, num_bands=3)
+    for i in range(4):
+        ctx.set_mask(i, masks[i])
+    stride = 480 * 3 + pad
+    bufs, ptrs = [], []
+    for f in c1["frames"]:
+        host = np.zeros(offset + stride * 270 + 64, np.uint8)
+        rows = host[offset:offset + stride * 270].reshape(270, stride)
+        rows[:, :480 * 3] = f.reshape(270, 480 * 3)
+        rows[:, 480 * 3:] = 0xA5           # stride padding must never be sampled
+        b = torch.from_numpy(host).cuda()
+        bufs.append(b)
+        ptrs.append(b.data_ptr() + offset)
+    out = torch.zeros((257, 1333, 3), dtype=torch.uint8, device="cuda")
+    ctx.compose(ptrs, [stride] * 4, out.data_ptr(), 1333 * 3, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
