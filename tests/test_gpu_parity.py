@@ -654,3 +654,22 @@ def test_frame_pointer_alignment_and_strides(pano, po, torch, c1, offset, pad):
     ctx.compose(ptrs, [stride] * 4, out.data_ptr(), 1333 * 3, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("offset,pad", [(1, 0), (2, 7), (3, 1), (4, 4), (0, 13)])
+def test_output_pointer_alignment_and_stride(pano, po, torch, c1, offset, pad):
+    """the panorama may land anywhere: any byte offset, any row stride >= 3 * width; bytes between rows stay untouched"""
+    masks = oracle_masks(po, c1)
+    want, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 3)
+    ctx = make_ctx(pano, c1, 0, num_bands=3)
+    for i in range(4):
+        ctx.set_mask(i, masks[i])
+    d = [torch.from_numpy(f).cuda() for f in c1["frames"]]
+    stride = 1333 * 3 + pad
+    buf = torch.full((offset + stride * 257 + 16,), 0x5A, dtype=torch.uint8, device="cuda")
+    ctx.compose([t.data_ptr() for t in d], [480 * 3] * 4, buf.data_ptr() + offset, stride, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    host = buf.cpu().numpy()
+    rows = host[offset:offset + stride * 257].reshape(257, stride)
+    assert np.array_equal(rows[:, :1333 * 3].reshape(257, 1333, 3), want)
+    assert (rows[:, 1333 * 3:] == 0x5A).all() and (host[:offset] == 0x5A).all() and (host[offset + stride * 257:] == 0x5A).all()
