@@ -460,9 +460,11 @@ __global__ __launch_bounds__(256) void build_warp_boxes_kernel(const uint32_t* l
         // rows ymin .. min(ymax + 1, sh - 1) are loaded; the taps of row ymax + 1 == sh (weight 0) read the spare row
         const int h = min(lim[3] + 1, sh - 1) - ymin + 1;
         // bytes 3*xmin .. 3*xmax+5 of each row, fetched from the enclosing 16-byte boundary (phase <= 15); the
-        // realigning tap read touches up to 6 bytes more, which the spare chunk of the LDS pitch absorbs
+        // realigning tap read touches up to 6 bytes more (the first bytes of the next row)
         const int cpr = (3 * (lim[1] - xmin) + 21 + 15) / 16;
-        bool ok = (h + 1) * (cpr + 1) * 16 <= kBoxBytes && cpr <= 63 && h * cpr <= 256 * kBoxIters;
+        // LDS rows are packed at cpr * 16 bytes: a tap read may run a few bytes into the next row, the taps of the spare
+        // row read whatever follows the box, and the last wave's copy rounds the box up to 64 chunks
+        bool ok = (h + 1) * cpr * 16 + 16 <= kBoxBytes && cpr <= 63 && (h * cpr + 63) / 64 * 64 * 16 <= kBoxBytes;
         // the chunks of the last frame row must end inside the frame
         ok &= !(ymin + h - 1 == sh - 1 && 3 * xmin + cpr * 16 > 3 * sw);
         if (ok) box = make_int4(xmin, ymin, (h << 8) | cpr, (65536 + cpr - 1) / cpr);
@@ -592,8 +594,9 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_checked_kernel(WarpParams 
 // LDS buffer (global_load_lds_dwordx4) while the current one is computed - exact, 35 us instead of 31 (two buffers
 // and 89 VGPRs leave 5 waves per SIMD); 8-byte ds reads at odd addresses instead of 3 dwords + v_alignbyte - 55 us.
 // So the taps do not come from global memory: the static table fixes the set of frame bytes a workgroup touches (its
-// source box, see build_warp_boxes_kernel); the workgroup copies that box into LDS with coalesced 16-byte loads -
-// 1 to 2 gathers per wave instead of 8, issued together with the table load - and reads the taps from LDS.
+// source box, see build_warp_boxes_kernel); the workgroup copies that box into LDS with coalesced 16-byte
+// direct-to-LDS loads (global_load_lds_dwordx4: 1 to 2 gathers per wave instead of 8, no staging registers), issued
+// together with the table load, and reads the taps from LDS.
 // Workgroups whose box does not fit keep the global taps.  Needs 4-byte aligned frames and strides % 16 == 0
 // (checked by the launcher; anything else runs warp_tiles_lut_checked_kernel).
 template <int ABL>
@@ -611,7 +614,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     struct Hot {
         const uint8_t* src; uint8_t* dst; const uint2* lutc; const int4* box;
         int tw, th, live_bx0, live_by0, src_stride, dst_pitch, dst_plane, lutc_pitch;
@@ -666,32 +668,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     const int src_w = live.z, src_h = live.w;
     if (ABL == 12 || ABL == 6 || ABL == 17) bb.z = 0;  // diagnostic: global taps everywhere
     const int bh = bb.z >> 8, cpr = bb.z & 255;
-    const unsigned lpitch = (unsigned)(cpr + 1) * 16u;
+    const unsigned lpitch = (unsigned)cpr * 16u;  // rows packed: chunk k = r * cpr + ci lands at LDS byte 16 * k
     // byte phase of the box origin inside its first 16-byte chunk; the same for every row because stride % 16 == 0
     const unsigned lo16 = (unsigned)(size_t)hot.h.src & 15u;
     const unsigned og = (unsigned)bb.y * stride + 3u * (unsigned)bb.x + lo16;  // from the 16-byte boundary below src
     const unsigned ph = og & 15u;
     if (bh) {
-        // chunk k = tid + 256 * it -> (row r = k / cpr, column ci = k % cpr); whole iterations a wave does not reach
-        // are skipped by a scalar branch, the surplus lanes of its last one re-read the last chunk (no predication)
+        // chunk k = tid + 256 * it -> (row r = k / cpr, column ci = k % cpr), copied by global_load_lds_dwordx4: the 64
+        // lanes of a wave write 64 consecutive 16-byte chunks at M0 - no staging registers, no ds_write.  Whole
+        // iterations a wave does not reach are skipped by a scalar branch; the surplus lanes of its last one re-read the
+        // last chunk and land behind the box, inside the buffer.
         const int total = bh * cpr;
-        const int wave0 = tid & ~63;
         const uint8_t PANO_GLOBAL* const srca = (src - lo16) + (og - ph);  // 16-byte aligned
-        u32x4 chunk[kBoxIters];
-        unsigned loff[kBoxIters];
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
 #pragma unroll
         for (int it = 0; it < kBoxIters; it++) {
-            if (wave0 + 256 * it < total) {
+            if (wv * 64 + 256 * it < total) {
                 const unsigned k = (unsigned)min(tid + 256 * it, total - 1);
                 const unsigned r = __umul24(k, (unsigned)bb.w) >> 16, ci = k - __umul24(r, (unsigned)cpr);
-                chunk[it] = *reinterpret_cast<const u32x4 PANO_GLOBAL*>(srca + (__umul24(r, stride) + ci * 16u));
-                loff[it] = __umul24(r, lpitch) + ci * 16u;
+                __builtin_amdgcn_global_load_lds(
+                    srca + (__umul24(r, stride) + ci * 16u),
+                    (__attribute__((address_space(3))) void*)((__attribute__((address_space(3))) uint8_t*)&sbox[0] + (wv * 64 + 256 * it) * 16),
+                    16, 0, 0);
             }
         }
-        uint8_t* sb1 = reinterpret_cast<uint8_t*>(sbox);
-#pragma unroll
-        for (int it = 0; it < kBoxIters; it++)
-            if (wave0 + 256 * it < total) *reinterpret_cast<u32x4*>(sb1 + loff[it]) = chunk[it];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     if (!active) return;
