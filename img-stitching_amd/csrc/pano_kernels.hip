@@ -184,6 +184,16 @@ __device__ __forceinline__ uint2 load_taps6(const uint8_t* __restrict__ src, uns
     return make_uint2(__builtin_amdgcn_alignbyte(d.y, d.x, k), __builtin_amdgcn_alignbyte(d.z, d.y, k));
 }
 
+// The same 6 bytes one at a time, never past byte `last` of the frame: for the few pixels whose aligned 12-byte fetch would
+// end beyond the frame (taps on the last pixels of the last rows).  A clamped byte only ever meets weight 0.
+template <typename P>
+__device__ __forceinline__ uint2 taps6_bytes(P src, unsigned o, unsigned last) {
+    unsigned b[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) b[i] = src[min(o + i, last)];
+    return make_uint2(b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24), b[4] | (b[5] << 8));
+}
+
 // x / z and y / z, correctly rounded (IEEE-754 round-to-nearest-even), for a shared denominator.
 // This is the AMDGPU f32 division expansion (v_rcp + Newton refinement + two residual corrections) with
 // the reciprocal refinement shared by both quotients and without the exponent pre-scaling, which is a
@@ -342,19 +352,18 @@ __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
 // 0xffffffff marks the few pixels this cannot express (a tap fetch that would run past the end of the
 // frame); they are projected on the fly.  Needs frame sides <= 2048 (16 bits per axis).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool lut_axis(int i0, int n, int frac, int& base, int& w1) {
+__device__ __forceinline__ void lut_axis(int i0, int n, int frac, int& base, int& w1) {
+    // BORDER_REFLECT maps neighbouring indices to neighbouring or equal ones: r1 - r0 is -1, 0 or +1
     const int r0 = reflect_idx(i0, n), r1 = reflect_idx(i0 + 1, n);
     if (r1 == r0 + 1) { base = r0; w1 = frac; }
     else if (r1 == r0 - 1) { base = r1; w1 = 32 - frac; }
-    else if (r1 == r0) { base = r0; w1 = 0; }
-    else return false;
+    else { base = r0; w1 = 0; }
     if (w1 == 32) { base += 1; w1 = 0; }
-    return true;
 }
 __global__ __launch_bounds__(256) void build_warp_lut_kernel(WarpCam c, uint32_t* lut, int lut_pitch) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= lut_pitch || y >= c.th) return;
-    uint32_t code = 0xffffffffu;
+    uint32_t code;
     {
         // the pad columns (x >= tw, never read downstream) repeat the last pixel so that they compress like it
         float fx, fy;
@@ -362,13 +371,12 @@ __global__ __launch_bounds__(256) void build_warp_lut_kernel(WarpCam c, uint32_t
         const int isx = cv_round_dev(fx * 32.f), isy = cv_round_dev(fy * 32.f);
         const int ix = sat16i(isx >> 5), iy = sat16i(isy >> 5);
         int xs, a1, ys, b1;
-        if (lut_axis(ix, c.src_w, isx & 31, xs, a1) && lut_axis(iy, c.src_h, isy & 31, ys, b1)) {
-            // the fetch reads the aligned 12 bytes around column xs of rows ys and min(ys+1, sh-1): it may spill
-            // into the next row (harmless) but not past the end of the frame
-            const bool last_row = ys + 1 >= c.src_h - 1;
-            const bool ok = xs <= c.src_w - 1 && ys <= c.src_h - 1 && !(last_row && xs > c.src_w - 4);
-            if (ok) code = (uint32_t)(xs * 32 + a1) | ((uint32_t)(ys * 32 + b1) << 16);
-        }
+        lut_axis(ix, c.src_w, isx & 31, xs, a1);
+        lut_axis(iy, c.src_h, isy & 31, ys, b1);
+        // Every pixel has a code (0 <= xs < src_w, 0 <= ys < src_h; 0xffffffff cannot occur: a base on the last column
+        // or row always carries weight 0).  What the table does NOT promise is that an aligned 12-byte fetch at (xs, ys)
+        // stays inside the frame: the kernels check that themselves for the last bytes of the frame.
+        code = (uint32_t)(xs * 32 + a1) | ((uint32_t)(ys * 32 + b1) << 16);
     }
     lut[(size_t)y * lut_pitch + x] = code;
 }
@@ -384,7 +392,7 @@ void launch_build_warp_lut(const WarpCam& c, uint32_t* lut, int lut_pitch, hipSt
 //           8..13  Eb  signed 6   y step base
 //          14..31  three fields {cx signed 3, cy signed 3} for pixels 1..3:
 //                  X[j] = X[j-1] + Db + cx[j],  Y[j] = Y[j-1] + Eb + cy[j]     (X = xs*32+a', Y = ys*32+b')
-// Exact or not at all: a group whose steps do not fit (a reflect fold inside the group, a marked pixel, > 4x
+// Exact or not at all: a group whose steps do not fit (a reflect fold inside the group, > 4x
 // magnification) stores word 0 = 0xffffffff and K1 reads its four codes from the dense table instead (on the 1080p rig
 // about one group in 300; `flags` marks the 64 x 16 pixel workgroups that hold one, for the statistics).
 __global__ __launch_bounds__(256) void pack_warp_lut_kernel(const uint32_t* lut, int lut_pitch, int tw, int th, uint2* lutc,
@@ -395,8 +403,6 @@ __global__ __launch_bounds__(256) void pack_warp_lut_kernel(const uint32_t* lut,
     const unsigned code[4] = {m.x, m.y, m.z, m.w};
     bool ok = true;
     int dx[3], dy[3];
-#pragma unroll
-    for (int j = 0; j < 4; j++) ok &= code[j] != 0xffffffffu;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         dx[j] = (int)(code[j + 1] & 0xffffu) - (int)(code[j] & 0xffffu);
@@ -442,7 +448,6 @@ __global__ __launch_bounds__(256) void build_warp_boxes_kernel(const uint32_t* l
         int xa = INT_MAX, xb = -1, ya = INT_MAX, yb = -1;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if (code[j] == 0xffffffffu) continue;
             const int xs = (int)((code[j] & 0xffffu) >> 5), ys = (int)(code[j] >> 21);
             xa = min(xa, xs); xb = max(xb, xs);
             ya = min(ya, ys); yb = max(yb, ys);
@@ -509,54 +514,27 @@ __device__ __forceinline__ void bilinear_b2(uint2 t, uint2 u, unsigned a, unsign
     r[2] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, h2), wb, 32768u, false);
 }
 
-// The per-lane body of the general kernel: marked pixels, frames or strides of any alignment.
+// The per-lane body of the general kernel: frames or strides of any alignment, dense table, global taps.
 template <int ABL>
 __device__ __forceinline__ void warp_lane_checked(const WarpCam& c, int x0, int y, uint4 mm, int v[4][3]) {
     const int stride = c.src_stride, sh1 = c.src_h - 1;
     const unsigned src_lo = (unsigned)(size_t)c.src & 3u;
+    const unsigned last = (unsigned)(sh1 * stride + 3 * c.src_w - 1);  // offset of the last byte of the frame
     const unsigned code[4] = {mm.x, mm.y, mm.z, mm.w};
     uint2 t[4], u[4];
     int fa[4], fb[4];
-    bool marked = false;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const bool mk = code[j] == 0xffffffffu;
-        const unsigned m = mk ? 0u : code[j];  // a marked pixel fetches (0,0) and is recomputed below
-        marked |= mk;
-        const unsigned mx = m & 0xffffu, my = m >> 16;
+        const unsigned mx = code[j] & 0xffffu, my = code[j] >> 16;
         fa[j] = mx & 31; fb[j] = my & 31;
-        const int xs = mx >> 5, ys = min((int)(my >> 5), sh1), ys1 = min(ys + 1, sh1);
-        t[j] = load_taps6(c.src, src_lo, (unsigned)(ys * stride) + 3 * xs);
-        u[j] = load_taps6(c.src, src_lo, (unsigned)(ys1 * stride) + 3 * xs);
+        const int xs = mx >> 5, ys = my >> 5, ys1 = min(ys + 1, sh1);
+        const unsigned ot = (unsigned)(ys * stride) + 3 * xs, ou = (unsigned)(ys1 * stride) + 3 * xs;
+        // the aligned 12-byte fetch starts up to 3 bytes before the tap and must end inside the frame
+        t[j] = ot + 12 <= last + 1 ? load_taps6(c.src, src_lo, ot) : taps6_bytes(c.src, ot, last);
+        u[j] = ou + 12 <= last + 1 ? load_taps6(c.src, src_lo, ou) : taps6_bytes(c.src, ou, last);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) bilinear_packed(t[j], u[j], fa[j], fb[j], v[j]);
-    if (marked) {
-        // rare: the bottom-right corner of the frame; project these pixels on the fly
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (code[j] == 0xffffffffu) {
-                float fx, fy;
-                map_source(c, c.m, c.colA[min(x0 + j, c.tw - 1)], c.rowB[y], fx, fy);
-                sample_bilinear_reflect<0>(c.src, c.src_w, c.src_h, stride, fx, fy, v[j]);
-            }
-    }
-}
-
-// Marked pixels of one lane (taps next to the last bytes of the frame: a handful of pixels per camera) projected on
-// the fly and stored over what the straight-line body wrote for them.  Deliberately NOT inlined: inlined, its
-// register needs would be paid by every wave of the kernel below.
-__device__ __attribute__((noinline)) void warp_fix_marked(const WarpCam* c, int x0, int y, uint4 mm) {
-    const unsigned code[4] = {mm.x, mm.y, mm.z, mm.w};
-    for (int j = 0; j < 4; j++) {
-        if (code[j] != 0xffffffffu) continue;
-        float fx, fy;
-        int v[3];
-        map_source(*c, c->m, c->colA[min(x0 + j, c->tw - 1)], c->rowB[y], fx, fy);
-        sample_bilinear_reflect<0>(c->src, c->src_w, c->src_h, c->src_stride, fx, fy, v);
-        uint8_t* d = (uint8_t*)c->dst + (size_t)y * c->dst_pitch + x0 + j;
-        for (int ch = 0; ch < 3; ch++) d[(size_t)ch * c->dst_plane] = (uint8_t)v[ch];
-    }
 }
 
 // K1, table form, the general kernel: any frame alignment, exposure gains, dense table, global taps.
@@ -711,19 +689,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             Y[j + 1] = Y[j] + (unsigned)(Eb + sbits(e.y, 17 + 6 * j, 3));
         }
     }
-    // an escaped group (a BORDER_REFLECT fold inside it, a marked pixel) reads its four codes from the dense table:
-    // one more dependent load for the waves that hold one (about one in eight)
-    uint4 mm = make_uint4(0u, 0u, 0u, 0u);
-    bool marked = false;
+    // an escaped group (a BORDER_REFLECT fold inside it) reads its four codes from the dense table: one more dependent
+    // load for the waves that hold one (about one in eight)
     if (e.x == 0xffffffffu) {
-        mm = *reinterpret_cast<const uint4*>(cg->lut + ((unsigned)y * (4u * lutc_pitch) + (unsigned)x0));
+        const uint4 mm = *reinterpret_cast<const uint4*>(cg->lut + ((unsigned)y * (4u * lutc_pitch) + (unsigned)x0));
         const unsigned code[4] = {mm.x, mm.y, mm.z, mm.w};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const bool mk = code[j] == 0xffffffffu;  // taps the box origin (or (0,0)), recomputed by warp_fix_marked
-            marked |= mk;
-            X[j] = mk ? (unsigned)bb.x << 5 : code[j] & 0xffffu;
-            Y[j] = mk ? (unsigned)bb.y << 5 : code[j] >> 16;
+            X[j] = code[j] & 0xffffu;
+            Y[j] = code[j] >> 16;
         }
     }
     uint2 t[4], u[4];
@@ -746,21 +720,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             }
         }
     } else {
-        // last aligned offset a 12-byte fetch may start at.  Row ys + 1 of a pixel on the last frame row lands beyond
-        // it and is clamped: that row always carries weight b' = 0 (see lut_axis), any readable bytes do.
-        const unsigned o_last = ((unsigned)(src_h - 1) * stride + 3u * (unsigned)src_w - 12u) & ~3u;
+        // Global taps (the box of this patch does not fit LDS or touches the end of the frame).  `o_last` is the last
+        // aligned offset a 12-byte fetch may start at; a pixel whose row ys + 1 fetch would start beyond it - the last
+        // pixels of the last rows, or row ys + 1 == src_h, which carries weight 0 - reads its taps byte by byte.
+        const unsigned last = (unsigned)(src_h - 1) * stride + 3u * (unsigned)src_w - 1u;
+        const unsigned o_last = (last + 1u - 12u) & ~3u;
+        const unsigned sh1 = (unsigned)(src_h - 1);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const unsigned ot = __umul24(Y[j] >> 5, stride) + __umul24(X[j] >> 5, 3u);
+            const unsigned ys = Y[j] >> 5;
+            const unsigned ot = __umul24(ys, stride) + __umul24(X[j] >> 5, 3u);
             const unsigned k = ot & 3u, oa = ot & ~3u;
-            const unsigned ob = min(oa + stride, o_last);
             if (ABL == 1 || ABL == 17) {  // diagnostic: no tap loads
-                t[j] = make_uint2(oa, ob); u[j] = make_uint2(ob, oa);
-            } else {
+                t[j] = make_uint2(oa, k); u[j] = make_uint2(k, oa);
+            } else if (oa + stride <= o_last) {
                 const u32x3 dt = *reinterpret_cast<const u32x3 PANO_GLOBAL*>(src + oa);
-                const u32x3 du = *reinterpret_cast<const u32x3 PANO_GLOBAL*>(src + ob);
+                const u32x3 du = *reinterpret_cast<const u32x3 PANO_GLOBAL*>(src + oa + stride);
                 t[j] = make_uint2(__builtin_amdgcn_alignbyte(dt.y, dt.x, k), __builtin_amdgcn_alignbyte(dt.z, dt.y, k));
                 u[j] = make_uint2(__builtin_amdgcn_alignbyte(du.y, du.x, k), __builtin_amdgcn_alignbyte(du.z, du.y, k));
+            } else {
+                t[j] = taps6_bytes(src, ot, last);
+                u[j] = taps6_bytes(src, ot + (ys < sh1 ? stride : 0u), last);
             }
         }
     }
@@ -776,7 +756,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         if ((ABL == 4 || ABL == 17) && pk != 0x12345678u) continue;  // diagnostic: no stores
         *reinterpret_cast<unsigned PANO_GLOBAL*>(d + (unsigned)ch * dst_plane) = pk;  // rows are padded to 16 bytes
     }
-    if (marked && ABL == 0) warp_fix_marked(cg, x0, y, mm);
 }
 
 void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hipStream_t s, hipEvent_t ev_start,
