@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         // aligned offset a 12-byte fetch may start at; a pixel whose row ys + 1 fetch would start beyond it - the last
         // pixels of the last rows, or row ys + 1 == src_h, which carries weight 0 - reads its taps byte by byte.
         const unsigned last = (unsigned)(src_h - 1) * stride + 3u * (unsigned)src_w - 1u;
-        const unsigned o_last = (last + 1u - 12u) & ~3u;
+        const unsigned o_last = last >= 11u ? (last + 1u - 12u) & ~3u : 0u;  // a frame of < 12 bytes has no such offset
         const unsigned sh1 = (unsigned)(src_h - 1);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             const unsigned k = ot & 3u, oa = ot & ~3u;
             if (ABL == 1 || ABL == 17) {  // diagnostic: no tap loads
                 t[j] = make_uint2(oa, k); u[j] = make_uint2(k, oa);
-            } else if (oa + stride <= o_last) {
+            } else if (o_last != 0u && oa + stride <= o_last) {
                 const u32x3 dt = *reinterpret_cast<const u32x3 PANO_GLOBAL*>(src + oa);
                 const u32x3 du = *reinterpret_cast<const u32x3 PANO_GLOBAL*>(src + oa + stride);
                 t[j] = make_uint2(__builtin_amdgcn_alignbyte(dt.y, dt.x, k), __builtin_amdgcn_alignbyte(dt.z, dt.y, k));
