@@ -673,3 +673,52 @@ def test_output_pointer_alignment_and_stride(pano, po, torch, c1, offset, pad):
     rows = host[offset:offset + stride * 257].reshape(257, stride)
     assert np.array_equal(rows[:, :1333 * 3].reshape(257, 1333, 3), want)
     assert (rows[:, 1333 * 3:] == 0x5A).all() and (host[:offset] == 0x5A).all() and (host[offset + stride * 257:] == 0x5A).all()
+
+
+def test_randomised_rigs_through_the_lds_warp_kernel(pano, po, torch):
+    """the same kind of seeded random rigs, but frame widths that are multiples of 16 pixels and device-resident frames:
+    these take the table kernel with LDS-staged source boxes (packed table, escapes, box fall-backs to global taps, the
+    byte-wise taps at the end of the frame) and the live rects; roll / pitch up to 25 degrees make large, skewed boxes"""
+    import math
+    rng = np.random.default_rng(77)
+    st = torch.cuda.current_stream().cuda_stream
+    done = 0
+    for case in range(30):
+        n = int(rng.integers(2, 5))
+        w, h = 16 * int(rng.integers(3, 40)), int(rng.integers(24, 300))
+        f = float(rng.uniform(0.5, 1.8)) * w
+        step = float(rng.uniform(8.0, 35.0)) * (1 if rng.random() < 0.5 else -1)
+        yaw0 = -step * (n - 1) / 2 + float(rng.uniform(-5, 5))
+        kind = int(rng.integers(0, 2))
+        bands = int(rng.integers(0, 7))
+        big = case % 4 == 0
+        K = [f, 0.0, w / 2.0 + float(rng.uniform(-5, 5)), 0.0, f * float(rng.uniform(0.95, 1.05)), h / 2.0, 0.0, 0.0, 1.0]
+        Rs = []
+        for i in range(n):
+            a = math.radians(yaw0 + i * step)
+            b = math.radians(float(rng.uniform(-25, 25) if big else rng.uniform(-6, 6)))
+            c = math.radians(float(rng.uniform(-25, 25) if big else rng.uniform(-4, 4)))
+            ry_ = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+            rx_ = np.array([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+            rz_ = np.array([[math.cos(c), -math.sin(c), 0], [math.sin(c), math.cos(c), 0], [0, 0, 1]])
+            Rs.append((ry_ @ rx_ @ rz_).astype(np.float32).reshape(9).tolist())
+        d = {"K": [K] * n, "R": Rs, "scale": f * float(rng.uniform(0.9, 1.1)), "w": w, "h": h, "n": n}
+        try:
+            ctx = make_ctx(pano, d, kind, num_bands=bands)
+        except pano.PanoError as e:
+            assert e.status == -6
+            continue
+        frames = [synth_frame(w, h, 300 + case * 8 + i) for i in range(n)]
+        ctx.build_masks_voronoi()
+        masks = [ctx.get_mask(i) for i in range(n)]
+        want, _ = po.compose(frames, d["K"], d["R"], d["scale"], masks, bands, kind=kind)
+        fd = [torch.from_numpy(fr).cuda() for fr in frames]
+        ow, oh = ctx.output_size()
+        out = torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda")
+        for rep in range(2):   # the second frame runs with the live rects of the masks
+            out.zero_()
+            ctx.compose([t.data_ptr() for t in fd], [w * 3] * n, out.data_ptr(), ow * 3, st)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want), (case, rep, n, w, h, kind, bands)
+        done += 1
+    assert done >= 18
