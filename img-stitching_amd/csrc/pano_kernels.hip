@@ -1178,18 +1178,18 @@ __device__ __forceinline__ void up_block(const unsigned q[3][2], int up[2][4]) {
 
 // store a finished 4 x 2 block: canvas level (planar int16) or, at level 0, dst_mask + convertTo(8U) + cut
 // ALLON: every pixel of the block carries weight (dst_mask set) - the caller's guarantee, no per-pixel select
-template <bool L0, bool ALLON = false>
+template <bool L0, bool ALLON = false, int NPL = 3>
 __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0, int Y0, const int v[3][2][4], bool o00,
-                                            bool o01, bool o02, bool o03, bool o10, bool o11, bool o12, bool o13) {
+                                            bool o01, bool o02, bool o03, bool o10, bool o11, bool o12, bool o13, int pb = 0) {
     if (!L0) {
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++)
+        for (int pl = 0; pl < NPL; pl++)
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 uint2 pk;
                 pk.x = ((unsigned)v[pl][r][0] & 0xffffu) | ((unsigned)v[pl][r][1] << 16);
                 pk.y = ((unsigned)v[pl][r][2] & 0xffffu) | ((unsigned)v[pl][r][3] << 16);
-                *reinterpret_cast<uint2*>(C.img[l] + (size_t)pl * C.cplane[l] + (unsigned)(__mul24(Y0 + r, C.cpitch[l]) + X0)) = pk;
+                *reinterpret_cast<uint2*>(C.img[l] + (size_t)(pb + pl) * C.cplane[l] + (unsigned)(__mul24(Y0 + r, C.cpitch[l]) + X0)) = pk;
             }
     } else {
         const bool on[2][4] = {{o00, o01, o02, o03}, {o10, o11, o12, o13}};
@@ -1224,9 +1224,14 @@ __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0
     }
 }
 
-template <bool L0, int ABL = 0>
+// NPL = 3: a lane does the three colour planes of its block.  NPL = 1 (canvas levels >= 1 only, where planes are stored
+// apart): grid.z = canvas * 3 + plane and a lane does one plane - a third of the serial work per wave, three times the
+// waves: these levels are one round of waves whose seam waves set the kernel's duration.
+template <bool L0, int ABL = 0, int NPL = 3>
 __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, CanvasSet CS, int lvl) {
-    const CanvasParams& C = CS.c[blockIdx.z];
+    static_assert(NPL == 3 || !L0, "level 0 writes interleaved BGR");
+    const int pb = NPL == 3 ? 0 : (int)(blockIdx.z % 3);  // first plane of this lane
+    const CanvasParams& C = CS.c[NPL == 3 ? blockIdx.z : blockIdx.z / 3];
     const int cam_lo = C.cam_lo, cam_n = C.cam_n;
     const int l = L0 ? 0 : lvl;
     const int cw = C.w0 >> l, ch = C.h0 >> l;
@@ -1254,12 +1259,12 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         unsigned cp[3][3][2];
         if (l < C.bands) {
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
+            for (int pl = 0; pl < NPL; pl++) {
                 if (ABL == 1) {  // diagnostic: no canvas loads
 #pragma unroll
                     for (int r = 0; r < 3; r++) cp[pl][r][0] = cp[pl][r][1] = (unsigned)(X0 + r);
                 } else {
-                    load_coarse<int16_t>(C.img[l + 1] + (size_t)pl * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1],
+                    load_coarse<int16_t>(C.img[l + 1] + (size_t)(pb + pl) * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1],
                                          X0 >> 1, Y0 >> 1, cp[pl]);
                 }
             }
@@ -1271,8 +1276,8 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
             unsigned g0[3], g1[3];
             unsigned p[3][3][2];
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
-                const uint8_t* g = c.lvl[l] + (size_t)pl * c.plane[l] + (unsigned)(__mul24(y, c.pitch[l]) + x);
+            for (int pl = 0; pl < NPL; pl++) {
+                const uint8_t* g = c.lvl[l] + (size_t)(pb + pl) * c.plane[l] + (unsigned)(__mul24(y, c.pitch[l]) + x);
                 if (ABL == 3) {  // diagnostic: no level-l tile loads
                     g0[pl] = x * 0x01010101u; g1[pl] = y * 0x01010101u;
                 } else {
@@ -1284,13 +1289,13 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
 #pragma unroll
                         for (int r = 0; r < 3; r++) p[pl][r][0] = p[pl][r][1] = (unsigned)(x + r) & 0x7f7f7f7fu;
                     } else {
-                        load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)pl * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1],
+                        load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)(pb + pl) * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1],
                                              x >> 1, y >> 1, p[pl]);
                     }
                 }
             }
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
+            for (int pl = 0; pl < NPL; pl++) {
                 int up[2][4];
                 if (l < C.bands) {
                     up_block<uint8_t>(p[pl], up);
@@ -1308,7 +1313,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
             }
         } else {
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++)
+            for (int pl = 0; pl < NPL; pl++)
 #pragma unroll
                 for (int r = 0; r < 2; r++)
 #pragma unroll
@@ -1316,7 +1321,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         }
         if (l < C.bands) {
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
+            for (int pl = 0; pl < NPL; pl++) {
                 int up[2][4];
                 up_block<int16_t>(cp[pl], up);
 #pragma unroll
@@ -1329,13 +1334,13 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         if (L0 && ucode >= 8u) {
             // an unowned block has W == 0: dst_mask is clear and the pixel is black whatever the coarser levels hold
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++)
+            for (int pl = 0; pl < NPL; pl++)
 #pragma unroll
                 for (int r = 0; r < 2; r++)
 #pragma unroll
                     for (int k = 0; k < 4; k++) v[pl][r][k] = 0;
         }
-        store_block<L0, true>(C, l, X0, Y0, v, true, true, true, true, true, true, true, true);
+        store_block<L0, true, NPL>(C, l, X0, Y0, v, true, true, true, true, true, true, true, true, pb);
         return;
     }
     if (ABL == 5) return;  // diagnostic: only the single-owner fast path
@@ -1368,8 +1373,8 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     unsigned cp[3][3][2];
     if (!L0 && l < C.bands) {
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++)
-            load_coarse<int16_t>(C.img[l + 1] + (size_t)pl * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
+        for (int pl = 0; pl < NPL; pl++)
+            load_coarse<int16_t>(C.img[l + 1] + (size_t)(pb + pl) * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
                                  Y0 >> 1, cp[pl]);
     }
     int acc[3][2][4];
@@ -1411,12 +1416,12 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         unsigned g0[3], g1[3];
         unsigned p[3][3][2];
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            const uint8_t* g = c.lvl[l] + (size_t)pl * c.plane[l] + (size_t)y * c.pitch[l] + x;
+        for (int pl = 0; pl < NPL; pl++) {
+            const uint8_t* g = c.lvl[l] + (size_t)(pb + pl) * c.plane[l] + (size_t)y * c.pitch[l] + x;
             g0[pl] = *reinterpret_cast<const unsigned*>(g);
             g1[pl] = *reinterpret_cast<const unsigned*>(g + c.pitch[l]);
             if (l < C.bands)
-                load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)pl * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1], x >> 1,
+                load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)(pb + pl) * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1], x >> 1,
                                      y >> 1, p[pl]);
         }
 #pragma unroll
@@ -1424,7 +1429,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
 #pragma unroll
             for (int k = 0; k < 4; k++) W[r][k] += w[r][k];  // + 0.f is exact
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
+        for (int pl = 0; pl < NPL; pl++) {
             int up[2][4];
             if (l < C.bands) {
                 up_block<uint8_t>(p[pl], up);
@@ -1448,8 +1453,8 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     }
     if (L0 && l < C.bands) {
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++)
-            load_coarse<int16_t>(C.img[l + 1] + (size_t)pl * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
+        for (int pl = 0; pl < NPL; pl++)
+            load_coarse<int16_t>(C.img[l + 1] + (size_t)(pb + pl) * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
                                  Y0 >> 1, cp[pl]);
     }
     // (short)(n / (1.0f + 1e-5f)) == n - sign(n) for every int16 n: the quotient lies strictly between
@@ -1462,7 +1467,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         for (int k = 0; k < 4; k++) unitW &= W[r][k] == 1.0f;
     int v[3][2][4];
 #pragma unroll
-    for (int pl = 0; pl < 3; pl++) {
+    for (int pl = 0; pl < NPL; pl++) {
         int up[2][4];
         if (l < C.bands) {
             up_block<int16_t>(cp[pl], up);
@@ -1486,7 +1491,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     for (int r = 0; r < 2; r++)
 #pragma unroll
         for (int k = 0; k < 4; k++) on[r][k] = W[r][k] > 1e-5f;
-    store_block<L0>(C, l, X0, Y0, v, on[0][0], on[0][1], on[0][2], on[0][3], on[1][0], on[1][1], on[1][2], on[1][3]);
+    store_block<L0, false, NPL>(C, l, X0, Y0, v, on[0][0], on[0][1], on[0][2], on[0][3], on[1][0], on[1][1], on[1][2], on[1][3], pb);
 }
 
 // owner map of a vector level: one byte per 4 x 2 block (see CanvasParams::owner)
@@ -1717,7 +1722,13 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
         if (l == 0 && kabl == 6) return;  // diagnostic: level 0 not launched at all
 #endif
         if (l == 0) hipLaunchKernelGGL((blend_level_vec_kernel<true, 0>), grid, block, 0, s, p, cs, l);
-        else hipLaunchKernelGGL((blend_level_vec_kernel<false, 0>), grid, block, 0, s, p, cs, l);
+        else {
+            // one plane per lane on the canvas levels >= 1 (measured: levels 1 + 2 29 -> 23 us, in flight no worse);
+            // PANO_BLEND_PLANES=0 keeps three planes per lane
+            static const bool split = !(getenv("PANO_BLEND_PLANES") && atoi(getenv("PANO_BLEND_PLANES")) == 0);
+            if (split) hipLaunchKernelGGL((blend_level_vec_kernel<false, 0, 1>), dim3(grid.x, grid.y, cs.n * 3), block, 0, s, p, cs, l);
+            else hipLaunchKernelGGL((blend_level_vec_kernel<false, 0, 3>), grid, block, 0, s, p, cs, l);
+        }
         return;
     }
     int w = 0, h = 0;
