@@ -1142,6 +1142,12 @@ __device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int 
         }
     }
 }
+// a . w for two packed int16 pairs, v_dot2_i32_i16 with an inline-constant 0 accumulator (w is a compile-time constant)
+__device__ __forceinline__ int sdot2_from_zero(unsigned a, unsigned w) {
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "s"(w));
+    return d;
+}
 // pyrUp of a 4 x 2 block from the packed 4 x 3 neighbourhood: up[0][..] = fine row Y0 (even), up[1][..] = row Y0+1.
 // Horizontal pass per coarse row: (p0 + 6 p1 + p2, 4 (p1 + p2), p1 + 6 p2 + p3, 4 (p2 + p3)) as dot products
 // (v_dot4_u32_u8 on the byte window / v_dot2_i32_i16 on the short pairs); vertical pass in 32-bit ints.
@@ -1158,11 +1164,13 @@ __device__ __forceinline__ void up_block(const unsigned q[3][2], int up[2][4]) {
             h[r][3] = (int)__builtin_amdgcn_udot4(w, 0x04040000u, 0u, false);
         } else {
             const s2_t A = __builtin_bit_cast(s2_t, q[r][0]), B = __builtin_bit_cast(s2_t, q[r][1]);
-            const s2_t c16 = {1, 6}, c04 = {0, 4}, c40 = {4, 0}, c01 = {0, 1}, c61 = {6, 1}, c44 = {4, 4};
+            const s2_t c16 = {1, 6}, c04 = {0, 4}, c01 = {0, 1};
+            // the products that start a sum use the three-operand form with an inline 0: the builtin becomes v_dot2c,
+            // whose accumulator is the destination, and costs a v_mov to zero it first
             h[r][0] = __builtin_amdgcn_sdot2(A, c16, (int)B.x, false);
-            h[r][1] = __builtin_amdgcn_sdot2(A, c04, __builtin_amdgcn_sdot2(B, c40, 0, false), false);
-            h[r][2] = __builtin_amdgcn_sdot2(A, c01, __builtin_amdgcn_sdot2(B, c61, 0, false), false);
-            h[r][3] = __builtin_amdgcn_sdot2(B, c44, 0, false);
+            h[r][1] = __builtin_amdgcn_sdot2(A, c04, sdot2_from_zero(q[r][1], 0x00000004u), false);  // B . (4, 0)
+            h[r][2] = __builtin_amdgcn_sdot2(A, c01, sdot2_from_zero(q[r][1], 0x00010006u), false);  // B . (6, 1)
+            h[r][3] = sdot2_from_zero(q[r][1], 0x00040004u);                                         // B . (4, 4)
         }
     }
     // No saturate_cast here: it cannot trigger.  Camera planes are 8-bit (h <= 8*255), and a collapsed canvas level
