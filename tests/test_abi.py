@@ -130,10 +130,18 @@ def test_errors_and_no_cpu_fallback(pano, c1):
     # every compute entry refuses on a plan-only context: PANO_ENODEVICE, never a host computation
     for fn in (lambda: ctx.compose_host(c1["frames"]), lambda: ctx.build_masks_voronoi(),
                lambda: ctx.set_mask(0, np.zeros((254, 422), np.uint8)), lambda: ctx.blend(0, 0),
-               lambda: ctx.warp(0, 0, 0, 0, 0), lambda: ctx.pyramid_slots(), lambda: ctx.debug_level(0, 0)):
+               lambda: ctx.warp(0, 0, 0, 0, 0), lambda: ctx.pyramid_slots(), lambda: ctx.debug_level(0, 0),
+               lambda: ctx.set_frame_slots(2), lambda: ctx.select_frame_slot(0)):
         with pytest.raises(pano.PanoError) as e:
             fn()
         assert e.value.status == -5
+    # the plan-side queries work without a device: before any mask exists every pixel of every level is live
+    (tx, ty, tw, th), _ = ctx.feed_tile(0)
+    assert ctx.live_rect(0, 0) == (0, 0, tw, th) and ctx.live_rect(0, 2) == (0, 0, tw >> 2, th >> 2)
+    for bad in ((9, 0), (0, 9), (-1, 0)):
+        with pytest.raises(pano.PanoError) as e:
+            ctx.live_rect(*bad)
+        assert e.value.status == -2
 
 
 def test_full_ring_is_rejected(pano):
