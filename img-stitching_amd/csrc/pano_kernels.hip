@@ -577,7 +577,9 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_checked_kernel(WarpParams 
 // together with the table load, and reads the taps from LDS.
 // Workgroups whose box does not fit keep the global taps.  Needs 4-byte aligned frames and strides % 16 == 0
 // (checked by the launcher; anything else runs warp_tiles_lut_checked_kernel).
-template <int ABL>
+// GAIN: an instantiation of its own that also applies the exposure gain maps (BlocksGainCompensator::apply) of the
+// cameras that carry one; the plain instantiation stays at 37 VGPRs.
+template <int ABL, bool GAIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void warp_tiles_lut_kernel(WarpParams P) {
     __shared__ uint4 sbox[kBoxBytes / 16];
     // grid = (ncam, ceil(tw/64), ceil(th/16)): the camera is the FASTEST workgroup coordinate.  Linear workgroup ids
@@ -747,6 +749,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     unsigned r[4][3];
 #pragma unroll
     for (int j = 0; j < 4; j++) bilinear_b2(t[j], u[j], X[j] & 31u, Y[j] & 31u, r[j]);
+    if (GAIN && cg->gain != nullptr) {  // per camera: workgroup-uniform
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int v[3] = {(int)(r[j][0] >> 16), (int)(r[j][1] >> 16), (int)(r[j][2] >> 16)};
+            apply_gain(*cg, min(x0 + j, tw - 1), y, v);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) r[j][ch] = (unsigned)v[ch] << 16;
+        }
+    }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         // byte 2 of r[0..3][ch] -> bytes 0..3
@@ -786,12 +797,14 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
         else hipLaunchKernelGGL(K, G, block, 0, s, p);                                        \
     } while (0)
     if (all_lut) {
-        // the LDS kernel wants 4-byte aligned frames, strides % 16 == 0 and no exposure gains; anything else takes the
-        // general kernel (same table, global taps, per-pixel checked body)
+        // the LDS kernel wants 4-byte aligned frames and strides % 16 == 0; anything else takes the general kernel (same
+        // table, global taps, per-pixel checked body)
         bool fast = true;
         for (int i = 0; i < ncam; i++)
-            fast &= ((size_t)p.cam[i].src & 3u) == 0 && (p.cam[i].src_stride & 15) == 0 && p.cam[i].gain == nullptr &&
-                    p.cam[i].lutc != nullptr && p.cam[i].box != nullptr;
+            fast &= ((size_t)p.cam[i].src & 3u) == 0 && (p.cam[i].src_stride & 15) == 0 && p.cam[i].lutc != nullptr &&
+                    p.cam[i].box != nullptr;
+        bool gains = false;
+        for (int i = 0; i < ncam; i++) gains |= p.cam[i].gain != nullptr;
 #ifdef PANO_DIAG
         static const int labl = getenv("PANO_LUT_ABL") ? atoi(getenv("PANO_LUT_ABL")) : 0;
         if (fast) switch (labl) {
@@ -805,7 +818,8 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
             default: break;
         }
 #endif
-        if (fast) PANO_LAUNCH_K1(warp_tiles_lut_kernel<0>, grid_lut);
+        if (fast && gains) PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, true>), grid_lut);
+        else if (fast) PANO_LAUNCH_K1(warp_tiles_lut_kernel<0>, grid_lut);
         else PANO_LAUNCH_K1(warp_tiles_lut_checked_kernel<0>, grid_lut);
     }
     else {
