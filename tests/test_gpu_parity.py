@@ -722,3 +722,25 @@ def test_randomised_rigs_through_the_lds_warp_kernel(pano, po, torch):
             assert np.array_equal(out.cpu().numpy(), want), (case, rep, n, w, h, kind, bands)
         done += 1
     assert done >= 18
+
+
+def test_largest_frames_the_remap_table_takes(pano, po, torch):
+    """2048 x 2048 is the largest frame the 11-bit tap indices of the remap table address (larger frames use the
+    projecting kernel): 2048-wide frames exercise xs = 2047 and the last bytes of the frame on the table path"""
+    d = c2_group(w=2048, h=1152, f=1069.0)
+    d = {**d, "n": 2, "K": d["K"][:2], "R": d["R"][1:3]}
+    ctx = make_ctx(pano, d, 0, num_bands=4)
+    ctx.build_masks_voronoi()
+    masks = [ctx.get_mask(i) for i in range(2)]
+    frames = [synth_frame(d["w"], d["h"], 77 + i) for i in range(2)]
+    want, _ = po.compose(frames, d["K"], d["R"], d["scale"], masks, 4)
+    fd = [torch.from_numpy(f).cuda() for f in frames]
+    ow, oh = ctx.output_size()
+    out = torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda")
+    for rep in range(2):
+        out.zero_()
+        ctx.compose([t.data_ptr() for t in fd], [d["w"] * 3] * 2, out.data_ptr(), ow * 3, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want), rep
+    stats = ctx.warp_table_stats()
+    assert stats["table_bytes"] > 0 and stats["blocks"] > 0      # the table path, not the projecting kernel
