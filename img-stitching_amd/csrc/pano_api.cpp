@@ -69,7 +69,7 @@ struct pano_ctx {
     double newK[kMaxCams][9] = {};
     FrontEndDev* d_fe[kMaxCams] = {};
     int frame_w = 0, frame_h = 0;   // size of the frames pano_compose takes (raw size with a front end)
-    uint32_t* lut[kMaxCams] = {};   // static remap tables of K1 (frames <= 2048 x 2048)
+    uint32_t* lut[kMaxCams] = {};   // static remap tables of K1 (dense form, codes relative to the workgroup's source box)
     int lut_pitch[kMaxCams] = {};
     uint2* lutc[kMaxCams] = {};         // packed form of lut (8 bytes per 4 pixels), read by unflagged workgroups
     int4* box[kMaxCams] = {};           // source box of every 64x16-pixel workgroup of K1
@@ -625,7 +625,7 @@ pano_status pano_set_undistort(pano_ctx* c, int cam, const pano_undistort* u) {
         u->rect[0] < 0 || u->rect[1] < 0 || u->rect[0] + u->rect[2] > u->undist_w || u->rect[1] + u->rect[3] > u->undist_h ||
         !(u->K[0] > 0) || !(u->K[4] > 0))
         return fail(c, PANO_EINVAL, "undistort parameters");
-    if (u->raw_w > 2048 || u->raw_h > 2048) return fail(c, PANO_EINVAL, "front end needs raw frames <= 2048 x 2048");
+    if (u->raw_w > 8192 || u->raw_h > 8192) return fail(c, PANO_EINVAL, "front end needs raw frames <= 8192 x 8192");
     c->und[cam] = *u;
     optimalNewCameraMatrix(u->K, u->dist, u->undist_w, u->undist_h, c->newK[cam]);
     c->have_fe[cam] = true;
@@ -766,23 +766,34 @@ pano_status pano_prepare(pano_ctx* c) {
             if (us != PANO_OK) return us;
         }
     // static remap tables of the warp (K1): the projection of every tile pixel is fixed from here on.
-    // PANO_WARP_ON_THE_FLY=1 keeps the projecting kernel (also what frames beyond 2048 x 2048 use).
+    // PANO_WARP_ON_THE_FLY=1 keeps the projecting kernel (also what frames beyond 8192 x 8192 use).
     // hipGraph replay of the frame is opt-in (PANO_GRAPH=1): measured on MI355X the 12 stream-ordered launches
     // of a frame run 3 % faster than the replayed graph (0.268 vs 0.276 ms per 8-camera panorama) - the GPU,
     // not the host, is the limiter
     c->use_graph = getenv("PANO_GRAPH") && atoi(getenv("PANO_GRAPH"));
-    c->use_lut = c->frame_w <= 2048 && c->frame_h <= 2048 && !(getenv("PANO_WARP_ON_THE_FLY") && atoi(getenv("PANO_WARP_ON_THE_FLY")));
+    // the codes are relative to each workgroup's source box, so the frame size does not limit the table; 8192 keeps the
+    // byte offsets of a frame inside 24-bit multiplies
+    c->use_lut = c->frame_w <= 8192 && c->frame_h <= 8192 && !(getenv("PANO_WARP_ON_THE_FLY") && atoi(getenv("PANO_WARP_ON_THE_FLY")));
     if (c->use_lut) {
-        for (int i = 0; i < n; i++) {
-            const FeedTile& t = P.tile[i];
-            c->lut_pitch[i] = (int)align_up((size_t)t.rect.w, 8);
-            HIP_TRY(c, hipMalloc((void**)&c->lut[i], (size_t)c->lut_pitch[i] * t.rect.h * sizeof(uint32_t)));
-            WarpCam w = make_warp_cam(c, i, nullptr, (size_t)c->frame_w * 3, false);
-            launch_build_warp_lut(w, c->lut[i], c->lut_pitch[i], nullptr);
-        }
+        bool too_wide = false;
         for (int i = 0; i < n; i++) {
             const FeedTile& t = P.tile[i];
             const size_t nb = (size_t)((t.rect.w + 63) / 64) * ((t.rect.h + 15) / 16);
+            c->lut_pitch[i] = (int)align_up((size_t)t.rect.w, 8);
+            HIP_TRY(c, hipMalloc((void**)&c->lut[i], (size_t)c->lut_pitch[i] * t.rect.h * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void**)&c->box[i], nb * sizeof(int4)));
+            unsigned* d_cnt = nullptr;
+            HIP_TRY(c, hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned)));
+            HIP_TRY(c, hipMemset(d_cnt, 0, 2 * sizeof(unsigned)));
+            // table and boxes are in pixels of the frame K1 samples (the RAW frame when a front end is set)
+            WarpCam w = make_warp_cam(c, i, nullptr, (size_t)c->frame_w * 3, false);
+            launch_build_warp_table(w, c->lut[i], c->lut_pitch[i], c->box[i], d_cnt, nullptr);
+            unsigned h_cnt[2] = {0, 0};
+            hipError_t ce = hipMemcpy(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost);
+            (void)hipFree(d_cnt);
+            HIP_TRY(c, ce);
+            c->box_global[i] = h_cnt[0];
+            too_wide |= h_cnt[1] != 0;
             const int gp = c->lut_pitch[i] / 4;
             HIP_TRY(c, hipMalloc((void**)&c->k1_flags[i], nb * sizeof(uint32_t)));
             HIP_TRY(c, hipMemset(c->k1_flags[i], 0, nb * sizeof(uint32_t)));
@@ -793,17 +804,11 @@ pano_status pano_prepare(pano_ctx* c) {
             c->k1_blocks[i] = (long long)nb;
             c->k1_flagged[i] = 0;
             for (uint32_t f : hf) c->k1_flagged[i] += f != 0;
-            unsigned* d_cnt = nullptr;
-            HIP_TRY(c, hipMalloc((void**)&d_cnt, sizeof(unsigned)));
-            HIP_TRY(c, hipMemset(d_cnt, 0, sizeof(unsigned)));
-            HIP_TRY(c, hipMalloc((void**)&c->box[i], nb * sizeof(int4)));
-            // boxes are in pixels of the frame K1 samples (the RAW frame when a front end is set), like the table
-            launch_build_warp_boxes(c->lut[i], c->lut_pitch[i], t.rect.w, t.rect.h, c->frame_w, c->frame_h, c->box[i], d_cnt, nullptr);
-            unsigned h_cnt = 0;
-            hipError_t ce = hipMemcpy(&h_cnt, d_cnt, sizeof(unsigned), hipMemcpyDeviceToHost);
-            (void)hipFree(d_cnt);
-            HIP_TRY(c, ce);
-            c->box_global[i] = h_cnt;
+        }
+        if (too_wide) {
+            // a 64 x 16 patch that spans 2048 source pixels (a projection that magnifies 32 x): no table for this rig
+            for (int i = 0; i < n; i++) { dfree(c->lut[i]); dfree(c->lutc[i]); dfree(c->box[i]); dfree(c->k1_flags[i]); }
+            c->use_lut = false;
         }
         HIP_TRY(c, hipDeviceSynchronize());
     }

@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
 // (xs, ys) = the smaller reflected tap index, a'/b' = weight of tap xs+1 / row ys+1 in 1/32:
 //   taps increasing (x1 == x0 + 1): a' = a;  mirrored (x1 == x0 - 1): a' = 32 - a;  same pixel: a' = 0;
 //   a' == 32 is stored as (xs + 1, 0), which weighs the same pixel.
-// 0xffffffff marks the few pixels this cannot express (a tap fetch that would run past the end of the
-// frame); they are projected on the fly.  Needs frame sides <= 2048 (16 bits per axis).
+// xs, ys are relative to the origin of the source box of the pixel's 64 x 16 workgroup (build_warp_table_kernel), so 11
+// bits per axis serve frames of any size.  Every pixel has a code; 0xffffffff does not occur.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lut_axis(int i0, int n, int frac, int& base, int& w1) {
     // BORDER_REFLECT maps neighbouring indices to neighbouring or equal ones: r1 - r0 is -1, 0 or +1
@@ -360,29 +360,73 @@ __device__ __forceinline__ void lut_axis(int i0, int n, int frac, int& base, int
     else { base = r0; w1 = 0; }
     if (w1 == 32) { base += 1; w1 = 0; }
 }
-__global__ __launch_bounds__(256) void build_warp_lut_kernel(WarpCam c, uint32_t* lut, int lut_pitch) {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= lut_pitch || y >= c.th) return;
-    uint32_t code;
-    {
-        // the pad columns (x >= tw, never read downstream) repeat the last pixel so that they compress like it
-        float fx, fy;
-        map_source(c, c.m, c.colA[min(x, c.tw - 1)], c.rowB[y], fx, fy);
-        const int isx = cv_round_dev(fx * 32.f), isy = cv_round_dev(fy * 32.f);
-        const int ix = sat16i(isx >> 5), iy = sat16i(isy >> 5);
-        int xs, a1, ys, b1;
-        lut_axis(ix, c.src_w, isx & 31, xs, a1);
-        lut_axis(iy, c.src_h, isy & 31, ys, b1);
-        // Every pixel has a code (0 <= xs < src_w, 0 <= ys < src_h; 0xffffffff cannot occur: a base on the last column
-        // or row always carries weight 0).  What the table does NOT promise is that an aligned 12-byte fetch at (xs, ys)
-        // stays inside the frame: the kernels check that themselves for the last bytes of the frame.
-        code = (uint32_t)(xs * 32 + a1) | ((uint32_t)(ys * 32 + b1) << 16);
+// Source boxes.  The table is static, so the set of frame pixels a 64 x 16 pixel workgroup of K1 taps is static too.
+// Its bounding box does two jobs:
+//   * the codes of the table are stored RELATIVE to the box origin (xs - xmin, ys - ymin): 11 bits per axis are then
+//     enough for any frame size (a 64 x 16 patch never spans 2048 source pixels), so 4K frames take the table path;
+//   * K1 copies the box into LDS and reads the taps there (see warp_tiles_lut_kernel).
+// Box entry: {xmin, ymin, rows << 8 | 16-byte chunks per row, ceil(2^16 / chunks)}.  Boxes that do not fit kBoxBytes (far
+// outside the frame, where BORDER_REFLECT folds pile up) or that would read past the last bytes of the frame get
+// rows == 0 and tap global memory instead; the origin is valid either way.
+constexpr int kBoxBytes = 16 * 1024;             // LDS per workgroup, one spare row included
+constexpr int kBoxIters = kBoxBytes / 16 / 256;  // 16-byte chunk loads per lane, at most
+__global__ __launch_bounds__(256) void build_warp_table_kernel(WarpCam c, uint32_t* lut, int lut_pitch, int4* boxes, int gx,
+                                                               unsigned* counters /* [0] boxes without LDS, [1] spans too wide */) {
+    __shared__ int lim[4];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if (tid == 0) { lim[0] = INT_MAX; lim[1] = -1; lim[2] = INT_MAX; lim[3] = -1; }
+    __syncthreads();
+    const int x0 = (blockIdx.x * 16 + (threadIdx.x & 15)) * 4;
+    const int y = blockIdx.y * 16 + threadIdx.y * 4 + (threadIdx.x >> 4);
+    const bool in = x0 < lut_pitch && y < c.th;  // the pad columns (x >= tw, never read downstream) repeat the last pixel
+    int xs[4], a1[4], ys[4], b1[4];
+    if (in) {
+        int xa = INT_MAX, xb = -1, ya = INT_MAX, yb = -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float fx, fy;
+            map_source(c, c.m, c.colA[min(x0 + j, c.tw - 1)], c.rowB[y], fx, fy);
+            const int isx = cv_round_dev(fx * 32.f), isy = cv_round_dev(fy * 32.f);
+            const int ix = sat16i(isx >> 5), iy = sat16i(isy >> 5);
+            lut_axis(ix, c.src_w, isx & 31, xs[j], a1[j]);
+            lut_axis(iy, c.src_h, isy & 31, ys[j], b1[j]);
+            xa = min(xa, xs[j]); xb = max(xb, xs[j]);
+            ya = min(ya, ys[j]); yb = max(yb, ys[j]);
+        }
+        atomicMin(&lim[0], xa); atomicMax(&lim[1], xb);
+        atomicMin(&lim[2], ya); atomicMax(&lim[3], yb);
     }
-    lut[(size_t)y * lut_pitch + x] = code;
+    __syncthreads();
+    const int xmin = lim[0], ymin = lim[2];
+    if (in) {
+        // Every pixel has a code (0xffffffff cannot occur: a base on the last column or row of the frame carries weight 0).
+        // What the table does NOT promise is that an aligned 12-byte fetch at (xs, ys) stays inside the frame: the
+        // kernels check that themselves for the last bytes of the frame.
+        unsigned code[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            code[j] = (uint32_t)((xs[j] - xmin) * 32 + a1[j]) | ((uint32_t)((ys[j] - ymin) * 32 + b1[j]) << 16);
+        *reinterpret_cast<uint4*>(lut + (size_t)y * lut_pitch + x0) = make_uint4(code[0], code[1], code[2], code[3]);
+    }
+    if (tid != 0 || lim[1] < 0) return;
+    const int sw = c.src_w, sh = c.src_h;
+    if (lim[1] - xmin >= 2048 || lim[3] - ymin >= 2048) atomicAdd(&counters[1], 1u);  // 11 bits per axis do not hold this patch
+    // rows ymin .. min(ymax + 1, sh - 1) are loaded; the taps of row ymax + 1 == sh (weight 0) read the spare row
+    const int h = min(lim[3] + 1, sh - 1) - ymin + 1;
+    // bytes 3*xmin .. 3*xmax+5 of each row, fetched from the enclosing 16-byte boundary (phase <= 15); the
+    // realigning tap read touches up to 6 bytes more (the first bytes of the next row)
+    const int cpr = (3 * (lim[1] - xmin) + 21 + 15) / 16;
+    // LDS rows are packed at cpr * 16 bytes: a tap read may run a few bytes into the next row, the taps of the spare
+    // row read whatever follows the box, and the last wave's copy rounds the box up to 64 chunks
+    bool ok = (h + 1) * cpr * 16 + 16 <= kBoxBytes && cpr <= 63 && (h * cpr + 63) / 64 * 64 * 16 <= kBoxBytes;
+    // the chunks of the last frame row must end inside the frame
+    ok &= !(ymin + h - 1 == sh - 1 && 3 * xmin + cpr * 16 > 3 * sw);
+    if (!ok) atomicAdd(&counters[0], 1u);
+    boxes[blockIdx.y * gx + blockIdx.x] = ok ? make_int4(xmin, ymin, (h << 8) | cpr, (65536 + cpr - 1) / cpr) : make_int4(xmin, ymin, 0, 0);
 }
-void launch_build_warp_lut(const WarpCam& c, uint32_t* lut, int lut_pitch, hipStream_t s) {
-    dim3 block(64, 4, 1), grid((lut_pitch + 63) / 64, (c.th + 3) / 4, 1);
-    hipLaunchKernelGGL(build_warp_lut_kernel, grid, block, 0, s, c, lut, lut_pitch);
+void launch_build_warp_table(const WarpCam& c, uint32_t* lut, int lut_pitch, int4* boxes, unsigned* counters, hipStream_t s) {
+    dim3 block(64, 4, 1), grid((lut_pitch + 63) / 64, (c.th + 15) / 16, 1);
+    hipLaunchKernelGGL(build_warp_table_kernel, grid, block, 0, s, c, lut, lut_pitch, boxes, (c.tw + 63) / 64, counters);
 }
 
 // Packed table.  The map is smooth, so inside a 4-pixel group the steps between neighbouring codes are a group
@@ -428,62 +472,6 @@ void launch_pack_warp_lut(const uint32_t* lut, int lut_pitch, int tw, int th, ui
 }
 __device__ __forceinline__ int sbits(unsigned w, int off, int n) { return (int)(w << (32 - off - n)) >> (32 - n); }
 
-// Source boxes.  The table is static, so the set of frame bytes a 64 x 16 pixel workgroup of K1 taps is static too:
-// its bounding box {xmin, ymin, rows << 8 | 16-byte chunks per row, ceil(2^16 / chunks)} is computed once here.
-// Boxes that do not fit kBoxBytes (far outside the frame, where BORDER_REFLECT folds pile up), that would read past
-// the last bytes of the frame, or workgroups without a valid pixel get rows == 0 and tap global memory instead.
-constexpr int kBoxBytes = 16 * 1024;            // LDS per workgroup, one spare row included
-constexpr int kBoxIters = kBoxBytes / 16 / 256;  // 16-byte chunk loads per lane, at most
-__global__ __launch_bounds__(256) void build_warp_boxes_kernel(const uint32_t* lut, int lut_pitch, int tw, int th, int sw,
-                                                               int sh, int4* boxes, int gx, unsigned* fallback) {
-    __shared__ int lim[4];
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    if (tid == 0) { lim[0] = INT_MAX; lim[1] = -1; lim[2] = INT_MAX; lim[3] = -1; }
-    __syncthreads();
-    const int x0 = (blockIdx.x * 16 + (threadIdx.x & 15)) * 4;
-    const int y = blockIdx.y * 16 + threadIdx.y * 4 + (threadIdx.x >> 4);
-    if (x0 < tw && y < th) {
-        const uint4 m = *reinterpret_cast<const uint4*>(lut + (size_t)y * lut_pitch + x0);
-        const unsigned code[4] = {m.x, m.y, m.z, m.w};
-        int xa = INT_MAX, xb = -1, ya = INT_MAX, yb = -1;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int xs = (int)((code[j] & 0xffffu) >> 5), ys = (int)(code[j] >> 21);
-            xa = min(xa, xs); xb = max(xb, xs);
-            ya = min(ya, ys); yb = max(yb, ys);
-        }
-        if (xb >= 0) {
-            atomicMin(&lim[0], xa); atomicMax(&lim[1], xb);
-            atomicMin(&lim[2], ya); atomicMax(&lim[3], yb);
-        }
-    }
-    __syncthreads();
-    if (tid != 0) return;
-    int4 box = make_int4(0, 0, 0, 0);
-    if (lim[1] >= 0) {
-        const int xmin = lim[0], ymin = lim[2];
-        // rows ymin .. min(ymax + 1, sh - 1) are loaded; the taps of row ymax + 1 == sh (weight 0) read the spare row
-        const int h = min(lim[3] + 1, sh - 1) - ymin + 1;
-        // bytes 3*xmin .. 3*xmax+5 of each row, fetched from the enclosing 16-byte boundary (phase <= 15); the
-        // realigning tap read touches up to 6 bytes more (the first bytes of the next row)
-        const int cpr = (3 * (lim[1] - xmin) + 21 + 15) / 16;
-        // LDS rows are packed at cpr * 16 bytes: a tap read may run a few bytes into the next row, the taps of the spare
-        // row read whatever follows the box, and the last wave's copy rounds the box up to 64 chunks
-        bool ok = (h + 1) * cpr * 16 + 16 <= kBoxBytes && cpr <= 63 && (h * cpr + 63) / 64 * 64 * 16 <= kBoxBytes;
-        // the chunks of the last frame row must end inside the frame
-        ok &= !(ymin + h - 1 == sh - 1 && 3 * xmin + cpr * 16 > 3 * sw);
-        if (ok) box = make_int4(xmin, ymin, (h << 8) | cpr, (65536 + cpr - 1) / cpr);
-    }
-    if (box.z == 0 && fallback) atomicAdd(fallback, 1u);
-    boxes[blockIdx.y * gx + blockIdx.x] = box;
-}
-void launch_build_warp_boxes(const uint32_t* lut, int lut_pitch, int tw, int th, int sw, int sh, int4* boxes,
-                             unsigned* fallback, hipStream_t s) {
-    dim3 block(64, 4, 1), grid((tw + 63) / 64, (th + 15) / 16, 1);
-    hipLaunchKernelGGL(build_warp_boxes_kernel, grid, block, 0, s, lut, lut_pitch, tw, th, sw, sh, boxes, (int)grid.x,
-                       fallback);
-}
-
 // v_pk_mul_lo_u16 / v_pk_mad_u16 with the SAME half of the weight register feeding both 16-bit lanes (op_sel), so a
 // weight pair (32-a) | a << 16 serves both products without being splatted first.
 __device__ __forceinline__ unsigned pk_mul_whi(unsigned x, unsigned w) {
@@ -516,7 +504,7 @@ __device__ __forceinline__ void bilinear_b2(uint2 t, uint2 u, unsigned a, unsign
 
 // The per-lane body of the general kernel: frames or strides of any alignment, dense table, global taps.
 template <int ABL>
-__device__ __forceinline__ void warp_lane_checked(const WarpCam& c, int x0, int y, uint4 mm, int v[4][3]) {
+__device__ __forceinline__ void warp_lane_checked(const WarpCam& c, int x0, int y, uint4 mm, int ox, int oy, int v[4][3]) {
     const int stride = c.src_stride, sh1 = c.src_h - 1;
     const unsigned src_lo = (unsigned)(size_t)c.src & 3u;
     const unsigned last = (unsigned)(sh1 * stride + 3 * c.src_w - 1);  // offset of the last byte of the frame
@@ -527,7 +515,7 @@ __device__ __forceinline__ void warp_lane_checked(const WarpCam& c, int x0, int 
     for (int j = 0; j < 4; j++) {
         const unsigned mx = code[j] & 0xffffu, my = code[j] >> 16;
         fa[j] = mx & 31; fb[j] = my & 31;
-        const int xs = mx >> 5, ys = my >> 5, ys1 = min(ys + 1, sh1);
+        const int xs = ox + (int)(mx >> 5), ys = oy + (int)(my >> 5), ys1 = min(ys + 1, sh1);  // codes are relative to the box origin
         const unsigned ot = (unsigned)(ys * stride) + 3 * xs, ou = (unsigned)(ys1 * stride) + 3 * xs;
         // the aligned 12-byte fetch starts up to 3 bytes before the tap and must end inside the frame
         t[j] = ot + 12 <= last + 1 ? load_taps6(c.src, src_lo, ot) : taps6_bytes(c.src, ot, last);
@@ -547,8 +535,9 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_checked_kernel(WarpParams 
     const int y = by * 16 + threadIdx.y * 4 + (threadIdx.x >> 4);
     if (x0 >= c.tw || y >= c.th) return;
     const uint4 mm = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0);
+    const int4 bb = c.box[by * ((c.tw + 63) >> 6) + bx];
     int v[4][3];
-    warp_lane_checked<ABL>(c, x0, y, mm, v);
+    warp_lane_checked<ABL>(c, x0, y, mm, bb.x, bb.y, v);
     if (c.gain) {
 #pragma unroll
         for (int j = 0; j < 4; j++) apply_gain(c, min(x0 + j, c.tw - 1), y, v[j]);
@@ -704,13 +693,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
     uint2 t[4], u[4];
     if (bh) {
-        // LDS byte offset of pixel (xs, ys): (ys - ymin) * lpitch + 3 * (xs - xmin) + ph.  Three aligned dwords and
+        // LDS byte offset of a pixel: (ys - ymin) * lpitch + 3 * (xs - xmin) + ph.  Three aligned dwords and
         // v_alignbyte, like the global taps: 8-byte ds reads at odd addresses work but run the kernel at half speed.
-        const unsigned cst = ph - (unsigned)bb.y * lpitch - 3u * (unsigned)bb.x;
         const unsigned* sb = reinterpret_cast<const unsigned*>(sbox);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const unsigned off = __umul24(Y[j] >> 5, lpitch) + __umul24(X[j] >> 5, 3u) + cst;
+            const unsigned off = __umul24(Y[j] >> 5, lpitch) + __umul24(X[j] >> 5, 3u) + ph;  // codes are box relative
             const unsigned k = off & 3u;
             const unsigned* wt = sb + (off >> 2);
             const unsigned* wu = wt + (lpitch >> 2);  // row ys + 1; for ys == sh - 1 (weight 0) the spare row
@@ -730,8 +718,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         const unsigned sh1 = (unsigned)(src_h - 1);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const unsigned ys = Y[j] >> 5;
-            const unsigned ot = __umul24(ys, stride) + __umul24(X[j] >> 5, 3u);
+            const unsigned ys = (Y[j] >> 5) + (unsigned)bb.y;
+            const unsigned ot = __umul24(ys, stride) + __umul24((X[j] >> 5) + (unsigned)bb.x, 3u);
             const unsigned k = ot & 3u, oa = ot & ~3u;
             if (ABL == 1 || ABL == 17) {  // diagnostic: no tap loads
                 t[j] = make_uint2(oa, k); u[j] = make_uint2(k, oa);
@@ -788,7 +776,7 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
     // fetched bytes to the minimum and both ran slower (23.8 / 27.1 us vs 21.8 us per 4-camera launch): concentrating
     // an XCD on a narrow address range loses more in channel spread than the L2 reuse gains.  What ships is one camera
     // per XCD (the camera is the fastest grid coordinate), which gets the same minimum without that cost.
-    // the table form needs every camera of the launch to carry a table (frames <= 2048 x 2048)
+    // the table form needs every camera of the launch to carry a table
     bool all_lut = true;
     for (int i = 0; i < ncam; i++) all_lut &= p.cam[i].lut != nullptr;
 #define PANO_LAUNCH_K1(K, G)                                                                   \

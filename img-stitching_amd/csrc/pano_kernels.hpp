@@ -23,7 +23,8 @@ struct alignas(64) WarpCam {
     const uint8_t* src;   // BGR8 interleaved frame
     void* dst;            // pipeline: plane B of the level-0 tile (planar u8); stage warp: uint8x3 image
     const uint2* lutc;    // packed remap table, 8 bytes per 4-pixel group (see pack_warp_lut_kernel)
-    const int4* box;      // per 64x16-pixel workgroup: its source box {xmin, ymin, rows<<8 | chunks, ceil(2^16/chunks)}
+    const int4* box;      // per 64x16-pixel workgroup: its source box {xmin, ymin, rows<<8 | chunks, ceil(2^16/chunks)};
+                          // the codes of lut / lutc are relative to (xmin, ymin)
     int tw, th;           // tile width/height in pixels
     // Blocks of 64 x 16 tile pixels (inclusive block coordinates) that anything downstream ever reads (see
     // pano_api.cpp live_rects): the K1 grid is laid over them.  {0, 0} .. {INT_MAX, INT_MAX} = everything.
@@ -104,10 +105,9 @@ struct CanvasSet {
 // ev_start/ev_stop (optional) receive the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL)
 void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hipStream_t s,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-// builds the static remap table of one camera tile (run once per pano_prepare)
-void launch_build_warp_lut(const WarpCam& c, uint32_t* lut, int lut_pitch, hipStream_t s);
-void launch_build_warp_boxes(const uint32_t* lut, int lut_pitch, int tw, int th, int sw, int sh, int4* boxes,
-                             unsigned* fallback, hipStream_t s);
+// builds the static remap table and the source boxes of one camera tile (run once per pano_prepare);
+// counters[0] = workgroups whose box does not fit LDS, counters[1] = workgroups whose source span does not fit the code
+void launch_build_warp_table(const WarpCam& c, uint32_t* lut, int lut_pitch, int4* boxes, unsigned* counters, hipStream_t s);
 void launch_pack_warp_lut(const uint32_t* lut, int lut_pitch, int tw, int th, uint2* lutc, int lutc_pitch, uint32_t* flags,
                           hipStream_t s);
 // stage entry: plain RotationWarper::warp to an 8UC3 image

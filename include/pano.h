@@ -118,7 +118,7 @@ pano_status pano_get_mask(pano_ctx* ctx, int i, uint8_t* h_mask, size_t stride);
  * (raw_w x raw_h) and the warp kernel samples them through the composed coordinate map of those five steps and the
  * projection - one bilinear tap set per panorama pixel, no intermediate images.  (A different resampling from the
  * reference's cubic + three bilinear passes: parity for this entry is defined against the fused map, DESIGN.md.)
- * Call before pano_prepare, for every camera or for none; all cameras share raw_w x raw_h <= 2048 x 2048. */
+ * Call before pano_prepare, for every camera or for none; all cameras share raw_w x raw_h <= 8192 x 8192. */
 typedef struct pano_undistort {
     int raw_w, raw_h;        /* stCamCfg.camSrcWidth/Height: the frames handed to pano_compose */
     int undist_w, undist_h;  /* stCamCfg.undistoredWidth/Height */

@@ -163,7 +163,7 @@ def test_new_camera_matrix_matches_oracle(pano, po, rig_r):
     ctx.set_undistort(0, (1920, 1080), (960, 540), K, dist, (70, 66, 885, 410))
     assert ctx.new_camera_matrix(0) == po.optimal_new_camera_matrix(K, dist, 960, 540)
     with pytest.raises(pano.PanoError):
-        ctx.set_undistort(1, (4096, 2160), (960, 540), K, dist, (70, 66, 885, 410))   # raw frame too large for the table
+        ctx.set_undistort(1, (8200, 2160), (960, 540), K, dist, (70, 66, 885, 410))   # raw frame too large for the table
     ctx.set_cameras_from_list(",".join(repr(v) for v in rig_r["stitchers"][0]["cams"]))
     with pytest.raises(pano.PanoError):
         ctx.prepare()                                                                  # front end on one camera only

@@ -457,9 +457,10 @@ def test_streaming_slots(pano, po, c1):
             assert np.array_equal(ctx.stream_output(s), wants[s])
 
 
-def test_fused_undistort_front_end(pano, po, rig_r):
-    """raw 1920x1080 frames -> (undistort 960x540, crop, resize, resize) -> spherical warp, as ONE composed map
-    sampled once; lens = cameras.yaml sensing/imx390/fov120/960, rig R stitcher 0.  Parity is against the oracle
+@pytest.mark.parametrize("rw,rh", [(1920, 1080), (2880, 1620)])
+def test_fused_undistort_front_end(pano, po, rig_r, rw, rh):
+    """raw 1920x1080 (and 2880x1620: source boxes past column 2048) frames -> (undistort 960x540, crop, resize,
+    resize) -> spherical warp, as ONE composed map sampled once; lens = cameras.yaml sensing/imx390/fov120/960, rig R stitcher 0.  Parity is against the oracle
     of the fused map (this is a different resampling from the reference's five-pass chain)."""
     K = [4.890925118101495e+02, 0, 4.940763211103715e+02, 0, 4.912630345468579e+02, 2.865820139005963e+02, 0, 0, 1]
     dist = [-0.2838, 0.0628, 0, 0]
@@ -467,21 +468,21 @@ def test_fused_undistort_front_end(pano, po, rig_r):
     st = rig_r["stitchers"][0]
     v = st["cams"]
     d = {"n": 2, "w": 960, "h": 540, "scale": v[-1], "K": [v[0:9], v[18:27]], "R": [v[9:18], v[27:36]]}
-    raw = [synth_frame(1920, 1080, 21 + i) for i in range(2)]
+    raw = [synth_frame(rw, rh, 21 + i) for i in range(2)]
     for flag in ("0", "1"):          # remap-table and projecting K1 variants
         os.environ["PANO_WARP_ON_THE_FLY"] = flag
         try:
             ctx = pano.Context(2, 960, 540, scale=d["scale"], num_bands=3, cut=st["cut"], device=0)
             for i in range(2):
                 ctx.set_camera(i, d["K"][i], d["R"][i])
-                ctx.set_undistort(i, (1920, 1080), (960, 540), K, dist, rect)
+                ctx.set_undistort(i, (rw, rh), (960, 540), K, dist, rect)
             ctx.prepare()
         finally:
             os.environ.pop("PANO_WARP_ON_THE_FLY", None)
         ctx.build_masks_voronoi()
         masks = [ctx.get_mask(i) for i in range(2)]
         assert all(np.array_equal(a, b) for a, b in zip(masks, oracle_masks(po, d)))   # masks: stitcher frame geometry
-        fe = [po.front_end((1920, 1080), (960, 540), K, dist, rect, (960, 540)) for _ in range(2)]
+        fe = [po.front_end((rw, rh), (960, 540), K, dist, rect, (960, 540)) for _ in range(2)]
         want, _ = po.compose(raw, d["K"], d["R"], d["scale"], masks, 3, cut=st["cut"], front=fe)
         got = ctx.compose_host(raw)
         assert got.shape == (250, 1430, 3) and np.array_equal(got, want)
@@ -724,10 +725,12 @@ def test_randomised_rigs_through_the_lds_warp_kernel(pano, po, torch):
     assert done >= 18
 
 
-def test_largest_frames_the_remap_table_takes(pano, po, torch):
-    """2048 x 2048 is the largest frame the 11-bit tap indices of the remap table address (larger frames use the
-    projecting kernel): 2048-wide frames exercise xs = 2047 and the last bytes of the frame on the table path"""
-    d = c2_group(w=2048, h=1152, f=1069.0)
+@pytest.mark.parametrize("w,h,f", [(2048, 1152, 1069.0), (2560, 1440, 1336.0)])
+def test_largest_frames_the_remap_table_takes(pano, po, torch, w, h, f):
+    """the table codes are relative to each workgroup's source box, so frames beyond the 11-bit tap indices of one
+    code (2048) stay on the table path: 2048-wide frames exercise xs = 2047 in a box at the origin, 2560-wide ones
+    boxes whose origin is past 2048, and both the last bytes of the frame"""
+    d = c2_group(w=w, h=h, f=f)
     d = {**d, "n": 2, "K": d["K"][:2], "R": d["R"][1:3]}
     ctx = make_ctx(pano, d, 0, num_bands=4)
     ctx.build_masks_voronoi()
