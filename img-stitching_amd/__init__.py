@@ -86,7 +86,7 @@ EXPORTS = [
     "pano_create", "pano_destroy", "pano_last_error", "pano_version", "pano_set_camera",
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
-    "pano_build_masks_voronoi", "pano_get_mask", "pano_set_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
+    "pano_build_masks_voronoi", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
     "pano_compose_host", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_stream_input", "pano_stream_output",
     "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
     "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_get_live_rect", "pano_get_warp_table_stats", "pano_debug_get_level", "pano_debug_get_weights",
@@ -201,6 +201,25 @@ class Context:
             self._ck(self.lib.pano_set_gain_map(self.h, i, None, 0, 0)); return
         g = np.ascontiguousarray(gain, np.float32)
         self._ck(self.lib.pano_set_gain_map(self.h, i, _vp(g.ctypes.data), g.shape[1], g.shape[0]))
+
+    def estimate_gains(self, frames, block=(32, 32)):
+        """ExposureCompensator(GAIN_BLOCKS)::feed as initSeam runs it (ocvstitcher.hpp:981-1032) on stitcher-size
+        frames; the maps are installed for the next compose and returned"""
+        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        assert len(frames) == self.n
+        ptrs = (C.c_void_p * self.n)(*[f.ctypes.data for f in frames])
+        strides = (C.c_size_t * self.n)(*[f.strides[0] for f in frames])
+        self._ck(self.lib.pano_estimate_gains(self.h, ptrs, strides, int(block[0]), int(block[1])))
+        return [self.gain_map(i) for i in range(self.n)]
+
+    def gain_map(self, i):
+        gw, gh = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.pano_get_gain_map(self.h, i, None, C.byref(gw), C.byref(gh)))
+        if gw.value == 0:
+            return None
+        g = np.empty((gh.value, gw.value), np.float32)
+        self._ck(self.lib.pano_get_gain_map(self.h, i, _vp(g.ctypes.data), C.byref(gw), C.byref(gh)))
+        return g
 
     # -- per-frame, host buffers (cv::Mat in / cv::Mat out)
     def compose_host(self, frames):

@@ -6,7 +6,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -504,6 +506,93 @@ bool parse_floats(const std::string& s, std::vector<float>& out) {
         out.push_back(v);
     }
     return true;
+}
+
+// INTER_LINEAR_EXACT coefficient tables (resize.cpp interpolationLinear<uchar>::getCoeffs), IEEE double
+void linearExactCoeffs(int ssize, int dsize, std::vector<int>& ofs, std::vector<int>& c1, int& mn, int& mx) {
+    double scale = 1.0 / ((double)dsize / ssize);
+    ofs.assign(dsize, 0);
+    c1.assign(dsize, 0);
+    mn = 0;
+    mx = dsize;
+    for (int v = 0; v < dsize; v++) {
+        double fval = scale * ((double)v + 0.5) - 0.5;
+        int ival = (int)std::floor(fval);
+        if (ival >= 0 && ssize > 1) {
+            if (ival < ssize - 1) {
+                ofs[v] = ival;
+                c1[v] = (int)std::lrint((fval - (double)ival) * 256.0);
+            } else {
+                ofs[v] = ssize - 1;
+                mx = std::min(mx, v);
+            }
+        } else {
+            mn = std::max(mn, v + 1);
+        }
+    }
+    if (mx < mn) mx = mn;
+}
+
+// device allocations that live for one init-time call
+struct Scratch {
+    std::vector<void*> p;
+    ~Scratch() {
+        for (void* q : p) (void)hipFree(q);
+    }
+    template <typename T>
+    bool alloc(T** d, size_t bytes) {
+        *d = nullptr;
+        if (hipMalloc((void**)d, bytes ? bytes : 16) != hipSuccess) return false;
+        p.push_back(*d);
+        return true;
+    }
+    template <typename T>
+    bool put(T** d, const void* h, size_t bytes) {
+        return alloc(d, bytes) && (bytes == 0 || hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess);
+    }
+};
+
+// cv::solve(A, b, x, DECOMP_LU) for CV_64F as OpenCV's own LU does it (core/src/matrix_decomp.cpp LUImpl, no LAPACK):
+// partial pivoting on |a|, eps = 100 * DBL_EPSILON, elimination with alpha = a_ji * (-1 / a_ii), back substitution.
+// The operation order is the result (f64 does not reassociate), so it is spelled out rather than delegated
+bool solveLU(std::vector<double>& A, int m, std::vector<double>& x) {
+    const double eps = 2.220446049250313e-16 * 100;
+    auto at = [&](int r, int col) -> double& { return A[(size_t)r * m + col]; };
+    for (int i = 0; i < m; i++) {
+        int piv = i;
+        for (int j = i + 1; j < m; j++)
+            if (std::fabs(at(j, i)) > std::fabs(at(piv, i))) piv = j;
+        if (std::fabs(at(piv, i)) < eps) return false;
+        if (piv != i) {
+            for (int j = i; j < m; j++) std::swap(at(i, j), at(piv, j));
+            std::swap(x[i], x[piv]);
+        }
+        const double d = -1 / at(i, i);
+        for (int j = i + 1; j < m; j++) {
+            const double alpha = at(j, i) * d;
+            for (int k = i + 1; k < m; k++) at(j, k) += alpha * at(i, k);
+            x[j] += alpha * x[i];
+        }
+    }
+    for (int i = m - 1; i >= 0; i--) {
+        double acc = x[i];
+        for (int k = i + 1; k < m; k++) acc -= at(i, k) * x[k];
+        x[i] = acc / at(i, i);
+    }
+    return true;
+}
+
+// cv::sepFilter2D(map, map, CV_32F, [.25 .5 .25], [.25 .5 .25]), BORDER_REFLECT_101: the symmetric small-kernel row and
+// column filters both evaluate  centre * k0 + (left + right) * k1  in f32 (imgproc/src/filter.cpp)
+void smooth121(std::vector<float>& m, int w, int h) {
+    std::vector<float> t((size_t)w * h);
+    auto r101 = [](int p, int len) { return len == 1 ? 0 : (p < 0 ? -p : (p >= len ? 2 * len - 2 - p : p)); };
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            t[(size_t)y * w + x] = m[(size_t)y * w + x] * 0.5f + (m[(size_t)y * w + r101(x - 1, w)] + m[(size_t)y * w + r101(x + 1, w)]) * 0.25f;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            m[(size_t)y * w + x] = (t[(size_t)r101(y - 1, h) * w + x] + t[(size_t)r101(y + 1, h) * w + x]) * 0.25f + t[(size_t)y * w + x] * 0.5f;
 }
 
 }  // namespace
@@ -1065,34 +1154,10 @@ pano_status pano_build_masks_voronoi(pano_ctx* c) {
         WarpCam w = make_warp_cam(c, i, nullptr, 0, true);
         launch_warp_mask(w, full, r.w, s);
         launch_dilate3x3(smask[i], dil, sroi[i].w, sroi[i].h, s);
-        // INTER_LINEAR_EXACT coefficient tables (resize.cpp interpolationLinear<uchar>::getCoeffs), IEEE double
-        auto coeffs = [&](int ssize, int dsize, std::vector<int>& ofs, std::vector<int>& c1, int& mn, int& mx) {
-            double scale = 1.0 / ((double)dsize / ssize);
-            ofs.assign(dsize, 0);
-            c1.assign(dsize, 0);
-            mn = 0;
-            mx = dsize;
-            for (int v = 0; v < dsize; v++) {
-                double fval = scale * ((double)v + 0.5) - 0.5;
-                int ival = (int)std::floor(fval);
-                if (ival >= 0 && ssize > 1) {
-                    if (ival < ssize - 1) {
-                        ofs[v] = ival;
-                        c1[v] = (int)std::lrint((fval - (double)ival) * 256.0);
-                    } else {
-                        ofs[v] = ssize - 1;
-                        mx = std::min(mx, v);
-                    }
-                } else {
-                    mn = std::max(mn, v + 1);
-                }
-            }
-            if (mx < mn) mx = mn;
-        };
         std::vector<int> xo, xc, yo, yc;
         int mnx, mxx, mny, mxy;
-        coeffs(sroi[i].w, r.w, xo, xc, mnx, mxx);
-        coeffs(sroi[i].h, r.h, yo, yc, mny, mxy);
+        linearExactCoeffs(sroi[i].w, r.w, xo, xc, mnx, mxx);
+        linearExactCoeffs(sroi[i].h, r.h, yo, yc, mny, mxy);
         int *dxo = nullptr, *dxc = nullptr, *dyo = nullptr, *dyc = nullptr;
         pano_status u;
         if ((u = upload(c, &dxo, xo.data(), xo.size() * sizeof(int)))) { cleanup(); return u; }
@@ -1103,7 +1168,7 @@ pano_status pano_build_masks_voronoi(pano_ctx* c) {
         to_free.push_back(dyo);
         if ((u = upload(c, &dyc, yc.data(), yc.size() * sizeof(int)))) { cleanup(); return u; }
         to_free.push_back(dyc);
-        launch_resize_linear_exact(dil, sroi[i].w, sroi[i].h, seam, r.w, r.h, dxo, dxc, dyo, dyc, mnx, mxx, mny, mxy, s);
+        launch_resize_linear_exact(dil, sroi[i].w, sroi[i].h, 1, seam, r.w, r.h, dxo, dxc, dyo, dyc, mnx, mxx, mny, mxy, s);
         launch_and(seam, full, c->mask[i], (size_t)r.w * r.h, s);
         c->mask_set[i] = true;
     }
@@ -1132,6 +1197,162 @@ pano_status pano_set_gain_map(pano_ctx* c, int i, const float* h_gain, int gw, i
     c->gain_h[i] = gh;
     if ((s = upload(c, &c->gain[i], h_gain, (size_t)gw * gh * sizeof(float)))) return s;
     return upload_gain_tables(c, i);
+}
+
+pano_status pano_get_gain_map(pano_ctx* c, int i, float* h_gain, int* gw, int* gh) {
+    pano_status s = check_compute(c);
+    if (s != PANO_OK) return s;
+    if (i < 0 || i >= c->plan.n) return PANO_EINVAL;
+    const bool have = c->gain[i] != nullptr;
+    if (gw) *gw = have ? c->gain_w[i] : 0;
+    if (gh) *gh = have ? c->gain_h[i] : 0;
+    if (h_gain && have)
+        HIP_TRY(c, hipMemcpy(h_gain, c->gain[i], (size_t)c->gain_w[i] * c->gain_h[i] * sizeof(float), hipMemcpyDeviceToHost));
+    return PANO_OK;
+}
+
+pano_status pano_estimate_gains(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides, int block_w,
+                                int block_h) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (!h_frames || !strides || block_w < 1 || block_h < 1) return PANO_EINVAL;
+    const Plan& P = c->plan;
+    const int n = P.n, sw = P.src_w, sh = P.src_h;
+    for (int i = 0; i < n; i++)
+        if (!h_frames[i] || strides[i] < (size_t)sw * 3) return fail(c, PANO_EINVAL, "frame pointer / stride");
+    hipStream_t s = c->own_stream;
+    Scratch tmp;
+    auto oom = [&]() { return fail(c, PANO_EHIP, "hipMalloc / hipMemcpy (gain estimation)"); };
+    // seam scale, exactly as the mask half of initSeam (ocvstitcher.hpp:298, :988-1017)
+    const double swa = std::min(1.0, std::sqrt(1e5 / ((double)sh * sw)));
+    const int ssw = (int)std::lrint(sw * swa), ssh = (int)std::lrint(sh * swa);
+    const float seam_scale = static_cast<float>(c->scale * swa), swa_f = (float)swa;
+    // resize(imgs[i], seam_work_aspect, INTER_LINEAR_EXACT) (:988): one coefficient set for all cameras
+    std::vector<int> xo, xc, yo, yc;
+    int mnx = 0, mxx = 0, mny = 0, mxy = 0;
+    int *dxo = nullptr, *dxc = nullptr, *dyo = nullptr, *dyc = nullptr;
+    const bool shrink = ssw != sw || ssh != sh;
+    if (shrink) {
+        linearExactCoeffs(sw, ssw, xo, xc, mnx, mxx);
+        linearExactCoeffs(sh, ssh, yo, yc, mny, mxy);
+        if (!tmp.put(&dxo, xo.data(), xo.size() * sizeof(int)) || !tmp.put(&dxc, xc.data(), xc.size() * sizeof(int)) ||
+            !tmp.put(&dyo, yo.data(), yo.size() * sizeof(int)) || !tmp.put(&dyc, yc.data(), yc.size() * sizeof(int)))
+            return oom();
+    }
+    std::vector<Rect> sroi(n);
+    GainImages gi{};
+    std::vector<float> a, b;
+    for (int i = 0; i < n; i++) {
+        float K[9];
+        std::memcpy(K, c->K[i], sizeof(K));
+        K[0] *= swa_f; K[2] *= swa_f; K[4] *= swa_f; K[5] *= swa_f;
+        Projector pj;
+        pj.set(c->cfg.projector, seam_scale, K, c->R[i]);
+        sroi[i] = warpRoi(pj, ssw, ssh);
+        trigTables(pj, sroi[i], 0, 0, sroi[i].w, sroi[i].h, a, b);
+        float2 *dA = nullptr, *dB = nullptr;
+        uint8_t *full = nullptr, *small = nullptr, *img = nullptr, *mask = nullptr;
+        if (!tmp.put(&dA, a.data(), a.size() * sizeof(float)) || !tmp.put(&dB, b.data(), b.size() * sizeof(float)) ||
+            !tmp.alloc(&full, (size_t)sw * sh * 3 + 16) || !tmp.alloc(&img, (size_t)sroi[i].w * sroi[i].h * 3) ||
+            !tmp.alloc(&mask, (size_t)sroi[i].w * sroi[i].h))
+            return oom();
+        HIP_TRY(c, hipMemcpy2DAsync(full, (size_t)sw * 3, h_frames[i], strides[i], (size_t)sw * 3, sh, hipMemcpyHostToDevice, s));
+        small = full;
+        if (shrink) {
+            if (!tmp.alloc(&small, (size_t)ssw * ssh * 3 + 16)) return oom();
+            launch_resize_linear_exact(full, sw, sh, 3, small, ssw, ssh, dxo, dxc, dyo, dyc, mnx, mxx, mny, mxy, s);
+        }
+        // seamfinder_warper->warp(.., INTER_LINEAR, BORDER_REFLECT) and (.., INTER_NEAREST, BORDER_CONSTANT) (:1011-1014)
+        WarpCam w{};
+        w.src = small; w.src_stride = ssw * 3;
+        w.src_w = ssw; w.src_h = ssh;
+        w.out_w = ssw; w.out_h = ssh;
+        std::memcpy(w.m, pj.k_rinv, sizeof(w.m));
+        w.colA = dA; w.rowB = dB; w.tw = sroi[i].w; w.th = sroi[i].h;
+        w.dst = img; w.dst_pitch = sroi[i].w * 3;
+        launch_warp_image(w, s);
+        launch_warp_mask(w, mask, sroi[i].w, s);
+        gi.img[i] = img; gi.mask[i] = mask; gi.w[i] = sroi[i].w;
+    }
+    // BlocksGainCompensator::feed: equalised blocks of every image, in image order then row-major
+    struct Block { int cam, x, y, w, h; };
+    std::vector<Block> blk;
+    std::vector<int> per_w(n), per_h(n);
+    for (int i = 0; i < n; i++) {
+        const int cols = sroi[i].w, rows = sroi[i].h;
+        per_w[i] = (cols + block_w - 1) / block_w;
+        per_h[i] = (rows + block_h - 1) / block_h;
+        const int bw = (cols + per_w[i] - 1) / per_w[i], bh = (rows + per_h[i] - 1) / per_h[i];
+        for (int by = 0; by < per_h[i]; by++)
+            for (int bx = 0; bx < per_w[i]; bx++)
+                blk.push_back({i, bx * bw, by * bh, std::min(bx * bw + bw, cols) - bx * bw, std::min(by * bh + bh, rows) - by * bh});
+    }
+    const int nb = (int)blk.size();
+    if (nb > 4096) return fail(c, PANO_EINVAL, "gain estimation: more than 4096 blocks (raise the block size)");
+    // GainCompensator::feed on the blocks: the overlapping pairs i <= j (a block overlaps itself)
+    std::vector<GainPair> pairs;
+    std::vector<int> pi, pj2;
+    for (int i = 0; i < nb; i++)
+        for (int j = i; j < nb; j++) {
+            const Block &A = blk[i], &B = blk[j];
+            const int ax = sroi[A.cam].x + A.x, ay = sroi[A.cam].y + A.y, bx = sroi[B.cam].x + B.x, by = sroi[B.cam].y + B.y;
+            const int x0 = std::max(ax, bx), y0 = std::max(ay, by), x1 = std::min(ax + A.w, bx + B.w), y1 = std::min(ay + A.h, by + B.h);
+            if (!(x0 < x1 && y0 < y1)) continue;
+            pairs.push_back({A.cam, A.x + x0 - ax, A.y + y0 - ay, B.cam, B.x + x0 - bx, B.y + y0 - by, x1 - x0, y1 - y0});
+            pi.push_back(i);
+            pj2.push_back(j);
+        }
+    const int np = (int)pairs.size();
+    GainPair* d_pairs = nullptr;
+    int* d_cnt = nullptr;
+    double *d_sa = nullptr, *d_sb = nullptr;
+    if (!tmp.put(&d_pairs, pairs.data(), (size_t)np * sizeof(GainPair)) || !tmp.alloc(&d_cnt, (size_t)np * sizeof(int)) ||
+        !tmp.alloc(&d_sa, (size_t)np * sizeof(double)) || !tmp.alloc(&d_sb, (size_t)np * sizeof(double)))
+        return oom();
+    launch_gain_pairs(gi, d_pairs, np, d_cnt, d_sa, d_sb, s);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<int> cnt(np);
+    std::vector<double> sa(np), sb(np);
+    HIP_TRY(c, hipMemcpyAsync(cnt.data(), d_cnt, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(sa.data(), d_sa, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(sb.data(), d_sb, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    // N, I, then the normal equations of the gain model (alpha = 0.01, beta = 100) and cv::solve
+    std::vector<int> N((size_t)nb * nb, 0);
+    std::vector<double> I((size_t)nb * nb, 0.0), A((size_t)nb * nb, 0.0), g(nb, 0.0);
+    for (int p = 0; p < np; p++) {
+        const int i = pi[p], j = pj2[p], m = std::max(1, cnt[p]);
+        N[(size_t)i * nb + j] = N[(size_t)j * nb + i] = m;
+        I[(size_t)i * nb + j] = sa[p] / m;
+        I[(size_t)j * nb + i] = sb[p] / m;
+    }
+    const double alpha = 0.01, beta = 100;
+    for (int i = 0; i < nb; i++)
+        for (int j = 0; j < nb; j++) {
+            const double nij = N[(size_t)i * nb + j], iij = I[(size_t)i * nb + j], iji = I[(size_t)j * nb + i];
+            g[i] += beta * nij;
+            A[(size_t)i * nb + i] += beta * nij;
+            if (j == i) continue;
+            A[(size_t)i * nb + i] += 2 * alpha * iij * iij * nij;
+            A[(size_t)i * nb + j] -= 2 * alpha * iij * iji * nij;
+        }
+    if (!solveLU(A, nb, g)) return fail(c, PANO_ESTATE, "gain estimation: singular system");
+    // gain maps: the block gains as f32, smoothed twice (BlocksGainCompensator::feed tail), then installed like
+    // pano_set_gain_map (apply = stitching_detailed.cpp:841)
+    HIP_TRY(c, hipDeviceSynchronize());
+    drop_graphs(c);
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+        std::vector<float> map((size_t)per_w[i] * per_h[i]);
+        for (size_t q = 0; q < map.size(); q++) map[q] = static_cast<float>(g[k++]);
+        smooth121(map, per_w[i], per_h[i]);
+        smooth121(map, per_w[i], per_h[i]);
+        c->gain_w[i] = per_w[i];
+        c->gain_h[i] = per_h[i];
+        if ((st = upload(c, &c->gain[i], map.data(), map.size() * sizeof(float)))) return st;
+        if ((st = upload_gain_tables(c, i))) return st;
+    }
+    return PANO_OK;
 }
 
 pano_status pano_warp(pano_ctx* c, int i, const uint8_t* d_src, size_t src_stride, uint8_t* d_dst, size_t dst_stride,

@@ -1925,38 +1925,83 @@ void launch_dilate3x3(const uint8_t* src, uint8_t* dst, int w, int h, hipStream_
     hipLaunchKernelGGL(dilate3x3_kernel, grid, block, 0, s, src, dst, w, h);
 }
 
-// cv::resize INTER_LINEAR_EXACT CV_8UC1: 8.8 horizontal, 16.16 vertical; coefficient tables from the host
+// cv::resize INTER_LINEAR_EXACT CV_8UC1 / CV_8UC3: 8.8 horizontal, 16.16 vertical; coefficient tables from the host
+template <int CN>
 __global__ __launch_bounds__(256) void resize_linear_exact_kernel(const uint8_t* src, int sw, int sh, uint8_t* dst,
                                                                   int dw, int dh, const int* xofs, const int* xc1,
                                                                   const int* yofs, const int* yc1, int minx, int maxx,
                                                                   int miny, int maxy) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= dw || y >= dh) return;
-    auto hval = [&](int row) -> unsigned {
-        const uint8_t* s = src + (size_t)row * sw;
-        if (x < minx) return (unsigned)s[0] << 8;
-        if (x >= maxx) return (unsigned)s[sw - 1] << 8;
-        int o = xofs[x], c1 = xc1[x];
-        unsigned v = s[o] * (unsigned)(256 - c1) + s[o + 1] * (unsigned)c1;
-        return v > 65535u ? 65535u : v;
-    };
-    int out;
-    if (y < miny) out = (int)((hval(0) + 128) >> 8);
-    else if (y >= maxy) out = (int)((hval(sh - 1) + 128) >> 8);
-    else {
-        int o = yofs[y], c1 = yc1[y];
-        unsigned long long v = (unsigned long long)hval(o) * (unsigned)(256 - c1) + (unsigned long long)hval(o + 1) * (unsigned)c1;
-        if (v > 0xffffffffull) v = 0xffffffffull;
-        out = (int)((v + 32768) >> 16);
+#pragma unroll
+    for (int ch = 0; ch < CN; ch++) {
+        auto hval = [&](int row) -> unsigned {
+            const uint8_t* s = src + (size_t)row * sw * CN + ch;
+            if (x < minx) return (unsigned)s[0] << 8;
+            if (x >= maxx) return (unsigned)s[(sw - 1) * CN] << 8;
+            int o = xofs[x], c1 = xc1[x];
+            unsigned v = s[o * CN] * (unsigned)(256 - c1) + s[(o + 1) * CN] * (unsigned)c1;
+            return v > 65535u ? 65535u : v;
+        };
+        int out;
+        if (y < miny) out = (int)((hval(0) + 128) >> 8);
+        else if (y >= maxy) out = (int)((hval(sh - 1) + 128) >> 8);
+        else {
+            int o = yofs[y], c1 = yc1[y];
+            unsigned long long v = (unsigned long long)hval(o) * (unsigned)(256 - c1) + (unsigned long long)hval(o + 1) * (unsigned)c1;
+            if (v > 0xffffffffull) v = 0xffffffffull;
+            out = (int)((v + 32768) >> 16);
+        }
+        dst[((size_t)y * dw + x) * CN + ch] = (uint8_t)sat8i(out);
     }
-    dst[(size_t)y * dw + x] = (uint8_t)sat8i(out);
 }
-void launch_resize_linear_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, const int* xofs,
+void launch_resize_linear_exact(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh, const int* xofs,
                                 const int* xc1, const int* yofs, const int* yc1, int minx, int maxx, int miny, int maxy,
                                 hipStream_t s) {
     dim3 block(64, 4, 1), grid((dw + 63) / 64, (dh + 3) / 4, 1);
-    hipLaunchKernelGGL(resize_linear_exact_kernel, grid, block, 0, s, src, sw, sh, dst, dw, dh, xofs, xc1, yofs, yc1,
-                       minx, maxx, miny, maxy);
+    if (cn == 3)
+        hipLaunchKernelGGL(resize_linear_exact_kernel<3>, grid, block, 0, s, src, sw, sh, dst, dw, dh, xofs, xc1, yofs, yc1,
+                           minx, maxx, miny, maxy);
+    else
+        hipLaunchKernelGGL(resize_linear_exact_kernel<1>, grid, block, 0, s, src, sw, sh, dst, dw, dh, xofs, xc1, yofs, yc1,
+                           minx, maxx, miny, maxy);
+}
+
+// detail::GainCompensator::feed, the pixel loop of one overlapping pair of sub-images (exposure_compensate.cpp):
+// count of pixels both masks mark and the two sums of sqrt(b^2 + g^2 + r^2) over them.  The sums are f64 and
+// f64 addition does not reassociate, so one lane walks one pair in the reference's row-major order; the pairs (a few
+// thousand 32 x 32 blocks, once per mask refresh) are the parallel axis.  sqrt(f64) is correctly rounded on gfx950.
+__global__ __launch_bounds__(64) void gain_pair_kernel(GainImages g, const GainPair* __restrict__ pairs, int npairs,
+                                                       int* __restrict__ count, double* __restrict__ sum_a,
+                                                       double* __restrict__ sum_b) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= npairs) return;
+    const GainPair q = pairs[p];
+    const int wa = g.w[q.a], wb = g.w[q.b];
+    int n = 0;
+    double sa = 0.0, sb = 0.0;
+    for (int y = 0; y < q.h; y++) {
+        const uint8_t* ra = g.img[q.a] + ((size_t)(q.ay + y) * wa + q.ax) * 3;
+        const uint8_t* rb = g.img[q.b] + ((size_t)(q.by + y) * wb + q.bx) * 3;
+        const uint8_t* ma = g.mask[q.a] + (size_t)(q.ay + y) * wa + q.ax;
+        const uint8_t* mb = g.mask[q.b] + (size_t)(q.by + y) * wb + q.bx;
+        for (int x = 0; x < q.w; x++) {
+            if (ma[x] != 255 || mb[x] != 255) continue;
+            n++;
+            const int a0 = ra[3 * x], a1 = ra[3 * x + 1], a2 = ra[3 * x + 2];
+            const int b0 = rb[3 * x], b1 = rb[3 * x + 1], b2 = rb[3 * x + 2];
+            sa += __builtin_sqrt((double)(a0 * a0 + a1 * a1 + a2 * a2));
+            sb += __builtin_sqrt((double)(b0 * b0 + b1 * b1 + b2 * b2));
+        }
+    }
+    count[p] = n;
+    sum_a[p] = sa;
+    sum_b[p] = sb;
+}
+void launch_gain_pairs(const GainImages& g, const GainPair* pairs, int npairs, int* count, double* sum_a, double* sum_b,
+                       hipStream_t s) {
+    if (npairs < 1) return;
+    hipLaunchKernelGGL(gain_pair_kernel, dim3((npairs + 63) / 64), dim3(64), 0, s, g, pairs, npairs, count, sum_a, sum_b);
 }
 
 __global__ __launch_bounds__(256) void and_kernel(const uint8_t* a, const uint8_t* b, uint8_t* d, size_t n) {

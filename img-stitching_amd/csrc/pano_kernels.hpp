@@ -142,9 +142,21 @@ void launch_stack(const uint8_t* up, int up_w, int up_h, int up_stride, int up_y
 
 // mask preparation (Voronoi)
 void launch_dilate3x3(const uint8_t* src, uint8_t* dst, int w, int h, hipStream_t s);
-void launch_resize_linear_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh,
-                                const int* xofs, const int* xc1, const int* yofs, const int* yc1,
-                                int minx, int maxx, int miny, int maxy, hipStream_t s);
+void launch_resize_linear_exact(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh,
+                                const int* xofs, const int* xc1, const int* yofs, const int* yc1, int minx, int maxx,
+                                int miny, int maxy, hipStream_t s);
+// gain estimation (GainCompensator::feed): dense 8UC3 images / 8U masks of the seam-scale warps and the overlapping
+// pairs of sub-images (blocks), each a rectangle of w x h pixels at (ax, ay) in image a and (bx, by) in image b
+struct GainImages {
+    const uint8_t* img[kCams];
+    const uint8_t* mask[kCams];
+    int w[kCams];
+};
+struct GainPair {
+    int a, ax, ay, b, bx, by, w, h;
+};
+void launch_gain_pairs(const GainImages& g, const GainPair* pairs, int npairs, int* count, double* sum_a, double* sum_b,
+                       hipStream_t s);
 void launch_and(const uint8_t* a, const uint8_t* b, uint8_t* dst, size_t n, hipStream_t s);
 // one VoronoiSeamFinder::findInPair on device masks
 void launch_voronoi_pair(uint8_t* mask1, int w1, int h1, int tlx1, int tly1,

@@ -162,6 +162,10 @@ class Stitcher {
     int projector = PANO_SPHERICAL;   // reference: SphericalWarperGpu (ocvstitcher.hpp:1000)
     int device = 0;
     int maskRefreshPeriod = 200;      // process() refreshes the masks every 200 calls (ocvstitcher.hpp:1152)
+    // initSeam feeds a GAIN_BLOCKS compensator (ocvstitcher.hpp:1031-1032) but process() keeps apply() commented out
+    // (:1178); the one-shot twin applies it (src/stitching_detailed.cpp:841).  true = estimate in calibration(), apply
+    // in every process()
+    bool exposureCompensation = false;
 
     // init(yaml) (ocvstitcher.hpp:262-358): stitcher cfg -> size, num_images, blend strength, init mode; the
     // matching `structures:` entry of the camera cfg -> default cams (18N+1 floats) and cut
@@ -206,7 +210,7 @@ class Stitcher {
     // record of <cfgPath>cameraparaout_<id>.txt (mode 3, falling back to the defaults like the reference falls
     // back after failures); then the mask half of initSeam (:975-1101) runs on the GPU.
     int calibration(const std::vector<Mat>& imgs) {
-        (void)imgs;  // Voronoi seams depend on geometry only
+        // Voronoi seams depend on geometry only; the frames feed the exposure compensator when it is on
         pano_destroy(ctx_);
         ctx_ = nullptr;
         pano_config c{};
@@ -224,6 +228,17 @@ class Stitcher {
         if (!loaded && pano_set_cameras_from_list(ctx_, defaultCamParams_.c_str()) != PANO_OK) return RET_ERR;
         if (pano_prepare(ctx_) != PANO_OK) return RET_ERR;
         if (device >= 0 && pano_build_masks_voronoi(ctx_) != PANO_OK) return RET_ERR;
+        if (device >= 0 && exposureCompensation) {
+            if ((int)imgs.size() < cfg_.num_images) return RET_ERR;
+            const uint8_t* frames[PANO_MAX_CAMS];
+            size_t strides[PANO_MAX_CAMS];
+            for (int i = 0; i < cfg_.num_images; i++) {
+                if (imgs[i].cols != cfg_.width || imgs[i].rows != cfg_.height) return RET_ERR;
+                frames[i] = imgs[i].data;
+                strides[i] = imgs[i].step;
+            }
+            if (pano_estimate_gains(ctx_, frames, strides, 32, 32) != PANO_OK) return RET_ERR;
+        }
         frame_ = 0;
         return RET_OK;
     }

@@ -134,6 +134,18 @@ pano_status pano_get_new_camera_matrix(const pano_ctx* ctx, int cam, double newK
 /* block gain map of camera i (f32, gw x gh), bilinearly resized to the ROI like apply() does;
  * NULL removes it */
 pano_status pano_set_gain_map(pano_ctx* ctx, int i, const float* h_gain, int gw, int gh);
+/* ExposureCompensator::createDefault(GAIN_BLOCKS) + feed as ocvStitcher::initSeam runs it (ocvstitcher.hpp:981-1032;
+ * CLI twin src/stitching_detailed.cpp:722-723): the n stitcher-size BGR8 frames (host pointers, like the cv::Mat the
+ * reference holds at that point) are resized by seam_work_aspect (INTER_LINEAR_EXACT), warped at the seam scale
+ * (INTER_LINEAR, BORDER_REFLECT) beside the INTER_NEAREST-warped masks, cut into block_w x block_h blocks
+ * (BlocksGainCompensator's default is 32 x 32), and GainCompensator::feed's pairwise overlap statistics run on the GPU;
+ * the normal equations are solved on the host in f64 with OpenCV's LU operation order and the two [1 2 1]/4 smoothing
+ * passes follow.  The resulting maps are installed as by pano_set_gain_map, so the next pano_compose applies them. */
+pano_status pano_estimate_gains(pano_ctx* ctx, const uint8_t* const* h_frames, const size_t* strides, int block_w,
+                                int block_h);
+/* the installed gain map of camera i (compensator->gains() / gain_maps_): *gw x *gh floats; h_gain may be NULL to ask
+ * for the size only; 0 x 0 when camera i has none */
+pano_status pano_get_gain_map(pano_ctx* ctx, int i, float* h_gain, int* gw, int* gh);
 
 /* ---- per-frame path ---------------------------------------------------------------------- */
 /* RotationWarper::warp(img, K, R, INTER_LINEAR, BORDER_REFLECT, dst) (ocvstitcher.hpp:1171):

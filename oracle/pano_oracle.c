@@ -989,6 +989,194 @@ void po_prepare_masks_voronoi(int n, int kind, int sw, int sh, const float* Ks, 
     free(ones); free(mw); free(corners); free(sizes);
 }
 
+/* ======================================================================== exposure: gain estimation */
+
+/* cv::solve(A, b, x, DECOMP_LU) on CV_64F without LAPACK: hal::LU64f -> LUImpl<double> (core/src/matrix_decomp.cpp),
+ * eps = DBL_EPSILON * 100.  Partial pivoting, row elimination with d = -1/pivot, back substitution.  A (m x m, row
+ * major) and b (m) are overwritten; b holds the solution.  Returns 0 when a pivot is below eps (cv::solve -> false) */
+static int lu_solve_64f(double* A, int m, double* b) {
+    const double eps = 2.220446049250313e-16 * 100;
+    for (int i = 0; i < m; i++) {
+        int k = i;
+        for (int j = i + 1; j < m; j++)
+            if (fabs(A[(size_t)j * m + i]) > fabs(A[(size_t)k * m + i])) k = j;
+        if (fabs(A[(size_t)k * m + i]) < eps) return 0;
+        if (k != i) {
+            for (int j = i; j < m; j++) { double t = A[(size_t)i * m + j]; A[(size_t)i * m + j] = A[(size_t)k * m + j]; A[(size_t)k * m + j] = t; }
+            double t = b[i]; b[i] = b[k]; b[k] = t;
+        }
+        double d = -1 / A[(size_t)i * m + i];
+        for (int j = i + 1; j < m; j++) {
+            double alpha = A[(size_t)j * m + i] * d;
+            for (k = i + 1; k < m; k++) A[(size_t)j * m + k] += alpha * A[(size_t)i * m + k];
+            b[j] += alpha * b[i];
+        }
+    }
+    for (int i = m - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < m; k++) s -= A[(size_t)i * m + k] * b[k];
+        b[i] = s / A[(size_t)i * m + i];
+    }
+    return 1;
+}
+
+/* detail::GainCompensator::feed (stitching/src/exposure_compensate.cpp, 3.4.0): for every overlapping pair i <= j
+ * (a sub-image overlaps itself) N = max(1, #pixels both masks mark), I = mean of sqrt(b^2+g^2+r^2) over them,
+ * accumulated in double in row-major order; then the normal equations with alpha = 0.01, beta = 100 and cv::solve.
+ * Sub-images are given as pointer + stride (BlocksGainCompensator feeds views into the warped images) */
+int po_gain_feed(int n, const int* corners, const int* sizes, const uint8_t* const* imgs, const size_t* istride,
+                 const uint8_t* const* masks, const size_t* mstride, double* gains) {
+    int* N = (int*)calloc((size_t)n * n, sizeof(int));
+    double* I = (double*)calloc((size_t)n * n, sizeof(double));
+    for (int i = 0; i < n; ++i)
+        for (int j = i; j < n; ++j) {
+            int roi[4];
+            if (!overlap_roi(corners + 2 * i, corners + 2 * j, sizes + 2 * i, sizes + 2 * j, roi)) continue;
+            const int x1 = roi[0] - corners[2 * i], y1 = roi[1] - corners[2 * i + 1];
+            const int x2 = roi[0] - corners[2 * j], y2 = roi[1] - corners[2 * j + 1];
+            int cnt = 0;
+            double Isum1 = 0, Isum2 = 0;
+            for (int y = 0; y < roi[3]; ++y) {
+                const uint8_t* r1 = imgs[i] + (size_t)(y1 + y) * istride[i] + 3 * (size_t)x1;
+                const uint8_t* r2 = imgs[j] + (size_t)(y2 + y) * istride[j] + 3 * (size_t)x2;
+                const uint8_t* m1 = masks[i] + (size_t)(y1 + y) * mstride[i] + x1;
+                const uint8_t* m2 = masks[j] + (size_t)(y2 + y) * mstride[j] + x2;
+                for (int x = 0; x < roi[2]; ++x)
+                    if (m1[x] == 255 && m2[x] == 255) {
+                        cnt++;
+                        Isum1 += sqrt((double)(r1[3 * x] * r1[3 * x] + r1[3 * x + 1] * r1[3 * x + 1] + r1[3 * x + 2] * r1[3 * x + 2]));
+                        Isum2 += sqrt((double)(r2[3 * x] * r2[3 * x] + r2[3 * x + 1] * r2[3 * x + 1] + r2[3 * x + 2] * r2[3 * x + 2]));
+                    }
+            }
+            N[(size_t)i * n + j] = N[(size_t)j * n + i] = cnt > 1 ? cnt : 1;
+            I[(size_t)i * n + j] = Isum1 / N[(size_t)i * n + j];
+            I[(size_t)j * n + i] = Isum2 / N[(size_t)i * n + j];
+        }
+    const double alpha = 0.01, beta = 100;
+    double* A = (double*)calloc((size_t)n * n, sizeof(double));
+    for (int i = 0; i < n; ++i) gains[i] = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            gains[i] += beta * N[(size_t)i * n + j];
+            A[(size_t)i * n + i] += beta * N[(size_t)i * n + j];
+            if (j == i) continue;
+            A[(size_t)i * n + i] += 2 * alpha * I[(size_t)i * n + j] * I[(size_t)i * n + j] * N[(size_t)i * n + j];
+            A[(size_t)i * n + j] -= 2 * alpha * I[(size_t)i * n + j] * I[(size_t)j * n + i] * N[(size_t)i * n + j];
+        }
+    int ok = lu_solve_64f(A, n, gains);
+    free(N); free(I); free(A);
+    return ok;
+}
+
+/* cv::sepFilter2D(m, m, CV_32F, [.25 .5 .25], [.25 .5 .25]) (BORDER_REFLECT_101): SymmRowSmallFilter then
+ * SymmColumnSmallFilter, both  S[0]*k0 + (S[-1] + S[1])*k1  in f32 (imgproc/src/filter.cpp) */
+static void sep_filter_121(float* m, int w, int h) {
+    float* t = (float*)malloc(sizeof(float) * (size_t)w * h);
+    const float k0 = 0.5f, k1 = 0.25f;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int xl = border_interpolate(x - 1, w, PO_BORDER_REFLECT_101), xr = border_interpolate(x + 1, w, PO_BORDER_REFLECT_101);
+            t[(size_t)y * w + x] = m[(size_t)y * w + x] * k0 + (m[(size_t)y * w + xl] + m[(size_t)y * w + xr]) * k1;
+        }
+    for (int y = 0; y < h; y++) {
+        int yu = border_interpolate(y - 1, h, PO_BORDER_REFLECT_101), yd = border_interpolate(y + 1, h, PO_BORDER_REFLECT_101);
+        for (int x = 0; x < w; x++)
+            m[(size_t)y * w + x] = (t[(size_t)yu * w + x] + t[(size_t)yd * w + x]) * k1 + t[(size_t)y * w + x] * k0;
+    }
+    free(t);
+}
+
+/* detail::BlocksGainCompensator::feed (exposure_compensate.cpp, 3.4.0; the reference's compensator,
+ * ocvstitcher.hpp:1031-1032, stitching_detailed.cpp:722-723): cut every image into ceil(w/bl_w) x ceil(h/bl_h) equal
+ * blocks, one gain per block from GainCompensator::feed on the blocks, then two [1 2 1]/4 smoothing passes per map.
+ * maps[i] must hold po_gain_blocks_map_size(i) floats */
+void po_gain_blocks_map_size(int w, int h, int bl_w, int bl_h, int wh[2]) {
+    wh[0] = (w + bl_w - 1) / bl_w;
+    wh[1] = (h + bl_h - 1) / bl_h;
+}
+int po_gain_blocks_feed(int n, const int* corners, const int* sizes, const uint8_t* const* imgs,
+                        const uint8_t* const* masks, int bl_w_, int bl_h_, float** maps) {
+    int nb = 0;
+    for (int i = 0; i < n; i++) {
+        int wh[2];
+        po_gain_blocks_map_size(sizes[2 * i], sizes[2 * i + 1], bl_w_, bl_h_, wh);
+        nb += wh[0] * wh[1];
+    }
+    int* bc = (int*)calloc((size_t)2 * nb + 1, sizeof(int));
+    int* bs = (int*)calloc((size_t)2 * nb + 1, sizeof(int));
+    const uint8_t** bi = (const uint8_t**)calloc((size_t)nb + 1, sizeof(void*));
+    const uint8_t** bm = (const uint8_t**)calloc((size_t)nb + 1, sizeof(void*));
+    size_t* bis = (size_t*)calloc((size_t)nb + 1, sizeof(size_t));
+    size_t* bms = (size_t*)calloc((size_t)nb + 1, sizeof(size_t));
+    double* gains = (double*)calloc((size_t)nb + 1, sizeof(double));
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+        const int cols = sizes[2 * i], rows = sizes[2 * i + 1];
+        int per[2];
+        po_gain_blocks_map_size(cols, rows, bl_w_, bl_h_, per);
+        const int bl_width = (cols + per[0] - 1) / per[0], bl_height = (rows + per[1] - 1) / per[1];
+        for (int by = 0; by < per[1]; ++by)
+            for (int bx = 0; bx < per[0]; ++bx, ++k) {
+                const int tlx = bx * bl_width, tly = by * bl_height;
+                const int brx = tlx + bl_width < cols ? tlx + bl_width : cols, bry = tly + bl_height < rows ? tly + bl_height : rows;
+                bc[2 * k] = corners[2 * i] + tlx; bc[2 * k + 1] = corners[2 * i + 1] + tly;
+                bs[2 * k] = brx - tlx; bs[2 * k + 1] = bry - tly;
+                bi[k] = imgs[i] + ((size_t)tly * cols + tlx) * 3; bis[k] = (size_t)cols * 3;
+                bm[k] = masks[i] + (size_t)tly * cols + tlx; bms[k] = (size_t)cols;
+            }
+    }
+    int ok = po_gain_feed(nb, bc, bs, bi, bis, bm, bms, gains);
+    k = 0;
+    for (int i = 0; i < n; i++) {
+        int per[2];
+        po_gain_blocks_map_size(sizes[2 * i], sizes[2 * i + 1], bl_w_, bl_h_, per);
+        for (int b = 0; b < per[0] * per[1]; b++, k++) maps[i][b] = (float)gains[k];
+        sep_filter_121(maps[i], per[0], per[1]);
+        sep_filter_121(maps[i], per[0], per[1]);
+    }
+    free(bc); free(bs); free(bi); free(bm); free(bis); free(bms); free(gains);
+    return ok;
+}
+
+/* the reference's feed of the compensator, ocvStitcher::initSeam (ocvstitcher.hpp:981-1032): frames resized by
+ * seam_work_aspect (INTER_LINEAR_EXACT), warped at the seam scale (INTER_LINEAR, BORDER_REFLECT) beside the
+ * INTER_NEAREST-warped all-255 masks, then BlocksGainCompensator(32, 32)::feed.  seam_sizes (2n) and maps are outputs */
+int po_estimate_gains(int n, int kind, int sw, int sh, const uint8_t* const* frames, const float* Ks, const float* Rs,
+                      float wscale, int bl_w, int bl_h, int* seam_sizes, float** maps) {
+    double swa = sqrt(1e5 / ((double)sh * sw));
+    if (swa > 1.0) swa = 1.0;
+    int ssw = cv_round_d(sw * swa), ssh = cv_round_d(sh * swa);
+    float seam_scale = (float)(wscale * swa);
+    float swa_f = (float)swa;
+    int* corners = (int*)calloc((size_t)2 * n, sizeof(int));
+    uint8_t** iw = (uint8_t**)calloc((size_t)n + 1, sizeof(uint8_t*));
+    uint8_t** mw = (uint8_t**)calloc((size_t)n + 1, sizeof(uint8_t*));
+    uint8_t* ones = (uint8_t*)malloc((size_t)ssw * ssh);
+    uint8_t* small = (uint8_t*)malloc((size_t)ssw * ssh * 3);
+    memset(ones, 255, (size_t)ssw * ssh);
+    for (int i = 0; i < n; i++) {
+        float K[9];
+        memcpy(K, Ks + 9 * i, sizeof(K));
+        K[0] *= swa_f; K[2] *= swa_f; K[4] *= swa_f; K[5] *= swa_f;
+        po_projector p;
+        po_projector_set(&p, kind, seam_scale, K, Rs + 9 * i);
+        int r[4], c[2];
+        po_warp_roi(&p, ssw, ssh, r);
+        corners[2 * i] = r[0]; corners[2 * i + 1] = r[1];
+        seam_sizes[2 * i] = r[2]; seam_sizes[2 * i + 1] = r[3];
+        if (ssw == sw && ssh == sh) memcpy(small, frames[i], (size_t)sw * sh * 3);
+        else po_resize_linear_exact_8u(frames[i], sw, sh, 3, small, ssw, ssh);
+        iw[i] = (uint8_t*)malloc((size_t)r[2] * r[3] * 3);
+        mw[i] = (uint8_t*)malloc((size_t)r[2] * r[3]);
+        po_warp_8u(&p, small, ssw, ssh, (size_t)ssw * 3, 3, PO_INTER_LINEAR, PO_BORDER_REFLECT, iw[i], c);
+        po_warp_8u(&p, ones, ssw, ssh, (size_t)ssw, 1, PO_INTER_NEAREST, PO_BORDER_CONSTANT, mw[i], c);
+    }
+    int ok = po_gain_blocks_feed(n, corners, seam_sizes, (const uint8_t* const*)iw, (const uint8_t* const*)mw, bl_w, bl_h, maps);
+    for (int i = 0; i < n; i++) { free(iw[i]); free(mw[i]); }
+    free(iw); free(mw); free(ones); free(small); free(corners);
+    return ok;
+}
+
 /* ======================================================================== fused undistort front end */
 
 /* cvUndistortPoints without R / P (imgproc/src/undistort.cpp cvUndistortPointsInternal): 5 fixed-point iterations */

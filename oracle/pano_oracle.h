@@ -126,6 +126,18 @@ void po_optimal_new_camera_matrix(const double K[9], const double dist[4], int w
 /* stitcher-frame coordinates -> raw-frame coordinates through the five inverse steps */
 void po_front_end_map(const po_front_end* fe, const double newK[9], float xo, float yo, float* xr, float* yr);
 
+/* ---- exposure: gain estimation (ocvstitcher.hpp:1031-1032, stitching_detailed.cpp:722-723) */
+/* detail::GainCompensator::feed on sub-images given as pointer + stride; gains (n doubles) out; 0 = singular */
+int po_gain_feed(int n, const int* corners, const int* sizes, const uint8_t* const* imgs, const size_t* istride,
+                 const uint8_t* const* masks, const size_t* mstride, double* gains);
+void po_gain_blocks_map_size(int w, int h, int bl_w, int bl_h, int wh[2]);
+/* detail::BlocksGainCompensator::feed: images 8UC3 / masks 8U, both dense (stride = width); maps out */
+int po_gain_blocks_feed(int n, const int* corners, const int* sizes, const uint8_t* const* imgs,
+                        const uint8_t* const* masks, int bl_w, int bl_h, float** maps);
+/* ocvStitcher::initSeam's feed of the compensator from stitcher-size frames (resize, seam-scale warps, feed) */
+int po_estimate_gains(int n, int kind, int sw, int sh, const uint8_t* const* frames, const float* Ks, const float* Rs,
+                      float wscale, int bl_w, int bl_h, int* seam_sizes, float** maps);
+
 /* ---- whole per-frame path, ocvStitcher::process (ocvstitcher.hpp:1141-1216) */
 typedef struct po_compose_args {
     int n;              /* num_images */

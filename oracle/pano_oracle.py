@@ -250,6 +250,62 @@ def prepare_masks_voronoi(kind, w, h, Ks, Rs, scale):
     return masks
 
 
+def gain_feed(corners, images, masks):
+    """detail::GainCompensator::feed: one gain (float64) per image"""
+    n = len(images)
+    c = np.ascontiguousarray(np.asarray(corners, dtype=np.int32).reshape(-1))
+    ims = [np.ascontiguousarray(m, dtype=np.uint8) for m in images]
+    ms = [np.ascontiguousarray(m, dtype=np.uint8) for m in masks]
+    s = np.ascontiguousarray(np.asarray([[m.shape[1], m.shape[0]] for m in ims], dtype=np.int32).reshape(-1))
+    ia = (C.c_void_p * n)(*[m.ctypes.data for m in ims])
+    ma = (C.c_void_p * n)(*[m.ctypes.data for m in ms])
+    ist = (C.c_size_t * n)(*[m.shape[1] * 3 for m in ims])
+    mst = (C.c_size_t * n)(*[m.shape[1] for m in ms])
+    g = np.zeros(n, np.float64)
+    ok = lib().po_gain_feed(n, _p(c), _p(s), ia, ist, ma, mst, _p(g))
+    return g, bool(ok)
+
+
+def gain_blocks_feed(corners, images, masks, bl_w=32, bl_h=32):
+    """detail::BlocksGainCompensator(bl_w, bl_h)::feed: one float32 gain map per image"""
+    n = len(images)
+    c = np.ascontiguousarray(np.asarray(corners, dtype=np.int32).reshape(-1))
+    ims = [np.ascontiguousarray(m, dtype=np.uint8) for m in images]
+    ms = [np.ascontiguousarray(m, dtype=np.uint8) for m in masks]
+    s = np.ascontiguousarray(np.asarray([[m.shape[1], m.shape[0]] for m in ims], dtype=np.int32).reshape(-1))
+    maps = [np.zeros(((m.shape[0] + bl_h - 1) // bl_h, (m.shape[1] + bl_w - 1) // bl_w), np.float32) for m in ims]
+    ia = (C.c_void_p * n)(*[m.ctypes.data for m in ims])
+    ma = (C.c_void_p * n)(*[m.ctypes.data for m in ms])
+    ga = (C.c_void_p * n)(*[m.ctypes.data for m in maps])
+    ok = lib().po_gain_blocks_feed(n, _p(c), _p(s), ia, ma, int(bl_w), int(bl_h), ga)
+    return maps, bool(ok)
+
+
+def estimate_gains(frames, Ks, Rs, scale, kind=SPHERICAL, bl_w=32, bl_h=32):
+    """the compensator feed of ocvStitcher::initSeam from stitcher-size frames: (gain maps, seam-scale tile sizes)"""
+    Ks = np.ascontiguousarray(np.asarray(Ks, dtype=np.float32).reshape(-1, 9))
+    Rs = np.ascontiguousarray(np.asarray(Rs, dtype=np.float32).reshape(-1, 9))
+    n = Ks.shape[0]
+    fr = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+    h, w = fr[0].shape[:2]
+    swa = min(1.0, (1e5 / (h * w)) ** 0.5)
+    ssw, ssh = int(np.rint(w * swa)), int(np.rint(h * swa))
+    maps = []
+    for i in range(n):
+        K = Ks[i].copy()
+        f = np.float32(swa)
+        K[0] *= f; K[2] *= f; K[4] *= f; K[5] *= f
+        r = warp_roi(projector(kind, np.float32(scale * swa), K, Rs[i]), ssw, ssh)
+        maps.append(np.zeros(((r[3] + bl_h - 1) // bl_h, (r[2] + bl_w - 1) // bl_w), np.float32))
+    sizes = np.zeros(2 * n, np.int32)
+    fa = (C.c_void_p * n)(*[f.ctypes.data for f in fr])
+    ga = (C.c_void_p * n)(*[m.ctypes.data for m in maps])
+    ok = lib().po_estimate_gains(n, int(kind), int(w), int(h), fa, _p(Ks), _p(Rs), C.c_float(scale), int(bl_w), int(bl_h),
+                                 _p(sizes), ga)
+    assert ok, "singular gain system"
+    return maps, sizes.reshape(-1, 2)
+
+
 class Blender:
     """cv::detail::MultiBandBlender (num_bands >= 0) / Blender::NO (num_bands == -1)."""
 

@@ -55,3 +55,8 @@ def test_replay_frames_on_gpu(replay_bin, rig_r, tmp_path):
     assert r.returncode == 0, r.stderr + r.stdout
     assert "wrote final.ppm 1430x500" in r.stdout
     assert os.path.getsize(tmp_path / "final.ppm") > 1430 * 500 * 3
+    # exposure compensation on: calibration() estimates the block gains (seam-scale tiles of rig R are about 340 x 218
+    # -> 11 x 7 blocks of 32), process() applies them
+    r = subprocess.run([replay_bin, str(cfg), "--exposure", "--frames", "1"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "stitcher 0: exposure gain maps 11x7 blocks" in r.stdout and "wrote final.ppm 1430x500" in r.stdout

@@ -747,3 +747,49 @@ def test_largest_frames_the_remap_table_takes(pano, po, torch, w, h, f):
         assert np.array_equal(out.cpu().numpy(), want), rep
     stats = ctx.warp_table_stats()
     assert stats["table_bytes"] > 0 and stats["blocks"] > 0      # the table path, not the projecting kernel
+
+
+@pytest.mark.parametrize("case", ["c1", "c1_dark_cylindrical", "c2_small_blocks", "full_size_seam"])
+def test_gain_estimation_bit_exact(pano, po, c1, case):
+    """SURVEY 8(f)-4: ExposureCompensator(GAIN_BLOCKS)::feed as initSeam runs it (ocvstitcher.hpp:981-1032) - resize
+    INTER_LINEAR_EXACT, seam-scale LINEAR/REFLECT and NEAREST warps, the pairwise overlap sums (f64, sequential per
+    pair) on the GPU, OpenCV's LU and the two smoothing passes on the host: gain maps bit-equal to the oracle's, and the
+    panorama composed with them equal to the oracle's composed with its own"""
+    kind, block, bands = 0, (32, 32), 2
+    if case == "c1":
+        d, frames = c1, c1["frames"]
+    elif case == "c1_dark_cylindrical":
+        d, kind = c1, 1
+        frames = [f.copy() for f in c1["frames"]]
+        frames[1] = (frames[1].astype(np.uint16) * 5 // 8).astype(np.uint8)
+        frames[3] = np.clip(frames[3].astype(np.float32) * 1.3, 0, 255).astype(np.uint8)
+    elif case == "c2_small_blocks":
+        d = c2_group(w=1280, h=720, f=668.0)
+        frames = [np.clip(synth_frame(1280, 720, 60 + i).astype(np.float32) * (0.75 + 0.15 * i), 0, 255).astype(np.uint8) for i in range(4)]
+        block = (16, 24)
+    else:   # frames below 0.1 Mpx: seam_work_aspect = 1, no resize, seam scale == compose scale
+        d = c2_group(w=320, h=200, f=167.0)
+        frames = [synth_frame(320, 200, 90 + i) for i in range(4)]
+        frames[2] = (frames[2] // 2).astype(np.uint8)
+    ctx = make_ctx(pano, d, kind, num_bands=bands)
+    assert ctx.gain_map(0) is None
+    got = ctx.estimate_gains(frames, block)
+    want, _ = po.estimate_gains(frames, d["K"], d["R"], d["scale"], kind, *block)
+    for i in range(d["n"]):
+        assert got[i].shape == want[i].shape and np.array_equal(got[i], want[i]), (case, i)
+    assert max(float(np.abs(g - 1).max()) for g in got) > 0.02          # the estimate is not the trivial one
+    masks = oracle_masks(po, d, kind)
+    full = []
+    for i in range(d["n"]):
+        r = ctx.roi(i)
+        ctx.set_mask(i, masks[i])
+        full.append(po.resize_linear_32f(want[i], r[2], r[3]))
+    ref, _ = po.compose(frames, d["K"], d["R"], d["scale"], masks, bands, kind=kind, gain_maps=full)
+    assert np.array_equal(ctx.compose_host(frames), ref)
+    # a second estimate replaces the first; removing the maps restores the uncompensated panorama
+    again = ctx.estimate_gains(frames, block)
+    assert all(np.array_equal(a, b) for a, b in zip(again, got))
+    for i in range(d["n"]):
+        ctx.set_gain_map(i, None)
+    plain, _ = po.compose(frames, d["K"], d["R"], d["scale"], masks, bands, kind=kind)
+    assert np.array_equal(ctx.compose_host(frames), plain)

@@ -229,3 +229,114 @@ def test_caller_side_assembly_known_answers(po):
     assert m.shape == (80, 60, 3) and (m[:35] == 200).all() and (m[35:45] == 0).all() and (m[45:] == 100).all()
     f = po.stack_finalcut(up, down, 3)
     assert f.shape == (48, 50, 3) and (f[:22] == 200).all() and (f[22:26] == 0).all() and (f[26:] == 100).all()
+
+
+def _np_gain_feed(corners, images, masks):
+    """independent NumPy restatement of GainCompensator::feed (vectorised sums, LAPACK solve): agrees with the C
+    restatement to rounding, not to the bit"""
+    n = len(images)
+    N = np.zeros((n, n))
+    I = np.zeros((n, n))
+    for i in range(n):
+        for j in range(i, n):
+            (xi, yi), (xj, yj) = corners[i], corners[j]
+            hi, wi = masks[i].shape
+            hj, wj = masks[j].shape
+            x0, y0, x1, y1 = max(xi, xj), max(yi, yj), min(xi + wi, xj + wj), min(yi + hi, yj + hj)
+            if x0 >= x1 or y0 >= y1:
+                continue
+            a = images[i][y0 - yi:y1 - yi, x0 - xi:x1 - xi].astype(np.float64)
+            b = images[j][y0 - yj:y1 - yj, x0 - xj:x1 - xj].astype(np.float64)
+            m = (masks[i][y0 - yi:y1 - yi, x0 - xi:x1 - xi] == 255) & (masks[j][y0 - yj:y1 - yj, x0 - xj:x1 - xj] == 255)
+            N[i, j] = N[j, i] = max(1, int(m.sum()))
+            I[i, j] = np.sqrt((a * a).sum(-1))[m].sum() / N[i, j]
+            I[j, i] = np.sqrt((b * b).sum(-1))[m].sum() / N[i, j]
+    A = np.zeros((n, n))
+    bb = np.zeros(n)
+    for i in range(n):
+        for j in range(n):
+            bb[i] += 100 * N[i, j]
+            A[i, i] += 100 * N[i, j]
+            if i != j:
+                A[i, i] += 0.02 * I[i, j] * I[i, j] * N[i, j]
+                A[i, j] -= 0.02 * I[i, j] * I[j, i] * N[i, j]
+    return np.linalg.solve(A, bb)
+
+
+def test_gain_feed_vs_numpy_and_known_answers(po):
+    """detail::GainCompensator::feed: the C restatement (sequential double sums, OpenCV's LU) against the NumPy
+    one, and the cases whose answer is known in closed form"""
+    rng = np.random.default_rng(5)
+    base = rng.integers(20, 200, (60, 150, 3), dtype=np.uint8)
+    # three images cut out of one scene: 0 and 1 overlap, 1 and 2 overlap, image 1 is darker by 0.7
+    imgs = [base[:, 0:70].copy(), np.clip(np.rint(base[:, 40:110] * 0.7), 0, 255).astype(np.uint8), base[:, 80:150].copy()]
+    corners = [(0, 0), (40, 0), (80, 0)]
+    masks = [np.full(i.shape[:2], 255, np.uint8) for i in imgs]
+    masks[1][:5] = 0                                              # rows no camera-1 pixel covers
+    g, ok = po.gain_feed(corners, imgs, masks)
+    assert ok
+    assert np.allclose(g, _np_gain_feed(corners, imgs, masks), rtol=1e-10, atol=0)
+    assert g[1] > g[0] and g[1] > g[2] and 1.2 < g[1] / g[0] < 1 / 0.7 + 0.02   # the dark image is lifted, the prior pulls to 1
+    # identical overlap content: every gain is 1 (A g = b has g = 1 as its solution when I_ij = I_ji)
+    same = [base[:, 0:70].copy(), base[:, 40:110].copy()]
+    g1, _ = po.gain_feed(corners[:2], same, [np.full((60, 70), 255, np.uint8)] * 2)
+    assert np.allclose(g1, 1.0, rtol=0, atol=1e-12)
+    # no overlap at all: N = 0 off the diagonal, gains 1
+    g2, _ = po.gain_feed([(0, 0), (500, 0)], same, [np.full((60, 70), 255, np.uint8)] * 2)
+    assert np.array_equal(g2, [1.0, 1.0])
+
+
+def test_gain_blocks_feed_structure(po):
+    """BlocksGainCompensator::feed: block grid ceil(w/32) x ceil(h/32) with equalised block sizes, gains of the blocks
+    from the same solver, then two [1 2 1]/4 x [1 2 1]/4 passes (REFLECT_101) - checked against NumPy on the blocks"""
+    rng = np.random.default_rng(6)
+    base = rng.integers(20, 200, (75, 200, 3), dtype=np.uint8)
+    imgs = [base[:, 0:110].copy(), np.clip(np.rint(base[:, 70:200] * 1.25), 0, 255).astype(np.uint8)]
+    corners = [(-3, 7), (67, 7)]
+    masks = [np.full(i.shape[:2], 255, np.uint8) for i in imgs]
+    masks[0][:, :9] = 0
+    maps, ok = po.gain_blocks_feed(corners, imgs, masks)
+    assert ok and [m.shape for m in maps] == [(3, 4), (3, 5)]
+    # the same blocks by hand
+    bc, bi, bm = [], [], []
+    for (cx, cy), im, mk in zip(corners, imgs, masks):
+        h, w = mk.shape
+        nx, ny = (w + 31) // 32, (h + 31) // 32
+        bw, bh = (w + nx - 1) // nx, (h + ny - 1) // ny
+        for by in range(ny):
+            for bx in range(nx):
+                bc.append((cx + bx * bw, cy + by * bh))
+                bi.append(im[by * bh:min(by * bh + bh, h), bx * bw:min(bx * bw + bw, w)])
+                bm.append(mk[by * bh:min(by * bh + bh, h), bx * bw:min(bx * bw + bw, w)])
+    g = _np_gain_feed(bc, bi, bm)
+    k = 0
+    for m in maps:
+        raw = g[k:k + m.size].astype(np.float32).reshape(m.shape)
+        k += m.size
+        for _ in range(2):
+            p = np.pad(raw, 1, mode="reflect")
+            t = p[:, 1:-1] * np.float32(0.5) + (p[:, :-2] + p[:, 2:]) * np.float32(0.25)
+            raw = t[1:-1] * np.float32(0.5) + (t[:-2] + t[2:]) * np.float32(0.25)
+        assert np.allclose(m, raw, rtol=2e-6, atol=0)
+    assert maps[1].mean() < maps[0].mean()                       # the brighter image is turned down
+
+
+def test_estimate_gains_c1(po, c1):
+    """the whole feed of the compensator from stitcher-size frames (resize, seam-scale warps, blocks): sizes of the
+    seam-scale tiles, map sizes, and exposure-equal cameras staying near 1"""
+    maps, sizes = po.estimate_gains(c1["frames"], c1["K"], c1["R"], c1["scale"])
+    swa = min(1.0, (1e5 / (480 * 270)) ** 0.5)
+    for i in range(4):
+        K = np.asarray(c1["K"][i], np.float32).copy()
+        K[[0, 2, 4, 5]] *= np.float32(swa)
+        r = po.warp_roi(po.projector(po.SPHERICAL, np.float32(c1["scale"] * swa), K, c1["R"][i]), int(np.rint(480 * swa)), int(np.rint(270 * swa)))
+        assert tuple(sizes[i]) == r[2:]
+        assert maps[i].shape == ((r[3] + 31) // 32, (r[2] + 31) // 32)
+        assert 0.5 < maps[i].min() and maps[i].max() < 2.0
+    # a camera darkened by half is lifted where it overlaps its neighbours (blocks without overlap keep gain 1: the
+    # prior beta pulls every block to 1 and only the overlap term moves it)
+    dark = [f.copy() for f in c1["frames"]]
+    dark[1] = (dark[1] // 2).astype(np.uint8)
+    m2, _ = po.estimate_gains(dark, c1["K"], c1["R"], c1["scale"])
+    assert m2[1][:, 0].mean() > maps[1][:, 0].mean() + 0.1 and m2[1][:, -1].mean() > maps[1][:, -1].mean() + 0.1
+    assert m2[0][:, 0].mean() < maps[0][:, 0].mean() and m2[2][:, -1].mean() < maps[2][:, -1].mean()
