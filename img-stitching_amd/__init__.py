@@ -89,7 +89,7 @@ EXPORTS = [
     "pano_build_masks_voronoi", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
     "pano_compose_host", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_stream_input", "pano_stream_output",
     "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
-    "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_get_live_rect", "pano_get_warp_table_stats", "pano_debug_get_level", "pano_debug_get_weights",
+    "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_get_live_rect", "pano_get_live_gap", "pano_get_warp_table_stats", "pano_debug_get_level", "pano_debug_get_weights",
     "pano_debug_get_canvas_weights", "pano_debug_get_canvas",
 ]
 
@@ -317,6 +317,11 @@ class Context:
     def live_rect(self, i, level):
         r = (C.c_int * 4)()
         self._ck(self.lib.pano_get_live_rect(self.h, int(i), int(level), r)); return tuple(r)
+
+    def live_gap(self, i, level):
+        """(first dead column, dead column count) inside live_rect: the middle of a +-pi straddler's tile, (0, 0) = none"""
+        g = (C.c_int * 2)()
+        self._ck(self.lib.pano_get_live_gap(self.h, i, level, g)); return tuple(g)
 
     def set_frame_slots(self, n):
         self._ck(self.lib.pano_set_frame_slots(self.h, int(n)))

@@ -90,6 +90,8 @@ struct pano_ctx {
     // live rects: per camera and level the pixels {x0, y0, x1, y1} (inclusive, tile coordinates of the level) that the
     // blend ever reads, directly or through the pyramid chain; K1 / K2 do not produce the rest (see live_rects)
     int live[kMaxCams][kMaxLevels][4] = {};
+    // dead columns {x0, x1} (inclusive, x1 < x0 = none) inside the live rect: the middle of a +-pi straddler's tile
+    int gap[kMaxCams][kMaxLevels][2] = {};
     bool full_tiles = false;  // PANO_FULL_TILES=1: produce every pixel of every level (stage inspection)
     int nslots = 1, cur_slot = 0;
     char* slot_pyr[PANO_MAX_FRAME_SLOTS] = {};
@@ -274,11 +276,18 @@ WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t strid
     }
     w.gain = c->gain[i];
     w.gw = c->gain_w[i];
-    w.live_bx0 = 0; w.live_bx1 = INT_MAX; w.live_by0 = 0; w.live_by1 = INT_MAX;
+    w.live_bx0 = 0; w.live_bx1 = INT_MAX; w.live_by0_gap = 0; w.live_by1 = INT_MAX;
     if (!roi_only) {  // the bordered feed() tile: only the 64 x 16 blocks that overlap the live rect of level 0
         const int* L = c->live[i][0];
-        if (L[2] < L[0] || L[3] < L[1]) { w.live_bx0 = 1; w.live_bx1 = 0; w.live_by0 = 1; w.live_by1 = 0; }  // nothing
-        else { w.live_bx0 = L[0] >> 6; w.live_bx1 = L[2] >> 6; w.live_by0 = L[1] >> 4; w.live_by1 = L[3] >> 4; }
+        if (L[2] < L[0] || L[3] < L[1]) { w.live_bx0 = 1; w.live_bx1 = 0; w.live_by0_gap = 1; w.live_by1 = 0; }  // nothing
+        else {
+            w.live_bx0 = L[0] >> 6; w.live_bx1 = L[2] >> 6; w.live_by1 = L[3] >> 4;
+            // dead columns gap[0] .. gap[1] of level 0: the block columns that lie entirely inside them
+            const int* G = c->gap[i][0];
+            const int g0 = (G[0] + 63) >> 6, g1 = ((G[1] + 1) >> 6) - 1;
+            const bool has = G[1] >= G[0] && g1 >= g0;
+            w.live_by0_gap = warp_pack_live(L[1] >> 4, has ? g0 : 0, has ? g1 - g0 + 1 : 0);
+        }
     }
     return w;
 }
@@ -290,64 +299,100 @@ WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t strid
 //   S_top = N_top,   S_l = N_l  U  the 5x5 pyrDown footprint of S_{l+1}
 // S_l is what K1 (l = 0) and K2 (l >= 1) have to produce; the rest of the bordered tile (on config 2 a quarter of it)
 // is never read by anything and is not produced.  Bounding boxes, all conservative; recomputed with the weights.
+// A camera that straddles the +-pi seam of the projection has a full-width ROI (RotationWarper::warpRoi takes min / max
+// of u) whose mask lives at the two ends.  The need sets are unions over the mask's support (w_l is linear in the mask),
+// so the mask is cut at its widest run of empty columns (>= kMinDeadColumns) into two pieces, each piece gets its own
+// chain of rectangles, and per level the columns between the two are recorded as the dead gap K1 / K2 step over.
 static void live_rects(pano_ctx* c, const std::vector<std::vector<uint8_t>>& masks) {
+    constexpr int kMinDeadColumns = 256;
     const Plan& P = c->plan;
     const int top = std::max(P.bands, 0);
     for (int i = 0; i < P.n; i++) {
         const FeedTile& t = P.tile[i];
         auto full = [&](int l, int* r) { r[0] = 0; r[1] = 0; r[2] = (t.rect.w >> l) - 1; r[3] = (t.rect.h >> l) - 1; };
+        for (int l = 0; l < kMaxLevels; l++) { c->gap[i][l][0] = 1; c->gap[i][l][1] = 0; }  // no gap
         if (c->full_tiles || masks.empty() || P.bands < 0) {
             for (int l = 0; l < c->levels; l++) full(l, c->live[i][l]);
             continue;
         }
-        // R_0: bounding box of the mask, in tile coordinates
+        // per mask column: the rows it occupies
         const int mw = P.roi[i].w, mh = P.roi[i].h;
-        int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
+        std::vector<int> ctop(mw, INT_MAX), cbot(mw, -1);
         const uint8_t* m = masks[i].data();
         for (int y = 0; y < mh; y++)
             for (int x = 0; x < mw; x++)
-                if (m[(size_t)y * mw + x]) { x0 = std::min(x0, x); x1 = std::max(x1, x); y0 = std::min(y0, y); y1 = std::max(y1, y); }
-        int R[kMaxLevels][4], N[kMaxLevels][4];
-        const bool empty = x1 < 0;
+                if (m[(size_t)y * mw + x]) { ctop[x] = std::min(ctop[x], y); cbot[x] = y; }
+        int x0 = 0, x1 = mw - 1;
+        while (x0 < mw && cbot[x0] < 0) x0++;
+        while (x1 >= 0 && cbot[x1] < 0) x1--;
+        if (x1 < x0) {  // empty mask: nothing is live
+            for (int l = 0; l < c->levels; l++) { c->live[i][l][0] = c->live[i][l][1] = 1; c->live[i][l][2] = c->live[i][l][3] = 0; }
+            continue;
+        }
+        int e0 = 0, e1 = -1;  // widest run of empty columns inside [x0, x1]
+        for (int x = x0; x <= x1;) {
+            if (cbot[x] >= 0) { x++; continue; }
+            int r = x;
+            while (cbot[r + 1] < 0) r++;  // column x1 is occupied: the run ends before it
+            if (r - x > e1 - e0) { e0 = x; e1 = r; }
+            x = r + 1;
+        }
+        const bool two = e1 - e0 + 1 >= kMinDeadColumns;
         auto clampl = [&](int l, int* r) {
             const int w = t.rect.w >> l, h = t.rect.h >> l;
             r[0] = std::max(r[0], 0); r[1] = std::max(r[1], 0); r[2] = std::min(r[2], w - 1); r[3] = std::min(r[3], h - 1);
         };
         auto uni = [](int* a, const int* b) { a[0] = std::min(a[0], b[0]); a[1] = std::min(a[1], b[1]); a[2] = std::max(a[2], b[2]); a[3] = std::max(a[3], b[3]); };
-        if (empty) {
-            for (int l = 0; l < c->levels; l++) { c->live[i][l][0] = c->live[i][l][1] = 1; c->live[i][l][2] = c->live[i][l][3] = 0; }
-            continue;
-        }
-        R[0][0] = x0 + t.left; R[0][1] = y0 + t.top; R[0][2] = x1 + t.left; R[0][3] = y1 + t.top;
-        for (int l = 0; l < top; l++) {  // w_{l+1}(p) != 0 only if w_l is != 0 somewhere in [2p-2, 2p+2]
-            R[l + 1][0] = (R[l][0] - 1) >> 1; R[l + 1][1] = (R[l][1] - 1) >> 1;   // ceil((x0 - 2) / 2)
-            R[l + 1][2] = (R[l][2] + 2) >> 1; R[l + 1][3] = (R[l][3] + 2) >> 1;
-            clampl(l + 1, R[l + 1]);
-        }
-        for (int l = 0; l <= top; l++) {
-            for (int k = 0; k < 4; k++) N[l][k] = R[l][k];
-            if (l > 0) {
-                // the blend works on 4 x 2 blocks of level l-1 and opens the coarse window columns (X0>>1)-1 .. +2,
-                // rows (Y0>>1)-1 .. +1 around each (load_coarse); the scalar kernels' pyr_up_px windows lie inside
-                const int W[4] = {((R[l - 1][0] >> 2) << 1) - 1, (R[l - 1][1] >> 1) - 1, ((R[l - 1][2] >> 2) << 1) + 2, (R[l - 1][3] >> 1) + 1};
-                uni(N[l], W);
-                clampl(l, N[l]);
+        // the chain of one piece: mask columns [cx0, cx1] -> S[l], what K1 (l = 0) and K2 (l >= 1) have to produce for it
+        auto chain = [&](int cx0, int cx1, int S_out[kMaxLevels][4]) {
+            int y0 = INT_MAX, y1 = -1;
+            for (int x = cx0; x <= cx1; x++)
+                if (cbot[x] >= 0) { y0 = std::min(y0, ctop[x]); y1 = std::max(y1, cbot[x]); }
+            int R[kMaxLevels][4], N[kMaxLevels][4];
+            R[0][0] = cx0 + t.left; R[0][1] = y0 + t.top; R[0][2] = cx1 + t.left; R[0][3] = y1 + t.top;
+            for (int l = 0; l < top; l++) {  // w_{l+1}(p) != 0 only if w_l is != 0 somewhere in [2p-2, 2p+2]
+                R[l + 1][0] = (R[l][0] - 1) >> 1; R[l + 1][1] = (R[l][1] - 1) >> 1;   // ceil((x0 - 2) / 2)
+                R[l + 1][2] = (R[l][2] + 2) >> 1; R[l + 1][3] = (R[l][3] + 2) >> 1;
+                clampl(l + 1, R[l + 1]);
             }
-        }
-        int S[4] = {N[top][0], N[top][1], N[top][2], N[top][3]};
-        for (int k = 0; k < 4; k++) c->live[i][top][k] = S[k];
-        for (int l = top - 1; l >= 0; l--) {
-            const int F[4] = {2 * S[0] - 2, 2 * S[1] - 2, 2 * S[2] + 2, 2 * S[3] + 2};  // REFLECT_101 stays inside this interval
-            for (int k = 0; k < 4; k++) S[k] = N[l][k];
-            uni(S, F);
-            clampl(l, S);
-            for (int k = 0; k < 4; k++) c->live[i][l][k] = S[k];
+            for (int l = 0; l <= top; l++) {
+                for (int k = 0; k < 4; k++) N[l][k] = R[l][k];
+                if (l > 0) {
+                    // the blend works on 4 x 2 blocks of level l-1 and opens the coarse window columns (X0>>1)-1 .. +2,
+                    // rows (Y0>>1)-1 .. +1 around each (load_coarse); the scalar kernels' pyr_up_px windows lie inside
+                    const int W[4] = {((R[l - 1][0] >> 2) << 1) - 1, (R[l - 1][1] >> 1) - 1, ((R[l - 1][2] >> 2) << 1) + 2, (R[l - 1][3] >> 1) + 1};
+                    uni(N[l], W);
+                    clampl(l, N[l]);
+                }
+            }
+            int S[4] = {N[top][0], N[top][1], N[top][2], N[top][3]};
+            for (int k = 0; k < 4; k++) S_out[top][k] = S[k];
+            for (int l = top - 1; l >= 0; l--) {
+                const int F[4] = {2 * S[0] - 2, 2 * S[1] - 2, 2 * S[2] + 2, 2 * S[3] + 2};  // REFLECT_101 stays inside this interval
+                for (int k = 0; k < 4; k++) S[k] = N[l][k];
+                uni(S, F);
+                clampl(l, S);
+                for (int k = 0; k < 4; k++) S_out[l][k] = S[k];
+            }
+        };
+        int SA[kMaxLevels][4], SB[kMaxLevels][4];
+        chain(x0, two ? e0 - 1 : x1, SA);
+        if (two) chain(e1 + 1, x1, SB);
+        for (int l = 0; l <= top; l++) {
+            for (int k = 0; k < 4; k++) c->live[i][l][k] = SA[l][k];
+            if (two) {
+                uni(c->live[i][l], SB[l]);
+                c->gap[i][l][0] = SA[l][2] + 1;   // dead columns of level l (inclusive); empty when the pieces meet
+                c->gap[i][l][1] = SB[l][0] - 1;
+            }
         }
         for (int l = top + 1; l < c->levels; l++) full(l, c->live[i][l]);
     }
     for (int i = 0; i < P.n; i++)
-        for (int l = 0; l < c->levels; l++)
+        for (int l = 0; l < c->levels; l++) {
             for (int k = 0; k < 4; k++) c->pyr.cam[i].live[l][k] = c->live[i][l][k];
+            for (int k = 0; k < 2; k++) c->pyr.cam[i].gap[l][k] = c->gap[i][l][k];
+        }
 }
 
 
@@ -776,8 +821,11 @@ pano_status pano_prepare(pano_ctx* c) {
         if (!c->have_cam[i]) return fail(c, PANO_ESTATE, "camera parameters missing");
         P.proj[i].set(c->cfg.projector, c->scale, c->K[i], c->R[i]);
         P.roi[i] = warpRoi(P.proj[i], P.src_w, P.src_h);
-        // a camera whose ROI spans the whole u range straddles the +-pi seam (reference README.md:27-29)
-        if (P.roi[i].w >= (int)(2.0 * M_PI * c->scale) - 1 || P.roi[i].w <= 0 || P.roi[i].h <= 0)
+        // a camera that straddles the +-pi seam of the projection gets the ROI RotationWarper::warpRoi gives it: the whole u
+        // range, its two ends live and the span between them dead (skipped, see live_rects).  PANO_WRAP_IS_ERROR=1
+        // keeps the refusal for callers that want the reference's 2 x 4 grouping enforced (README.md:27-29)
+        if (P.roi[i].w <= 0 || P.roi[i].h <= 0) return fail(c, PANO_EINVAL, "camera ROI is empty");
+        if (P.roi[i].w >= (int)(2.0 * M_PI * c->scale) - 1 && getenv("PANO_WRAP_IS_ERROR") && atoi(getenv("PANO_WRAP_IS_ERROR")))
             return fail(c, PANO_EWRAP, "camera ROI wraps the projection seam; split the ring into groups");
     }
     Rect pano_rect = resultRoi(P.roi, n);
@@ -1819,6 +1867,16 @@ pano_status pano_get_live_rect(const pano_ctx* c, int i, int level, int rect[4])
     rect[0] = L[0]; rect[1] = L[1];
     rect[2] = L[2] >= L[0] ? L[2] - L[0] + 1 : 0;
     rect[3] = L[3] >= L[1] ? L[3] - L[1] + 1 : 0;
+    return PANO_OK;
+}
+
+pano_status pano_get_live_gap(const pano_ctx* c, int i, int level, int gap[2]) {
+    if (!c || !gap) return PANO_EINVAL;
+    if (!c->prepared) return PANO_ESTATE;
+    if (i < 0 || i >= c->plan.n || level < 0 || level >= c->levels) return PANO_EINVAL;
+    const int* G = c->gap[i][level];
+    gap[0] = G[1] >= G[0] ? G[0] : 0;
+    gap[1] = G[1] >= G[0] ? G[1] - G[0] + 1 : 0;
     return PANO_OK;
 }
 

@@ -248,7 +248,12 @@ __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x0 >= c.tw || y >= c.th) return;
-    if ((x0 >> 6) < c.live_bx0 || (x0 >> 6) > c.live_bx1 || (y >> 4) < c.live_by0 || (y >> 4) > c.live_by1) return;
+    {
+        const unsigned lg = (unsigned)c.live_by0_gap;
+        const int gap0 = (int)((lg >> 12) & 0x3ffu), by0 = (int)(lg & 0xfffu);
+        if ((x0 >> 6) < c.live_bx0 || (x0 >> 6) > c.live_bx1 || (y >> 4) < by0 || (y >> 4) > c.live_by1) return;
+        if ((x0 >> 6) >= gap0 && (x0 >> 6) < gap0 + (int)(lg >> 22)) return;   // the dead middle of a +-pi straddler
+    }
     float m[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) m[i] = c.m[i];
@@ -529,7 +534,10 @@ __device__ __forceinline__ void warp_lane_checked(const WarpCam& c, int x0, int 
 template <int ABL>
 __global__ __launch_bounds__(256) void warp_tiles_lut_checked_kernel(WarpParams P) {
     const WarpCam& c = P.cam[blockIdx.x];
-    const int bx = c.live_bx0 + (int)blockIdx.y, by = c.live_by0 + (int)blockIdx.z;  // the grid is laid over the live blocks
+    const unsigned lg = (unsigned)c.live_by0_gap;
+    int bx = c.live_bx0 + (int)blockIdx.y;  // the grid is laid over the live blocks ...
+    const int by = (int)(lg & 0xfffu) + (int)blockIdx.z;
+    if (bx >= (int)((lg >> 12) & 0x3ffu)) bx += (int)(lg >> 22);  // ... minus the dead middle of a +-pi straddler
     if (bx > c.live_bx1 || by > c.live_by1) return;
     const int x0 = (bx * 16 + (threadIdx.x & 15)) * 4;
     const int y = by * 16 + threadIdx.y * 4 + (threadIdx.x >> 4);
@@ -585,7 +593,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
     struct Hot {
         const uint8_t* src; uint8_t* dst; const uint2* lutc; const int4* box;
-        int tw, th, live_bx0, live_by0, src_stride, dst_pitch, dst_plane, lutc_pitch;
+        int tw, th, live_bx0, live_by0_gap, src_stride, dst_pitch, dst_plane, lutc_pitch;
     };
     static_assert(sizeof(Hot) == 64 && offsetof(WarpCam, lutc_pitch) == 60 && offsetof(WarpCam, src) == 0 &&
                       offsetof(WarpCam, box) == 24 && offsetof(WarpCam, live_bx0) == 40, "hot part layout");
@@ -603,8 +611,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     uint8_t PANO_GLOBAL* const dst = (uint8_t PANO_GLOBAL*)hot.h.dst;
     const u32x2 PANO_GLOBAL* const lutc = (const u32x2 PANO_GLOBAL*)hot.h.lutc;
     const int tw = hot.h.tw, th = hot.h.th;
-    // the grid is laid over the live blocks of the camera: workgroup (0, 0) is block (live_bx0, live_by0)
-    const int bx = hot.h.live_bx0 + (int)blockIdx.y, by = hot.h.live_by0 + (int)blockIdx.z;
+    // the grid is laid over the live blocks of the camera: workgroup (0, 0) is block (live_bx0, live_by0); the dead
+    // block columns in the middle of a +-pi straddler (gap_len from gap_bx0 on, else 0) are stepped over
+    const unsigned lg = (unsigned)hot.h.live_by0_gap;
+    int bx = hot.h.live_bx0 + (int)blockIdx.y;
+    const int by = (int)(lg & 0xfffu) + (int)blockIdx.z;
+    if (bx >= (int)((lg >> 12) & 0x3ffu)) bx += (int)(lg >> 22);
     const unsigned stride = (unsigned)hot.h.src_stride;
     const unsigned dst_pitch = (unsigned)hot.h.dst_pitch, dst_plane = (unsigned)hot.h.dst_plane, lutc_pitch = (unsigned)hot.h.lutc_pitch;
     const int gxc = (tw + 63) >> 6;
@@ -766,8 +778,8 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
     for (int i = 0; i < ncam; i++) {
         const WarpCam& c = p.cam[i];
         const int nbx = (c.tw + 63) / 64, nby = (c.th + 15) / 16;
-        lbx = max(lbx, min(c.live_bx1, nbx - 1) - c.live_bx0 + 1);
-        lby = max(lby, min(c.live_by1, nby - 1) - c.live_by0 + 1);
+        lbx = max(lbx, min(c.live_bx1, nbx - 1) - c.live_bx0 + 1 - (int)((unsigned)c.live_by0_gap >> 22));
+        lby = max(lby, min(c.live_by1, nby - 1) - (c.live_by0_gap & 0xfff) + 1);
     }
     lbx = max(lbx, 1); lby = max(lby, 1);  // nothing live (empty masks): one workgroup that leaves at once keeps the events valid
     const dim3 grid_lut(ncam, lbx, lby);
@@ -891,6 +903,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam
     const int y0 = ((ly0 >> 1) + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * 2;  // pair of output rows
     if (y0 >= dh || y0 > ly1) return;
     if (t * 4 >= dw || t * 4 > lx1) return;
+    if (t * 4 >= c.gap[l + 1][0] && t * 4 + 3 <= c.gap[l + 1][1]) return;  // the dead middle of a +-pi straddler's tile
     const uint8_t* __restrict__ src = c.lvl[l] + (size_t)pl * c.plane[l];
     const int sp = c.pitch[l];
     // Every lane does seven 16-byte loads (columns 8t-4 .. 8t+11; lane 0 loads columns 0..15 and shifts).

@@ -28,7 +28,10 @@ struct alignas(64) WarpCam {
     int tw, th;           // tile width/height in pixels
     // Blocks of 64 x 16 tile pixels (inclusive block coordinates) that anything downstream ever reads (see
     // pano_api.cpp live_rects): the K1 grid is laid over them.  {0, 0} .. {INT_MAX, INT_MAX} = everything.
-    int live_bx0, live_by0;
+    // A camera that straddles the +-pi seam of the projection has a full-width tile whose two ends are live and whose
+    // middle is dead: gap_len block columns from gap_bx0 on are skipped (the grid is that much narrower).
+    // live_by0_gap = live_by0 | gap_bx0 << 12 | gap_len << 22 (one dword, so that the hot part stays 64 bytes)
+    int live_bx0, live_by0_gap;
     int src_stride;       // bytes
     int dst_pitch;        // bytes per row
     int dst_plane;        // pipeline: bytes between the B, G, R planes
@@ -53,6 +56,7 @@ struct alignas(64) WarpCam {
     const float2* groww;  // [th] {1-fy, fy}
     int gw;
 };
+inline int warp_pack_live(int live_by0, int gap_bx0, int gap_len) { return live_by0 | gap_bx0 << 12 | (int)((unsigned)gap_len << 22); }
 struct WarpParams {
     WarpCam cam[kCams];
 };
@@ -70,6 +74,7 @@ struct PyrCam {
     int w0, h0;                // level-0 tile size (multiples of 2^bands)
     int tx, ty;                // tile origin in the padded canvas (level 0)
     int live[kLevels][4];      // per level {x0, y0, x1, y1} inclusive: the pixels of the level anything downstream reads
+    int gap[kLevels][2];       // per level dead columns {x0, x1} inside live (x1 < x0: none): a +-pi straddler's middle
 };
 struct PyrParams {
     PyrCam cam[kCams];

@@ -40,7 +40,7 @@ typedef enum pano_status {
     PANO_ESTATE = -3,     /* call order (e.g. compose before prepare / masks) */
     PANO_EHIP = -4,       /* HIP runtime error, see pano_last_error() */
     PANO_ENODEVICE = -5,  /* compute call on a plan-only ctx */
-    PANO_EWRAP = -6,      /* a camera's ROI straddles the +-pi seam of the projection (reference README.md:27-29) */
+    PANO_EWRAP = -6,      /* a camera's ROI straddles the +-pi seam and PANO_WRAP_IS_ERROR=1 asks to refuse it (README.md:27-29) */
     PANO_ENOMEM = -7
 } pano_status;
 
@@ -254,6 +254,11 @@ pano_status pano_get_warp_table_stats(const pano_ctx* ctx, uint64_t* table_bytes
  * panorama is unaffected; pano_debug_get_level is defined inside this rectangle.  PANO_FULL_TILES=1 (environment, at
  * pano_prepare) produces whole tiles. */
 pano_status pano_get_live_rect(const pano_ctx* ctx, int i, int level, int rect[4]);
+/* A camera that straddles the +-pi seam of the projection gets, as from RotationWarper::warpRoi, a ROI as wide as the
+ * whole u range, live at its two ends and dead in between (the reference avoids such cameras by stitching the ring as two
+ * groups of four, README.md:27-29; here the ring may be one context).  gap = {first dead column, number of dead columns}
+ * of the live rect at `level` ({0, 0}: none): the warp / pyramid kernels step over them. */
+pano_status pano_get_live_gap(const pano_ctx* ctx, int i, int level, int gap[2]);
 pano_status pano_debug_get_level(pano_ctx* ctx, int i, int level, int16_t* h_dst, int* w, int* h);
 /* f32 weight level of camera i (pyrDown chain of mask/255 with constant border) */
 pano_status pano_debug_get_weights(pano_ctx* ctx, int i, int level, float* h_dst, int* w, int* h);

@@ -144,10 +144,17 @@ def test_errors_and_no_cpu_fallback(pano, c1):
         assert e.value.status == -2
 
 
-def test_full_ring_is_rejected(pano):
-    # a camera looking backwards straddles the +-pi seam (reference README.md:27-29): PANO_EWRAP
+def test_camera_across_the_projection_seam(pano, po, monkeypatch):
+    """a camera looking backwards straddles the +-pi seam: it gets RotationWarper::warpRoi's full-width ROI (SURVEY
+    8(f)-4); PANO_WRAP_IS_ERROR=1 keeps the refusal that enforces the reference's 2 x 4 grouping (README.md:27-29)"""
     from helpers import ry
     K = [1002.416, 0, 960, 0, 1002.416, 540, 0, 0, 1]
+    ctx = pano.Context(1, 1920, 1080, scale=1002.416, num_bands=2, device=-1)
+    ctx.set_camera(0, K, ry(180.0))
+    ctx.prepare()
+    assert ctx.roi(0) == po.warp_roi(po.projector(po.SPHERICAL, 1002.416, K, ry(180.0)), 1920, 1080)
+    assert ctx.roi(0)[2] >= int(2 * 3.14159265 * 1002.416) - 1
+    monkeypatch.setenv("PANO_WRAP_IS_ERROR", "1")
     ctx = pano.Context(1, 1920, 1080, scale=1002.416, num_bands=2, device=-1)
     ctx.set_camera(0, K, ry(180.0))
     with pytest.raises(pano.PanoError) as e:

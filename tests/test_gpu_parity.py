@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import c2_group, c4_rig, synth_frame
+from helpers import c2_group, c4_rig, ry, synth_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -793,3 +793,43 @@ def test_gain_estimation_bit_exact(pano, po, c1, case):
         ctx.set_gain_map(i, None)
     plain, _ = po.compose(frames, d["K"], d["R"], d["scale"], masks, bands, kind=kind)
     assert np.array_equal(ctx.compose_host(frames), plain)
+
+
+def ring_of_eight(w=480, h=270, f=250.6, first=157.5):
+    """eight cameras 45 degrees apart in ONE stitcher (the reference splits them 2 x 4, README.md:27-29).  first = 157.5:
+    the cameras at +-157.5 degrees both straddle +-pi and RotationWarper::warpRoi gives them the full panorama width
+    (Voronoi then hands each of them one end); first = 180: one camera looks straight at the seam and keeps both ends"""
+    K = [f, 0.0, w / 2.0, 0.0, f, h / 2.0, 0.0, 0.0, 1.0]
+    return {"n": 8, "w": w, "h": h, "scale": f, "K": [K] * 8, "R": [ry(first - 45.0 * i) for i in range(8)]}
+
+
+@pytest.mark.parametrize("w,h,f,bands,first", [(480, 270, 250.6, 4, 157.5), (480, 270, 250.6, 4, 180.0), (1920, 1080, 1002.416, 5, 180.0)])
+def test_single_ring_of_eight_cameras(pano, po, monkeypatch, w, h, f, bands, first):
+    """SURVEY 8(f)-4: a 360-degree ring in ONE context.  The +-pi straddlers get RotationWarper::warpRoi's full-width
+    ROIs, Voronoi runs between tiles that overlap everywhere; masks and panorama bit-equal to the oracle, with the dead
+    middle of the straddlers' tiles stepped over (pano_get_live_gap) and with whole tiles (PANO_FULL_TILES=1)"""
+    d = ring_of_eight(w, h, f, first)
+    full_w = int(2 * np.pi * f)
+    masks = oracle_masks(po, d)
+    frames = [synth_frame(w, h, 30 + i) for i in range(8)]
+    want, _ = po.compose(frames, d["K"], d["R"], d["scale"], masks, bands)
+    for full_tiles in ("0", "1"):
+        monkeypatch.setenv("PANO_FULL_TILES", full_tiles)
+        ctx = make_ctx(pano, d, 0, num_bands=bands)
+        assert ctx.roi(0)[2] >= full_w - 1 and ctx.roi(3)[2] < full_w // 3
+        ctx.build_masks_voronoi()
+        for i in range(8):
+            assert np.array_equal(ctx.get_mask(i), masks[i]), i
+        for rep in range(2):
+            assert np.array_equal(ctx.compose_host(frames), want), (full_tiles, rep)
+        gaps = [ctx.live_gap(i, 0) for i in range(8)]
+        two_ended = [i for i in range(8) if ctx.roi(i)[2] >= full_w - 1 and (masks[i][:, :w // 4] != 0).any() and (masks[i][:, -w // 4:] != 0).any()]
+        if full_tiles == "1":
+            assert all(g == (0, 0) for g in gaps)
+        else:
+            assert all(gaps[i] == (0, 0) for i in range(8) if i not in two_ended)
+            for i in two_ended:     # a straddler whose mask lives at both ends: most of its width is dead
+                assert gaps[i][1] > full_w // 2, (i, gaps[i])
+                x, y, lw, lh = ctx.live_rect(i, 0)
+                assert x <= gaps[i][0] and gaps[i][0] + gaps[i][1] <= x + lw
+    assert two_ended or first != 180.0
