@@ -641,9 +641,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     const bool active = x0 < tw && y < th;
     // plain (cached) loads and stores: non-temporal ones for the streamed table and tile measured 15 % slower
     u32x2 e = u32x2{0u, 0u};
-    if (active)  // 32-bit byte offset: scalar base + vector offset addressing, no 64-bit multiply
+    if (active && ABL != 20)  // 32-bit byte offset: scalar base + vector offset addressing, no 64-bit multiply
         e = *reinterpret_cast<const u32x2 PANO_GLOBAL*>((const uint8_t PANO_GLOBAL*)lutc + (((unsigned)y * lutc_pitch + (unsigned)(x0 >> 2)) << 3));
     if (ABL == 6 || ABL == 17) e = u32x2{(unsigned)((x0 * 7 / 8) * 32 + 5) | ((unsigned)((y * 7 / 8) * 32 + 9) << 16), 32u};
+    uint4 dense = make_uint4(0u, 0u, 0u, 0u);
+    if (ABL == 20 && active)  // diagnostic: the dense table (one code per pixel, no decode) instead of the packed one
+        dense = *reinterpret_cast<const uint4*>(cg->lut + ((unsigned)y * (4u * lutc_pitch) + (unsigned)x0));
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bb), "+s"(live) : : "memory");  // bb, live are only valid past this point
     if (bx > live.x || by > live.y) return;  // beyond this camera's live blocks (workgroup-uniform)
     const int src_w = live.z, src_h = live.w;
@@ -694,7 +697,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
     // an escaped group (a BORDER_REFLECT fold inside it) reads its four codes from the dense table: one more dependent
     // load for the waves that hold one (about one in eight)
-    if (e.x == 0xffffffffu) {
+    if (ABL == 20) {
+        const unsigned code[4] = {dense.x, dense.y, dense.z, dense.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            X[j] = code[j] & 0xffffu;
+            Y[j] = code[j] >> 16;
+        }
+    } else if (e.x == 0xffffffffu) {
         const uint4 mm = *reinterpret_cast<const uint4*>(cg->lut + ((unsigned)y * (4u * lutc_pitch) + (unsigned)x0));
         const unsigned code[4] = {mm.x, mm.y, mm.z, mm.w};
 #pragma unroll
@@ -814,6 +824,7 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
             case 12: PANO_LAUNCH_K1(warp_tiles_lut_kernel<12>, grid_lut); return;
             case 17: PANO_LAUNCH_K1(warp_tiles_lut_kernel<17>, grid_lut); return;
             case 18: PANO_LAUNCH_K1(warp_tiles_lut_kernel<18>, grid_lut); return;
+            case 20: PANO_LAUNCH_K1(warp_tiles_lut_kernel<20>, grid_lut); return;
             case 13: fast = false; break;  // the general kernel
             default: break;
         }

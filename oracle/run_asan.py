@@ -18,4 +18,12 @@ for kind in (0, 1):
     for nb in (-1, 0, 3):
         out, _ = po.compose(frames, K, d["R"], d["scale"], masks, nb, kind=kind)
         out2, _ = po.compose(frames, K, d["R"], d["scale"], masks, nb, kind=kind, cut=(5, 7, 300, 100))
+# gain estimation (BlocksGainCompensator::feed from frames) and the caller-side / front-end helpers
+for kind in (0, 1):
+    for bl in ((32, 32), (16, 24), (500, 500)):
+        po.estimate_gains(frames, K, d["R"], d["scale"], kind, *bl)
+rng = np.random.default_rng(0)
+imgs = [rng.integers(0, 256, (37, 53, 3), dtype=np.uint8), rng.integers(0, 256, (41, 47, 3), dtype=np.uint8)]
+po.gain_blocks_feed([(0, 0), (30, 5)], imgs, [np.full(i.shape[:2], 255, np.uint8) for i in imgs], 8, 8)
+po.gain_feed([(0, 0), (1000, 5)], imgs, [np.full(i.shape[:2], 255, np.uint8) for i in imgs])
 print("oracle ran clean under ASan/UBSan")
