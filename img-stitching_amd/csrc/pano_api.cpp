@@ -1829,14 +1829,22 @@ pano_status pano_get_warp_bytes(const pano_ctx* c, uint64_t* src_bytes, uint64_t
         // are written once (planar u8), and the same share of the frame is what they sample
         const int tw = c->plan.tile[i].rect.w, th = c->plan.tile[i].rect.h;
         const int* L = c->live[i][0];
-        uint64_t live_px = 0;
+        uint64_t live_px = 0, dead_px = 0;
         if (L[2] >= L[0] && L[3] >= L[1]) {
             const int x0 = (L[0] >> 6) << 6, x1 = std::min(((L[2] >> 6) + 1) << 6, tw);
             const int y0 = (L[1] >> 4) << 4, y1 = std::min(((L[3] >> 4) + 1) << 4, th);
             live_px = (uint64_t)(x1 - x0) * (uint64_t)(y1 - y0);
+            // the dead middle of a +-pi straddler: its block columns are not produced, and its columns are no part of the
+            // tile area the frame maps onto
+            const int* G = c->gap[i][0];
+            const int g0 = (G[0] + 63) >> 6, g1 = ((G[1] + 1) >> 6) - 1;
+            if (G[1] >= G[0] && g1 >= g0) {
+                live_px -= (uint64_t)(g1 - g0 + 1) * 64 * (uint64_t)(y1 - y0);
+                dead_px = (uint64_t)(G[1] - G[0] + 1) * (uint64_t)th;
+            }
         }
         d += live_px * 3;
-        s += (uint64_t)((double)c->frame_w * c->frame_h * 3 * ((double)live_px / ((double)tw * th)));
+        s += (uint64_t)((double)c->frame_w * c->frame_h * 3 * std::min(1.0, (double)live_px / ((double)tw * th - (double)dead_px)));
     }
     *src_bytes = s;
     *dst_bytes = d;

@@ -1267,15 +1267,31 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     const int pb = NPL == 3 ? 0 : (int)(blockIdx.z % 3);  // first plane of this lane
     const CanvasParams& C = CS.c[NPL == 3 ? blockIdx.z : blockIdx.z / 3];
     const int cam_lo = C.cam_lo, cam_n = C.cam_n;
-    const int l = L0 ? 0 : lvl;
+    const int l = L0 ? 0 : (lvl & 0xff);
     const int cw = C.w0 >> l, ch = C.h0 >> l;
     // level 0 covers only the block-aligned hull of the cut rectangle
     const int bx0 = L0 ? (C.cut_x & ~3) : 0, by0 = L0 ? (C.cut_y & ~1) : 0;
     // a wave is 16 x 4 blocks = 64 x 8 pixels (not a 256-pixel strip): four times fewer waves straddle a seam,
-    // and a wave that does not straddle one takes the single-owner fast path below
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int X0 = bx0 + (blockIdx.x * 16 + (tid & 15)) * 4;
-    const int Y0 = by0 + (blockIdx.y * 16 + (tid >> 4)) * 2;
+    // and a wave that does not straddle one takes the single-owner fast path below.
+    // The four waves of a workgroup form a 2 x 2 patch (128 x 16 pixels).  Consecutive workgroups go to different XCDs,
+    // each with its own L2, so what a workgroup reads of a row should be whole 128-byte lines: stacked (64 x 32 pixels,
+    // shape 1) the 64 bytes a wave reads of a u8 plane row are half a line and the level-0 launch fetched 152 MB for the
+    // ~45 MB it uses; side by side (256 x 8, shape 0) it fetches 74 MB.  Measured per frame (levels 0-2, C2), stacked /
+    // side by side / 2 x 2: HBM bytes of these launches 247 / 145 / 182 MB, panoramas/s one frame at a time 7.18 / 7.35 /
+    // 7.27 k, with four frames in flight 11.77 / 11.64 / 11.83 k (same box, alternating): bytes are not what bounds the
+    // pipeline, and 2 x 2 is the fastest where it counts.  PANO_K3_SHAPE=0|1|2.
+    int X0, Y0;
+    if ((lvl >> 8) == 1) {         // stacked
+        const int tid = threadIdx.y * 64 + threadIdx.x;
+        X0 = bx0 + (blockIdx.x * 16 + (tid & 15)) * 4;
+        Y0 = by0 + (blockIdx.y * 16 + (tid >> 4)) * 2;
+    } else if ((lvl >> 8) == 0) {  // side by side
+        X0 = bx0 + ((blockIdx.x * 4 + threadIdx.y) * 16 + (threadIdx.x & 15)) * 4;
+        Y0 = by0 + (blockIdx.y * 4 + (threadIdx.x >> 4)) * 2;
+    } else {                       // 2 x 2
+        X0 = bx0 + ((blockIdx.x * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
+        Y0 = by0 + ((blockIdx.y * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * 2;
+    }
     if (L0) {
         if (X0 >= C.cut_x + C.cut_w || Y0 >= C.cut_y + C.cut_h) return;
     } else if (X0 >= cw || Y0 >= ch) {
@@ -1745,23 +1761,28 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
                 h = max(h, cg.h0 >> l);
             }
         }
-        dim3 block(64, 4, 1), grid((w + 63) / 64, (h + 31) / 32, cs.n);
+        // workgroup shape (see the kernel): 2 = 2 x 2 waves (default), 0 = side by side, 1 = stacked
+        static const int stacked = getenv("PANO_K3_SHAPE") ? atoi(getenv("PANO_K3_SHAPE")) & 3 : 2;
+        dim3 block(64, 4, 1), grid((w + 127) / 128, (h + 15) / 16, cs.n);
+        if (stacked == 0) grid = dim3((w + 255) / 256, (h + 7) / 8, cs.n);
+        if (stacked == 1) grid = dim3((w + 63) / 64, (h + 31) / 32, cs.n);
+        const int larg = l | ((stacked == 3 ? 2 : stacked) << 8);
 #ifdef PANO_DIAG
         static const int kabl = getenv("PANO_K3_ABL") ? atoi(getenv("PANO_K3_ABL")) : 0;
-        if (l == 0 && kabl == 1) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 1>), grid, block, 0, s, p, cs, l); return; }
-        if (l == 0 && kabl == 2) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 2>), grid, block, 0, s, p, cs, l); return; }
-        if (l == 0 && kabl == 3) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 3>), grid, block, 0, s, p, cs, l); return; }
-        if (l == 0 && kabl == 4) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 4>), grid, block, 0, s, p, cs, l); return; }
-        if (l == 0 && kabl == 5) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 5>), grid, block, 0, s, p, cs, l); return; }
+        if (l == 0 && kabl == 1) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 1>), grid, block, 0, s, p, cs, larg); return; }
+        if (l == 0 && kabl == 2) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 2>), grid, block, 0, s, p, cs, larg); return; }
+        if (l == 0 && kabl == 3) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 3>), grid, block, 0, s, p, cs, larg); return; }
+        if (l == 0 && kabl == 4) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 4>), grid, block, 0, s, p, cs, larg); return; }
+        if (l == 0 && kabl == 5) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 5>), grid, block, 0, s, p, cs, larg); return; }
         if (l == 0 && kabl == 6) return;  // diagnostic: level 0 not launched at all
 #endif
-        if (l == 0) hipLaunchKernelGGL((blend_level_vec_kernel<true, 0>), grid, block, 0, s, p, cs, l);
+        if (l == 0) hipLaunchKernelGGL((blend_level_vec_kernel<true, 0>), grid, block, 0, s, p, cs, larg);
         else {
             // one plane per lane on the canvas levels >= 1 (measured: levels 1 + 2 29 -> 23 us, in flight no worse);
             // PANO_BLEND_PLANES=0 keeps three planes per lane
             static const bool split = !(getenv("PANO_BLEND_PLANES") && atoi(getenv("PANO_BLEND_PLANES")) == 0);
-            if (split) hipLaunchKernelGGL((blend_level_vec_kernel<false, 0, 1>), dim3(grid.x, grid.y, cs.n * 3), block, 0, s, p, cs, l);
-            else hipLaunchKernelGGL((blend_level_vec_kernel<false, 0, 3>), grid, block, 0, s, p, cs, l);
+            if (split) hipLaunchKernelGGL((blend_level_vec_kernel<false, 0, 1>), dim3(grid.x, grid.y, cs.n * 3), block, 0, s, p, cs, larg);
+            else hipLaunchKernelGGL((blend_level_vec_kernel<false, 0, 3>), grid, block, 0, s, p, cs, larg);
         }
         return;
     }

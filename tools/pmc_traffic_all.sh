@@ -1,0 +1,31 @@
+# HBM bytes of EVERY kernel of the compose path per 8-camera frame: FETCH_SIZE and WRITE_SIZE in separate passes
+# (MI355X_MICROARCH.md, HBM section; gfx950: FETCH_SIZE x2) over tools/warp_ablate8.py.  Usage: bash tools/pmc_traffic_all.sh
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/taF $R/gpurun_out/taW
+timeout -k 10 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/taF -o run --output-format csv -- python3 $R/tools/warp_ablate8.py > $R/gpurun_out/taF.log 2>&1 || exit 1
+timeout -k 10 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/taW -o run --output-format csv -- python3 $R/tools/warp_ablate8.py > $R/gpurun_out/taW.log 2>&1 || exit 1
+python3 - <<'PY'
+import csv, collections, json, os
+R = os.environ["GRAFT_REPO_ROOT"]
+out = collections.defaultdict(dict)
+frames = None
+for tag, name in (("taF", "FETCH_SIZE"), ("taW", "WRITE_SIZE")):
+    agg, calls = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(f"{R}/gpurun_out/{tag}/run_counter_collection.csv")):
+        if r["Counter_Name"] != name: continue
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k] += float(r["Counter_Value"]); calls[k] += 1
+    frames = calls[[k for k in calls if "warp_tiles_lut" in k][0]]
+    for k in agg:
+        if calls[k] >= frames:
+            out[k][name + "_KB_per_frame_raw"] = round(agg[k] / frames, 1)
+            out[k]["launches_per_frame"] = round(calls[k] / frames, 2)
+tot = 0.0
+for k, v in out.items():
+    v["hbm_MB_per_frame"] = round((2 * v.get("FETCH_SIZE_KB_per_frame_raw", 0) + v.get("WRITE_SIZE_KB_per_frame_raw", 0)) * 1024 / 1e6, 2)
+    tot += v["hbm_MB_per_frame"]
+out["_total_hbm_MB_per_frame"] = round(tot, 1)
+json.dump(out, open(R + "/gpurun_out/traffic_all.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
