@@ -289,6 +289,19 @@ def main():
                         "in_timed_region": dict(timed, frames_in_flight=F),
                         "one_frame_at_a_time_panoramas_per_s": alone_rate,
                         "one_frame_at_a_time_stage_us": alone_stage}
+        if world > 1 and stage_n[0]:
+            # N > 1: rank 0's own K1 launches (its cameras of each group, one launch per group it feeds), taken from the
+            # event pass; the algorithmic bytes are its cameras' share of the group's
+            fed = [bin(pl["bits"]).count("1") for pl in plans if pl["bits"]]
+            if fed:
+                alg_rank0 = (src_b + dst_b) * fed[0] // NC
+                avg_ms = stage_ms[0] / stage_n[0]
+                ach = alg_rank0 / (avg_ms * 1e-3) / 1e9
+                roofline = {"kernel": "warp_tiles_lut_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                            "algorithmic_bytes_per_launch": alg_rank0, "avg_launch_us": round(avg_ms * 1e3, 2),
+                            "launches_per_step": len(fed),
+                            "measured": "rank 0, K steps of the sharded path, dispatch events of its %d-camera launches" % fed[0]}
         result = {
             "metric": "stitched panoramas/sec (8x1080p->pano)", "value": round((args.steps if sharded_failed is None else world * args.steps) / dt, 2),
             "unit": "panoramas/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
