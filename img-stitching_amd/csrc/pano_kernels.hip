@@ -1776,6 +1776,11 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
         if (l == 0 && kabl == 5) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 5>), grid, block, 0, s, p, cs, larg); return; }
         if (l == 0 && kabl == 6) return;  // diagnostic: level 0 not launched at all
 #endif
+#ifdef PANO_DIAG
+        // diagnostic: unused dynamic LDS per workgroup caps the workgroups per CU (160 KB / bytes), i.e. the waves per SIMD
+        static const int klds = getenv("PANO_K3_LDS") ? atoi(getenv("PANO_K3_LDS")) : 0;
+        if (l == 0 && klds > 0) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 0>), grid, block, klds, s, p, cs, larg); return; }
+#endif
         if (l == 0) hipLaunchKernelGGL((blend_level_vec_kernel<true, 0>), grid, block, 0, s, p, cs, larg);
         else {
             // one plane per lane on the canvas levels >= 1 (measured: levels 1 + 2 29 -> 23 us, in flight no worse);
