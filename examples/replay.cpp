@@ -3,7 +3,7 @@
 // half-panoramas stacked with a black divider.  No OpenCV: frames are binary PPM (P6) files or synthetic.
 //
 //   g++ -O2 -std=c++17 examples/replay.cpp -o replay -Limg-stitching_amd -lpano_hip -Wl,-rpath,$PWD/img-stitching_amd -lpthread
-//   ./replay <stitcher-cfg.yaml> [--plan] [--exposure] [--frames N] [up0.ppm up1.ppm ... down0.ppm ...]
+//   ./replay <stitcher-cfg.yaml> [--plan] [--exposure] [--voronoi] [--frames N] [up0.ppm up1.ppm ... down0.ppm ...]
 //
 // --plan: geometry only (no GPU): prints the panorama size of both stitchers and exits.
 // --exposure: estimate block gains in calibration() and apply them in process() (the reference estimates, ocvstitcher.hpp:1031-1032,
@@ -54,15 +54,16 @@ static void synthetic(pano::Mat& m, int w, int h, int seed) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: replay <stitcher-cfg.yaml> [--plan] [--exposure] [--frames N] [ppm files]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: replay <stitcher-cfg.yaml> [--plan] [--exposure] [--voronoi] [--frames N] [ppm files]\n"); return 2; }
     std::string cfg = argv[1];
-    bool plan = false, exposure = false;
+    bool plan = false, exposure = false, voronoi = false;
     int nframes = 3;
     std::vector<std::string> files;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--plan") plan = true;
         else if (a == "--exposure") exposure = true;
+        else if (a == "--voronoi") voronoi = true;
         else if (a == "--frames" && i + 1 < argc) nframes = atoi(argv[++i]);
         else files.push_back(a);
     }
@@ -70,6 +71,7 @@ int main(int argc, char** argv) {
     for (int s = 0; s < 2; s++) {
         if (plan) st[s].device = -1;
         st[s].exposureCompensation = exposure;
+        if (voronoi) st[s].seamFinder = pano::Stitcher::SeamVoronoi;  // default: graph cut, like the reference
         if (st[s].init(cfg, s) != pano::RET_OK) { fprintf(stderr, "stitcher %d init failed\n", s); return 1; }
     }
     const int n = st[0].config().num_images, W = st[0].config().width, H = st[0].config().height;

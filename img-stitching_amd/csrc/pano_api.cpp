@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "pano_graphcut.hpp"
 #include "pano_kernels.hpp"
 #include "pano_plan.hpp"
 
@@ -640,6 +641,108 @@ void smooth121(std::vector<float>& m, int w, int h) {
             m[(size_t)y * w + x] = (t[(size_t)r101(y - 1, h) * w + x] + t[(size_t)r101(y + 1, h) * w + x]) * 0.25f + t[(size_t)y * w + x] * 0.5f;
 }
 
+// What initSeam / updateMask put in front of the seam finder and the compensator (ocvstitcher.hpp:981-1017, :1228-1242):
+// per camera the seam-scale ROI, the INTER_NEAREST / BORDER_CONSTANT warp of an all-255 mask and - when frames are given -
+// resize(frame, seam_work_aspect, INTER_LINEAR_EXACT) warped INTER_LINEAR / BORDER_REFLECT.  Device buffers live in `tmp`
+struct SeamWarps {
+    std::vector<Rect> roi;
+    std::vector<uint8_t*> img, mask;  // dense 8UC3 / 8U, roi[i].w x roi[i].h (img: nullptr without frames)
+};
+pano_status seam_scale_warps(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides, Scratch& tmp, hipStream_t s,
+                             SeamWarps& out) {
+    const Plan& P = c->plan;
+    const int n = P.n, sw = P.src_w, sh = P.src_h;
+    auto oom = [&]() { return fail(c, PANO_EHIP, "hipMalloc / hipMemcpy (seam-scale warps)"); };
+    // seam scale (ocvstitcher.hpp:298, :988-1017)
+    const double swa = std::min(1.0, std::sqrt(1e5 / ((double)sh * sw)));
+    const int ssw = (int)std::lrint(sw * swa), ssh = (int)std::lrint(sh * swa);
+    const float seam_scale = static_cast<float>(c->scale * swa), swa_f = (float)swa;
+    // resize(imgs[i], seam_work_aspect, INTER_LINEAR_EXACT) (:988): one coefficient set for all cameras
+    std::vector<int> xo, xc, yo, yc;
+    int mnx = 0, mxx = 0, mny = 0, mxy = 0;
+    int *dxo = nullptr, *dxc = nullptr, *dyo = nullptr, *dyc = nullptr;
+    const bool shrink = h_frames && (ssw != sw || ssh != sh);
+    if (shrink) {
+        linearExactCoeffs(sw, ssw, xo, xc, mnx, mxx);
+        linearExactCoeffs(sh, ssh, yo, yc, mny, mxy);
+        if (!tmp.put(&dxo, xo.data(), xo.size() * sizeof(int)) || !tmp.put(&dxc, xc.data(), xc.size() * sizeof(int)) ||
+            !tmp.put(&dyo, yo.data(), yo.size() * sizeof(int)) || !tmp.put(&dyc, yc.data(), yc.size() * sizeof(int)))
+            return oom();
+    }
+    out.roi.assign(n, Rect{});
+    out.img.assign(n, nullptr);
+    out.mask.assign(n, nullptr);
+    std::vector<float> a, b;
+    for (int i = 0; i < n; i++) {
+        float K[9];
+        std::memcpy(K, c->K[i], sizeof(K));
+        K[0] *= swa_f; K[2] *= swa_f; K[4] *= swa_f; K[5] *= swa_f;
+        Projector pj;
+        pj.set(c->cfg.projector, seam_scale, K, c->R[i]);
+        const Rect r = out.roi[i] = warpRoi(pj, ssw, ssh);
+        trigTables(pj, r, 0, 0, r.w, r.h, a, b);
+        float2 *dA = nullptr, *dB = nullptr;
+        if (!tmp.put(&dA, a.data(), a.size() * sizeof(float)) || !tmp.put(&dB, b.data(), b.size() * sizeof(float)) ||
+            !tmp.alloc(&out.mask[i], (size_t)r.w * r.h))
+            return oom();
+        // seamfinder_warper->warp(.., INTER_LINEAR, BORDER_REFLECT) and (.., INTER_NEAREST, BORDER_CONSTANT) (:1011-1014)
+        WarpCam w{};
+        w.src_w = ssw; w.src_h = ssh;
+        w.out_w = ssw; w.out_h = ssh;
+        std::memcpy(w.m, pj.k_rinv, sizeof(w.m));
+        w.colA = dA; w.rowB = dB; w.tw = r.w; w.th = r.h;
+        if (h_frames) {
+            uint8_t *full = nullptr, *small = nullptr;
+            if (!tmp.alloc(&full, (size_t)sw * sh * 3 + 16) || !tmp.alloc(&out.img[i], (size_t)r.w * r.h * 3)) return oom();
+            HIP_TRY(c, hipMemcpy2DAsync(full, (size_t)sw * 3, h_frames[i], strides[i], (size_t)sw * 3, sh, hipMemcpyHostToDevice, s));
+            small = full;
+            if (shrink) {
+                if (!tmp.alloc(&small, (size_t)ssw * ssh * 3 + 16)) return oom();
+                launch_resize_linear_exact(full, sw, sh, 3, small, ssw, ssh, dxo, dxc, dyo, dyc, mnx, mxx, mny, mxy, s);
+            }
+            w.src = small; w.src_stride = ssw * 3;
+            w.dst = out.img[i]; w.dst_pitch = r.w * 3;
+            launch_warp_image(w, s);
+        }
+        launch_warp_mask(w, out.mask[i], r.w, s);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return PANO_OK;
+}
+
+// ... and behind the seam finder (ocvstitcher.hpp:1085, :1097-1101, :1246-1257): the full-scale NEAREST mask, the seam mask
+// dilated 3 x 3 and resized INTER_LINEAR_EXACT to the ROI, their AND = m_blenderMask[i]
+pano_status finish_seam_masks(pano_ctx* c, const SeamWarps& sm, Scratch& tmp, hipStream_t s) {
+    const Plan& P = c->plan;
+    auto oom = [&]() { return fail(c, PANO_EHIP, "hipMalloc / hipMemcpy (blend masks)"); };
+    for (int i = 0; i < P.n; i++) {
+        const Rect& r = P.roi[i];
+        const Rect& q = sm.roi[i];
+        uint8_t *full = nullptr, *dil = nullptr, *seam = nullptr;
+        if (!tmp.alloc(&full, (size_t)r.w * r.h) || !tmp.alloc(&dil, (size_t)q.w * q.h) || !tmp.alloc(&seam, (size_t)r.w * r.h)) return oom();
+        WarpCam w = make_warp_cam(c, i, nullptr, 0, true);
+        launch_warp_mask(w, full, r.w, s);
+        launch_dilate3x3(sm.mask[i], dil, q.w, q.h, s);
+        std::vector<int> xo, xc, yo, yc;
+        int mnx, mxx, mny, mxy;
+        linearExactCoeffs(q.w, r.w, xo, xc, mnx, mxx);
+        linearExactCoeffs(q.h, r.h, yo, yc, mny, mxy);
+        int *dxo = nullptr, *dxc = nullptr, *dyo = nullptr, *dyc = nullptr;
+        if (!tmp.put(&dxo, xo.data(), xo.size() * sizeof(int)) || !tmp.put(&dxc, xc.data(), xc.size() * sizeof(int)) ||
+            !tmp.put(&dyo, yo.data(), yo.size() * sizeof(int)) || !tmp.put(&dyc, yc.data(), yc.size() * sizeof(int)))
+            return oom();
+        launch_resize_linear_exact(dil, q.w, q.h, 1, seam, r.w, r.h, dxo, dxc, dyo, dyc, mnx, mxx, mny, mxy, s);
+        launch_and(seam, full, c->mask[i], (size_t)r.w * r.h, s);
+        c->mask_set[i] = true;
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipGetLastError());
+    c->weights_dirty = true;
+    live_rects(c, {});  // until the weights are rebuilt, produce every pixel
+    drop_graphs(c);
+    return PANO_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1135,44 +1238,12 @@ pano_status pano_get_mask(pano_ctx* c, int i, uint8_t* h_mask, size_t stride) {
 pano_status pano_build_masks_voronoi(pano_ctx* c) {
     pano_status st = check_compute(c);
     if (st != PANO_OK) return st;
-    const Plan& P = c->plan;
-    const int n = P.n, sw = P.src_w, sh = P.src_h;
+    const int n = c->plan.n;
     hipStream_t s = c->own_stream;
-    // seam scale (ocvstitcher.hpp:298, :988-1017)
-    double swa = std::min(1.0, std::sqrt(1e5 / ((double)sh * sw)));
-    int ssw = (int)std::lrint(sw * swa), ssh = (int)std::lrint(sh * swa);
-    float seam_scale = static_cast<float>(c->scale * swa);
-    float swa_f = (float)swa;
-    std::vector<Rect> sroi(n);
-    std::vector<uint8_t*> smask(n, nullptr);
-    std::vector<void*> to_free;
-    auto cleanup = [&]() {
-        for (void* p : to_free) (void)hipFree(p);
-    };
-    std::vector<float> a, b;
-    for (int i = 0; i < n; i++) {
-        float K[9];
-        std::memcpy(K, c->K[i], sizeof(K));
-        K[0] *= swa_f; K[2] *= swa_f; K[4] *= swa_f; K[5] *= swa_f;
-        Projector pj;
-        pj.set(c->cfg.projector, seam_scale, K, c->R[i]);
-        sroi[i] = warpRoi(pj, ssw, ssh);
-        trigTables(pj, sroi[i], 0, 0, sroi[i].w, sroi[i].h, a, b);
-        float2 *dA = nullptr, *dB = nullptr;
-        pano_status u;
-        if ((u = upload(c, &dA, a.data(), a.size() * sizeof(float)))) { cleanup(); return u; }
-        to_free.push_back(dA);
-        if ((u = upload(c, &dB, b.data(), b.size() * sizeof(float)))) { cleanup(); return u; }
-        to_free.push_back(dB);
-        if (hipMalloc((void**)&smask[i], (size_t)sroi[i].w * sroi[i].h) != hipSuccess) { cleanup(); return fail(c, PANO_EHIP, "hipMalloc"); }
-        to_free.push_back(smask[i]);
-        WarpCam w{};
-        w.src_w = ssw; w.src_h = ssh;
-        w.out_w = ssw; w.out_h = ssh;
-        std::memcpy(w.m, pj.k_rinv, sizeof(w.m));
-        w.colA = dA; w.rowB = dB; w.tw = sroi[i].w; w.th = sroi[i].h;
-        launch_warp_mask(w, smask[i], sroi[i].w, s);
-    }
+    Scratch tmp;
+    SeamWarps sm;
+    if ((st = seam_scale_warps(c, nullptr, nullptr, tmp, s, sm)) != PANO_OK) return st;
+    const std::vector<Rect>& sroi = sm.roi;
     // PairwiseSeamFinder::run order
     for (int i = 0; i < n - 1; i++)
         for (int j = i + 1; j < n; j++) {
@@ -1181,53 +1252,62 @@ pano_status pano_build_masks_voronoi(pano_ctx* c) {
             int y_br = std::min(sroi[i].y + sroi[i].h, sroi[j].y + sroi[j].h);
             if (!(x_tl < x_br && y_tl < y_br)) continue;
             int* scratch = nullptr;
-            if (hipMalloc((void**)&scratch, voronoi_scratch_ints(x_br - x_tl, y_br - y_tl) * sizeof(int)) != hipSuccess) {
-                cleanup();
-                return fail(c, PANO_EHIP, "hipMalloc");
-            }
-            to_free.push_back(scratch);
-            launch_voronoi_pair(smask[i], sroi[i].w, sroi[i].h, sroi[i].x, sroi[i].y, smask[j], sroi[j].w, sroi[j].h,
+            if (!tmp.alloc(&scratch, voronoi_scratch_ints(x_br - x_tl, y_br - y_tl) * sizeof(int))) return fail(c, PANO_EHIP, "hipMalloc");
+            launch_voronoi_pair(sm.mask[i], sroi[i].w, sroi[i].h, sroi[i].x, sroi[i].y, sm.mask[j], sroi[j].w, sroi[j].h,
                                 sroi[j].x, sroi[j].y, x_tl, y_tl, x_br - x_tl, y_br - y_tl, scratch, s);
         }
-    // full-size: warp mask, dilate seam mask, resize, and (ocvstitcher.hpp:1085, :1097-1101)
-    for (int i = 0; i < n; i++) {
-        const Rect& r = P.roi[i];
-        uint8_t *full = nullptr, *dil = nullptr, *seam = nullptr;
-        if (hipMalloc((void**)&full, (size_t)r.w * r.h) != hipSuccess) { cleanup(); return fail(c, PANO_EHIP, "hipMalloc"); }
-        to_free.push_back(full);
-        if (hipMalloc((void**)&dil, (size_t)sroi[i].w * sroi[i].h) != hipSuccess) { cleanup(); return fail(c, PANO_EHIP, "hipMalloc"); }
-        to_free.push_back(dil);
-        if (hipMalloc((void**)&seam, (size_t)r.w * r.h) != hipSuccess) { cleanup(); return fail(c, PANO_EHIP, "hipMalloc"); }
-        to_free.push_back(seam);
-        WarpCam w = make_warp_cam(c, i, nullptr, 0, true);
-        launch_warp_mask(w, full, r.w, s);
-        launch_dilate3x3(smask[i], dil, sroi[i].w, sroi[i].h, s);
-        std::vector<int> xo, xc, yo, yc;
-        int mnx, mxx, mny, mxy;
-        linearExactCoeffs(sroi[i].w, r.w, xo, xc, mnx, mxx);
-        linearExactCoeffs(sroi[i].h, r.h, yo, yc, mny, mxy);
-        int *dxo = nullptr, *dxc = nullptr, *dyo = nullptr, *dyc = nullptr;
-        pano_status u;
-        if ((u = upload(c, &dxo, xo.data(), xo.size() * sizeof(int)))) { cleanup(); return u; }
-        to_free.push_back(dxo);
-        if ((u = upload(c, &dxc, xc.data(), xc.size() * sizeof(int)))) { cleanup(); return u; }
-        to_free.push_back(dxc);
-        if ((u = upload(c, &dyo, yo.data(), yo.size() * sizeof(int)))) { cleanup(); return u; }
-        to_free.push_back(dyo);
-        if ((u = upload(c, &dyc, yc.data(), yc.size() * sizeof(int)))) { cleanup(); return u; }
-        to_free.push_back(dyc);
-        launch_resize_linear_exact(dil, sroi[i].w, sroi[i].h, 1, seam, r.w, r.h, dxo, dxc, dyo, dyc, mnx, mxx, mny, mxy, s);
-        launch_and(seam, full, c->mask[i], (size_t)r.w * r.h, s);
-        c->mask_set[i] = true;
-    }
-    hipError_t e = hipStreamSynchronize(s);
-    cleanup();
-    if (e != hipSuccess) return fail(c, PANO_EHIP, hipGetErrorString(e));
-    HIP_TRY(c, hipGetLastError());
-    c->weights_dirty = true;
-    live_rects(c, {});  // until the weights are rebuilt, produce every pixel
-    drop_graphs(c);
-    return PANO_OK;
+    return finish_seam_masks(c, sm, tmp, s);
+}
+
+pano_status pano_build_masks_graphcut(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (!h_frames || !strides) return PANO_EINVAL;
+    const int n = c->plan.n;
+    for (int i = 0; i < n; i++)
+        if (!h_frames[i] || strides[i] < (size_t)c->plan.src_w * 3) return fail(c, PANO_EINVAL, "frame pointer / stride");
+    hipStream_t s = c->own_stream;
+    Scratch tmp;
+    SeamWarps sm;
+    if ((st = seam_scale_warps(c, h_frames, strides, tmp, s, sm)) != PANO_OK) return st;
+    GainImages gi{};
+    for (int i = 0; i < n; i++) { gi.img[i] = sm.img[i]; gi.mask[i] = sm.mask[i]; gi.w[i] = sm.roi[i].w; }
+    // PairwiseSeamFinder::run order; GraphCutSeamFinder::Impl::findInPair per overlapping pair: weights on the GPU, the
+    // max-flow on the host (pano_graphcut.hpp), the mask update on the GPU - a later pair sees the masks the earlier left
+    const int gap = 10;
+    std::vector<float> term, wh, wv;
+    std::vector<uint8_t> in_source;
+    for (int i = 0; i < n - 1; i++)
+        for (int j = i + 1; j < n; j++) {
+            const Rect &ra = sm.roi[i], &rb = sm.roi[j];
+            const int x_tl = std::max(ra.x, rb.x), y_tl = std::max(ra.y, rb.y);
+            const int x_br = std::min(ra.x + ra.w, rb.x + rb.w), y_br = std::min(ra.y + ra.h, rb.y + rb.h);
+            if (!(x_tl < x_br && y_tl < y_br)) continue;
+            GcPair q{};
+            q.W = x_br - x_tl + 2 * gap; q.H = y_br - y_tl + 2 * gap;
+            q.a = i; q.ax = x_tl - ra.x - gap; q.ay = y_tl - ra.y - gap; q.wa = ra.w; q.ha = ra.h;
+            q.b = j; q.bx = x_tl - rb.x - gap; q.by = y_tl - rb.y - gap; q.wb = rb.w; q.hb = rb.h;
+            const size_t nv = (size_t)q.W * q.H;
+            float *d_term = nullptr, *d_wh = nullptr, *d_wv = nullptr;
+            uint8_t* d_lab = nullptr;
+            if (!tmp.alloc(&d_term, nv * sizeof(float)) || !tmp.alloc(&d_wh, nv * sizeof(float)) || !tmp.alloc(&d_wv, nv * sizeof(float)) ||
+                !tmp.alloc(&d_lab, nv))
+                return fail(c, PANO_EHIP, "hipMalloc (graph cut)");
+            launch_graphcut_weights(gi, q, d_term, d_wh, d_wv, s);
+            HIP_TRY(c, hipGetLastError());
+            term.resize(nv); wh.resize(nv); wv.resize(nv); in_source.resize(nv);
+            HIP_TRY(c, hipMemcpyAsync(term.data(), d_term, nv * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(wh.data(), d_wh, nv * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(wv.data(), d_wv, nv * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            GridMaxFlow flow(q.W, q.H, term.data(), wh.data(), wv.data());
+            flow.run();
+            for (size_t k = 0; k < nv; k++) in_source[k] = flow.inSource((int)k) ? 1 : 0;
+            HIP_TRY(c, hipMemcpyAsync(d_lab, in_source.data(), nv, hipMemcpyHostToDevice, s));
+            launch_graphcut_apply(q, sm.mask[i], sm.mask[j], d_lab, gap, s);
+            HIP_TRY(c, hipStreamSynchronize(s));  // in_source is reused by the next pair
+        }
+    return finish_seam_masks(c, sm, tmp, s);
 }
 
 pano_status pano_set_gain_map(pano_ctx* c, int i, const float* h_gain, int gw, int gh) {
@@ -1265,63 +1345,17 @@ pano_status pano_estimate_gains(pano_ctx* c, const uint8_t* const* h_frames, con
     if (st != PANO_OK) return st;
     if (!h_frames || !strides || block_w < 1 || block_h < 1) return PANO_EINVAL;
     const Plan& P = c->plan;
-    const int n = P.n, sw = P.src_w, sh = P.src_h;
+    const int n = P.n, sw = P.src_w;
     for (int i = 0; i < n; i++)
         if (!h_frames[i] || strides[i] < (size_t)sw * 3) return fail(c, PANO_EINVAL, "frame pointer / stride");
     hipStream_t s = c->own_stream;
     Scratch tmp;
     auto oom = [&]() { return fail(c, PANO_EHIP, "hipMalloc / hipMemcpy (gain estimation)"); };
-    // seam scale, exactly as the mask half of initSeam (ocvstitcher.hpp:298, :988-1017)
-    const double swa = std::min(1.0, std::sqrt(1e5 / ((double)sh * sw)));
-    const int ssw = (int)std::lrint(sw * swa), ssh = (int)std::lrint(sh * swa);
-    const float seam_scale = static_cast<float>(c->scale * swa), swa_f = (float)swa;
-    // resize(imgs[i], seam_work_aspect, INTER_LINEAR_EXACT) (:988): one coefficient set for all cameras
-    std::vector<int> xo, xc, yo, yc;
-    int mnx = 0, mxx = 0, mny = 0, mxy = 0;
-    int *dxo = nullptr, *dxc = nullptr, *dyo = nullptr, *dyc = nullptr;
-    const bool shrink = ssw != sw || ssh != sh;
-    if (shrink) {
-        linearExactCoeffs(sw, ssw, xo, xc, mnx, mxx);
-        linearExactCoeffs(sh, ssh, yo, yc, mny, mxy);
-        if (!tmp.put(&dxo, xo.data(), xo.size() * sizeof(int)) || !tmp.put(&dxc, xc.data(), xc.size() * sizeof(int)) ||
-            !tmp.put(&dyo, yo.data(), yo.size() * sizeof(int)) || !tmp.put(&dyc, yc.data(), yc.size() * sizeof(int)))
-            return oom();
-    }
-    std::vector<Rect> sroi(n);
+    SeamWarps sm;
+    if ((st = seam_scale_warps(c, h_frames, strides, tmp, s, sm)) != PANO_OK) return st;
+    const std::vector<Rect>& sroi = sm.roi;
     GainImages gi{};
-    std::vector<float> a, b;
-    for (int i = 0; i < n; i++) {
-        float K[9];
-        std::memcpy(K, c->K[i], sizeof(K));
-        K[0] *= swa_f; K[2] *= swa_f; K[4] *= swa_f; K[5] *= swa_f;
-        Projector pj;
-        pj.set(c->cfg.projector, seam_scale, K, c->R[i]);
-        sroi[i] = warpRoi(pj, ssw, ssh);
-        trigTables(pj, sroi[i], 0, 0, sroi[i].w, sroi[i].h, a, b);
-        float2 *dA = nullptr, *dB = nullptr;
-        uint8_t *full = nullptr, *small = nullptr, *img = nullptr, *mask = nullptr;
-        if (!tmp.put(&dA, a.data(), a.size() * sizeof(float)) || !tmp.put(&dB, b.data(), b.size() * sizeof(float)) ||
-            !tmp.alloc(&full, (size_t)sw * sh * 3 + 16) || !tmp.alloc(&img, (size_t)sroi[i].w * sroi[i].h * 3) ||
-            !tmp.alloc(&mask, (size_t)sroi[i].w * sroi[i].h))
-            return oom();
-        HIP_TRY(c, hipMemcpy2DAsync(full, (size_t)sw * 3, h_frames[i], strides[i], (size_t)sw * 3, sh, hipMemcpyHostToDevice, s));
-        small = full;
-        if (shrink) {
-            if (!tmp.alloc(&small, (size_t)ssw * ssh * 3 + 16)) return oom();
-            launch_resize_linear_exact(full, sw, sh, 3, small, ssw, ssh, dxo, dxc, dyo, dyc, mnx, mxx, mny, mxy, s);
-        }
-        // seamfinder_warper->warp(.., INTER_LINEAR, BORDER_REFLECT) and (.., INTER_NEAREST, BORDER_CONSTANT) (:1011-1014)
-        WarpCam w{};
-        w.src = small; w.src_stride = ssw * 3;
-        w.src_w = ssw; w.src_h = ssh;
-        w.out_w = ssw; w.out_h = ssh;
-        std::memcpy(w.m, pj.k_rinv, sizeof(w.m));
-        w.colA = dA; w.rowB = dB; w.tw = sroi[i].w; w.th = sroi[i].h;
-        w.dst = img; w.dst_pitch = sroi[i].w * 3;
-        launch_warp_image(w, s);
-        launch_warp_mask(w, mask, sroi[i].w, s);
-        gi.img[i] = img; gi.mask[i] = mask; gi.w[i] = sroi[i].w;
-    }
+    for (int i = 0; i < n; i++) { gi.img[i] = sm.img[i]; gi.mask[i] = sm.mask[i]; gi.w[i] = sroi[i].w; }
     // BlocksGainCompensator::feed: equalised blocks of every image, in image order then row-major
     struct Block { int cam, x, y, w, h; };
     std::vector<Block> blk;

@@ -2017,6 +2017,78 @@ void launch_resize_linear_exact(const uint8_t* src, int sw, int sh, int cn, uint
                            minx, maxx, miny, maxy);
 }
 
+// GraphCutSeamFinder::Impl::findInPair, the pixel work in front of the max-flow (seam_finders.cpp, COST_COLOR): the
+// overlap ROI of images a and b padded by gap = 10 on every side is a W x H grid graph.  Per vertex the terminal weight
+// (10000 towards the source where mask a is set, towards the sink where mask b is set), per horizontal / vertical
+// neighbour pair the capacity |a - b|^2(v) + |a - b|^2(v') + 1, plus 1000 where any of the four mask samples is clear.
+// Images are the 8UC3 seam-scale warps (the reference converts them to f32 first; the values are the same integers).
+struct GcSample {
+    float nd;  // squared colour distance of the two images at the vertex (0 outside either image)
+    bool ma, mb;
+};
+__device__ __forceinline__ GcSample gc_sample(const GainImages& g, const GcPair& q, int x, int y) {
+    GcSample r;
+    const int xa = q.ax + x, ya = q.ay + y, xb = q.bx + x, yb = q.by + y;
+    float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f};
+    r.ma = r.mb = false;
+    if (xa >= 0 && ya >= 0 && xa < q.wa && ya < q.ha) {
+        const uint8_t* p = g.img[q.a] + ((size_t)ya * q.wa + xa) * 3;
+        pa[0] = p[0]; pa[1] = p[1]; pa[2] = p[2];
+        r.ma = g.mask[q.a][(size_t)ya * q.wa + xa] != 0;
+    }
+    if (xb >= 0 && yb >= 0 && xb < q.wb && yb < q.hb) {
+        const uint8_t* p = g.img[q.b] + ((size_t)yb * q.wb + xb) * 3;
+        pb[0] = p[0]; pb[1] = p[1]; pb[2] = p[2];
+        r.mb = g.mask[q.b][(size_t)yb * q.wb + xb] != 0;
+    }
+    const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+    r.nd = dx * dx + dy * dy + dz * dz;
+    return r;
+}
+__global__ __launch_bounds__(256) void graphcut_weights_kernel(GainImages g, GcPair q, float* __restrict__ term,
+                                                               float* __restrict__ wh, float* __restrict__ wv) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= q.W || y >= q.H) return;
+    const GcSample c = gc_sample(g, q, x, y);
+    const int v = y * q.W + x;
+    term[v] = (c.ma ? 10000.f : 0.f) - (c.mb ? 10000.f : 0.f);
+    float h = 0.f, d = 0.f;
+    if (x < q.W - 1) {
+        const GcSample n = gc_sample(g, q, x + 1, y);
+        h = c.nd + n.nd + 1.f;
+        if (!c.ma || !n.ma || !c.mb || !n.mb) h += 1000.f;
+    }
+    if (y < q.H - 1) {
+        const GcSample n = gc_sample(g, q, x, y + 1);
+        d = c.nd + n.nd + 1.f;
+        if (!c.ma || !n.ma || !c.mb || !n.mb) d += 1000.f;
+    }
+    wh[v] = h;
+    wv[v] = d;
+}
+void launch_graphcut_weights(const GainImages& g, const GcPair& q, float* term, float* wh, float* wv, hipStream_t s) {
+    dim3 block(64, 4, 1), grid((q.W + 63) / 64, (q.H + 3) / 4, 1);
+    hipLaunchKernelGGL(graphcut_weights_kernel, grid, block, 0, s, g, q, term, wh, wv);
+}
+// ... and behind it: inside the ROI a vertex of the source segment keeps image a (mask b is cleared where mask a is
+// set), a vertex of the sink segment keeps image b
+__global__ __launch_bounds__(256) void graphcut_apply_kernel(GcPair q, uint8_t* mask_a, uint8_t* mask_b,
+                                                             const uint8_t* __restrict__ in_source, int gap) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= q.W - 2 * gap || y >= q.H - 2 * gap) return;
+    // ROI pixel (x, y) is padded-grid vertex (x + gap, y + gap) and image pixel (ax + gap + x, ay + gap + y)
+    const size_t ka = (size_t)(q.ay + gap + y) * q.wa + (q.ax + gap + x), kb = (size_t)(q.by + gap + y) * q.wb + (q.bx + gap + x);
+    if (in_source[(y + gap) * q.W + x + gap]) {
+        if (mask_a[ka]) mask_b[kb] = 0;
+    } else {
+        if (mask_b[kb]) mask_a[ka] = 0;
+    }
+}
+void launch_graphcut_apply(const GcPair& q, uint8_t* mask_a, uint8_t* mask_b, const uint8_t* in_source, int gap, hipStream_t s) {
+    dim3 block(64, 4, 1), grid((q.W - 2 * gap + 63) / 64, (q.H - 2 * gap + 3) / 4, 1);
+    hipLaunchKernelGGL(graphcut_apply_kernel, grid, block, 0, s, q, mask_a, mask_b, in_source, gap);
+}
+
 // detail::GainCompensator::feed, the pixel loop of one overlapping pair of sub-images (exposure_compensate.cpp):
 // count of pixels both masks mark and the two sums of sqrt(b^2 + g^2 + r^2) over them.  The sums are f64 and
 // f64 addition does not reassociate, so one lane walks one pair in the reference's row-major order; the pairs (a few

@@ -160,6 +160,13 @@ struct GainImages {
 struct GainPair {
     int a, ax, ay, b, bx, by, w, h;
 };
+// graph-cut seam finder (GraphCutSeamFinder::Impl::findInPair): the padded overlap ROI of images a and b as a W x H
+// grid; (ax, ay) / (bx, by) = image coordinates of grid vertex (0, 0) (may be negative: the gap reaches outside)
+struct GcPair {
+    int a, ax, ay, wa, ha, b, bx, by, wb, hb, W, H;
+};
+void launch_graphcut_weights(const GainImages& g, const GcPair& q, float* term, float* wh, float* wv, hipStream_t s);
+void launch_graphcut_apply(const GcPair& q, uint8_t* mask_a, uint8_t* mask_b, const uint8_t* in_source, int gap, hipStream_t s);
 void launch_gain_pairs(const GainImages& g, const GainPair* pairs, int npairs, int* count, double* sum_a, double* sum_b,
                        hipStream_t s);
 void launch_and(const uint8_t* a, const uint8_t* b, uint8_t* dst, size_t n, hipStream_t s);

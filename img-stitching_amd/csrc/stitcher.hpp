@@ -162,6 +162,10 @@ class Stitcher {
     int projector = PANO_SPHERICAL;   // reference: SphericalWarperGpu (ocvstitcher.hpp:1000)
     int device = 0;
     int maskRefreshPeriod = 200;      // process() refreshes the masks every 200 calls (ocvstitcher.hpp:1152)
+    // seam finder of initSeam / updateMask: the reference creates GraphCutSeamFinder(COST_COLOR) (ocvstitcher.hpp:1033,
+    // :860) and has NoSeamFinder commented beside it; the one-shot twin also offers Voronoi (stitching_detailed.cpp:728)
+    enum SeamFinder { SeamGraphCut = 0, SeamVoronoi = 1 };
+    int seamFinder = SeamGraphCut;
     // initSeam feeds a GAIN_BLOCKS compensator (ocvstitcher.hpp:1031-1032) but process() keeps apply() commented out
     // (:1178); the one-shot twin applies it (src/stitching_detailed.cpp:841).  true = estimate in calibration(), apply
     // in every process()
@@ -210,7 +214,7 @@ class Stitcher {
     // record of <cfgPath>cameraparaout_<id>.txt (mode 3, falling back to the defaults like the reference falls
     // back after failures); then the mask half of initSeam (:975-1101) runs on the GPU.
     int calibration(const std::vector<Mat>& imgs) {
-        // Voronoi seams depend on geometry only; the frames feed the exposure compensator when it is on
+        // the frames feed the graph-cut seam finder and, when it is on, the exposure compensator
         pano_destroy(ctx_);
         ctx_ = nullptr;
         pano_config c{};
@@ -227,17 +231,14 @@ class Stitcher {
         }
         if (!loaded && pano_set_cameras_from_list(ctx_, defaultCamParams_.c_str()) != PANO_OK) return RET_ERR;
         if (pano_prepare(ctx_) != PANO_OK) return RET_ERR;
-        if (device >= 0 && pano_build_masks_voronoi(ctx_) != PANO_OK) return RET_ERR;
-        if (device >= 0 && exposureCompensation) {
-            if ((int)imgs.size() < cfg_.num_images) return RET_ERR;
-            const uint8_t* frames[PANO_MAX_CAMS];
-            size_t strides[PANO_MAX_CAMS];
-            for (int i = 0; i < cfg_.num_images; i++) {
-                if (imgs[i].cols != cfg_.width || imgs[i].rows != cfg_.height) return RET_ERR;
-                frames[i] = imgs[i].data;
-                strides[i] = imgs[i].step;
+        if (device >= 0) {
+            if (buildMasks(imgs) != RET_OK) return RET_ERR;
+            if (exposureCompensation) {
+                const uint8_t* frames[PANO_MAX_CAMS];
+                size_t strides[PANO_MAX_CAMS];
+                if (!borrow(imgs, frames, strides)) return RET_ERR;
+                if (pano_estimate_gains(ctx_, frames, strides, 32, 32) != PANO_OK) return RET_ERR;
             }
-            if (pano_estimate_gains(ctx_, frames, strides, 32, 32) != PANO_OK) return RET_ERR;
         }
         frame_ = 0;
         return RET_OK;
@@ -247,7 +248,7 @@ class Stitcher {
     void process(std::vector<Mat>& imgs, Mat& ret) {
         if (!ctx_ || (int)imgs.size() < cfg_.num_images) return;
         if (maskRefreshPeriod > 0 && ++frame_ > maskRefreshPeriod) {  // updateMask cadence (:1152-1159)
-            pano_build_masks_voronoi(ctx_);
+            buildMasks(imgs);
             frame_ = 0;
         }
         int w = 0, h = 0;
@@ -267,6 +268,24 @@ class Stitcher {
     const char* lastError() const { return pano_last_error(ctx_); }
 
   private:
+    // the frames as the C-ABI takes them; false when there are too few or they are not stitcher sized
+    bool borrow(const std::vector<Mat>& imgs, const uint8_t** frames, size_t* strides) const {
+        if ((int)imgs.size() < cfg_.num_images) return false;
+        for (int i = 0; i < cfg_.num_images; i++) {
+            if (!imgs[i].data || imgs[i].cols != cfg_.width || imgs[i].rows != cfg_.height) return false;
+            frames[i] = imgs[i].data;
+            strides[i] = imgs[i].step;
+        }
+        return true;
+    }
+    // the mask half of initSeam / updateMask (ocvstitcher.hpp:975-1101, :1218-1261)
+    int buildMasks(const std::vector<Mat>& imgs) {
+        const uint8_t* frames[PANO_MAX_CAMS];
+        size_t strides[PANO_MAX_CAMS];
+        if (seamFinder == SeamGraphCut && borrow(imgs, frames, strides))
+            return pano_build_masks_graphcut(ctx_, frames, strides) == PANO_OK ? RET_OK : RET_ERR;
+        return pano_build_masks_voronoi(ctx_) == PANO_OK ? RET_OK : RET_ERR;  // geometry only: needs no frames
+    }
     pano_ctx* ctx_ = nullptr;
     StitcherCfg cfg_;
     std::string defaultCamParams_;

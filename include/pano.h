@@ -109,6 +109,14 @@ pano_status pano_set_mask(pano_ctx* ctx, int i, const uint8_t* h_mask, int w, in
  * Voronoi seam option (src/stitching_detailed.cpp:728-729) instead of graph cut: seam-scale NEAREST
  * mask warp, VoronoiSeamFinder, dilate 3x3, resize INTER_LINEAR_EXACT, AND - all on the GPU */
 pano_status pano_build_masks_voronoi(pano_ctx* ctx);
+/* ocvStitcher::updateMask (ocvstitcher.hpp:1218-1261; the same steps inside initSeam, :981-1101) with the reference's
+ * own seam finder, detail::GraphCutSeamFinder(COST_COLOR) (:1033-1035, :1244): the n stitcher-size BGR8 frames (host
+ * pointers) are resized by seam_work_aspect (INTER_LINEAR_EXACT) and warped at the seam scale beside the NEAREST masks on
+ * the GPU; per overlapping pair, in PairwiseSeamFinder::run order, the GPU builds the grid graph of findInPair (terminal
+ * weights 10000, edge weights |a-b|^2 + |a'-b'|^2 + 1, +1000 at mask borders, gap 10), the host runs OpenCV's
+ * Boykov-Kolmogorov max-flow (sequential by construction; csrc/pano_graphcut.hpp), the GPU applies the labels; then dilate
+ * 3x3, resize INTER_LINEAR_EXACT, AND as in pano_build_masks_voronoi. */
+pano_status pano_build_masks_graphcut(pano_ctx* ctx, const uint8_t* const* h_frames, const size_t* strides);
 pano_status pano_get_mask(pano_ctx* ctx, int i, uint8_t* h_mask, size_t stride);
 
 /* ---- fused undistort front end (reference include/nvcam.hpp:823-833, :898-921, :1094) ----------------------

@@ -829,6 +829,286 @@ void po_voronoi_find(int n, const int* corners, const int* sizes, uint8_t** mask
         }
 }
 
+/* ---- GraphCutSeamFinder(COST_COLOR), the reference's seam finder (ocvstitcher.hpp:1033-1035, :1244) */
+
+/* GCGraph<float> (imgproc/src/gcgraph.hpp): Boykov-Kolmogorov max-flow with OpenCV's bookkeeping (active list threaded
+ * through `next`, time stamps + distances for the orphan adoption).  RECALLED from the OpenCV sources; the labelling of
+ * vertices that end in neither tree depends on these details */
+typedef struct { int next; int parent; int first; int ts; int dist; float weight; uint8_t t; } gc_vtx;   /* next: index + 1, 0 = none, -1 = nil */
+typedef struct { int dst; int next; float weight; } gc_edge;
+typedef struct { gc_vtx* v; int nv; gc_edge* e; int ne; float flow; } gc_graph;
+
+static void gc_init(gc_graph* g, int nv, int ne) {
+    g->v = (gc_vtx*)calloc((size_t)nv, sizeof(gc_vtx));
+    g->nv = nv;
+    g->e = (gc_edge*)calloc((size_t)2 * ne + 2, sizeof(gc_edge));
+    g->ne = 2;   /* edges 0 and 1 are unused so that "first == 0" means no edge and e ^ 1 is the reverse edge */
+    g->flow = 0;
+}
+static void gc_free(gc_graph* g) { free(g->v); free(g->e); }
+static void gc_add_edges(gc_graph* g, int i, int j, float w, float revw) {
+    gc_edge* a = &g->e[g->ne];
+    a->dst = j; a->next = g->v[i].first; a->weight = w; g->v[i].first = g->ne++;
+    gc_edge* b = &g->e[g->ne];
+    b->dst = i; b->next = g->v[j].first; b->weight = revw; g->v[j].first = g->ne++;
+}
+static void gc_add_term_weights(gc_graph* g, int i, float source_w, float sink_w) {
+    float dw = g->v[i].weight;
+    if (dw > 0) source_w += dw; else sink_w -= dw;
+    g->flow += source_w < sink_w ? source_w : sink_w;
+    g->v[i].weight = source_w - sink_w;
+}
+#define GC_NIL (-1)
+static void gc_max_flow(gc_graph* g) {
+    const int TERMINAL = -1, ORPHAN = -2;
+    gc_vtx* V = g->v;
+    gc_edge* E = g->e;
+    /* the active list: first/last are vertex indices, GC_NIL terminates it; V[i].next: 0 = not in the list,
+     * otherwise index + 1 of the successor or GC_NIL for the tail */
+    int first = GC_NIL, last = GC_NIL;
+    int curr_ts = 0;
+    int* orphans = (int*)malloc(sizeof(int) * (size_t)(g->nv > 16 ? g->nv : 16));
+    size_t n_orph = 0, cap_orph = (size_t)(g->nv > 16 ? g->nv : 16);
+#define PUSH_ORPHAN(ix) do { if (n_orph == cap_orph) { cap_orph *= 2; orphans = (int*)realloc(orphans, sizeof(int) * cap_orph); } orphans[n_orph++] = (ix); } while (0)
+#define APPEND_ACTIVE(ix) do { V[ix].next = GC_NIL; if (last == GC_NIL) first = (ix); else V[last].next = (ix) + 1; last = (ix); } while (0)
+    for (int i = 0; i < g->nv; i++) {
+        gc_vtx* v = &V[i];
+        v->ts = 0;
+        if (v->weight != 0) {
+            APPEND_ACTIVE(i);
+            v->dist = 1;
+            v->parent = TERMINAL;
+            v->t = v->weight < 0;
+        } else
+            v->parent = 0;
+    }
+    for (;;) {
+        int e0 = -1, ei = 0, ej = 0;
+        float min_weight, weight;
+        uint8_t vt;
+        /* grow the S and T trees, find an edge that connects them */
+        while (first != GC_NIL) {
+            const int vi = first;
+            gc_vtx* v = &V[vi];
+            if (v->parent) {
+                vt = v->t;
+                for (ei = v->first; ei != 0; ei = E[ei].next) {
+                    if (E[ei ^ vt].weight == 0) continue;
+                    const int ui = E[ei].dst;
+                    gc_vtx* u = &V[ui];
+                    if (!u->parent) {
+                        u->t = vt;
+                        u->parent = ei ^ 1;
+                        u->ts = v->ts;
+                        u->dist = v->dist + 1;
+                        if (!u->next) APPEND_ACTIVE(ui);
+                        continue;
+                    }
+                    if (u->t != vt) { e0 = ei ^ vt; break; }
+                    if (u->dist > v->dist + 1 && u->ts <= v->ts) {
+                        u->parent = ei ^ 1;
+                        u->ts = v->ts;
+                        u->dist = v->dist + 1;
+                    }
+                }
+                if (e0 > 0) break;
+            }
+            /* exclude the vertex from the active list */
+            const int nx = v->next;
+            first = nx == GC_NIL ? GC_NIL : nx - 1;
+            if (first == GC_NIL) last = GC_NIL;
+            v->next = 0;
+        }
+        if (e0 <= 0) break;
+        /* bottleneck of the path: k = 1 source tree, k = 0 sink tree */
+        min_weight = E[e0].weight;
+        for (int k = 1; k >= 0; k--) {
+            int vi;
+            for (vi = E[e0 ^ k].dst;; vi = E[ei].dst) {
+                if ((ei = V[vi].parent) < 0) break;
+                weight = E[ei ^ k].weight;
+                min_weight = min_weight < weight ? min_weight : weight;
+            }
+            weight = fabsf(V[vi].weight);
+            min_weight = min_weight < weight ? min_weight : weight;
+        }
+        /* push it, collect orphans */
+        E[e0].weight -= min_weight;
+        E[e0 ^ 1].weight += min_weight;
+        g->flow += min_weight;
+        for (int k = 1; k >= 0; k--) {
+            int vi;
+            for (vi = E[e0 ^ k].dst;; vi = E[ei].dst) {
+                if ((ei = V[vi].parent) < 0) break;
+                E[ei ^ (k ^ 1)].weight += min_weight;
+                if ((E[ei ^ k].weight -= min_weight) == 0) {
+                    PUSH_ORPHAN(vi);
+                    V[vi].parent = ORPHAN;
+                }
+            }
+            V[vi].weight = V[vi].weight + min_weight * (float)(1 - k * 2);
+            if (V[vi].weight == 0) {
+                PUSH_ORPHAN(vi);
+                V[vi].parent = ORPHAN;
+            }
+        }
+        /* adopt the orphans */
+        curr_ts++;
+        while (n_orph) {
+            const int v2i = orphans[--n_orph];
+            gc_vtx* v2 = &V[v2i];
+            int d, min_dist = INT_MAX;
+            e0 = 0;
+            vt = v2->t;
+            for (ei = v2->first; ei != 0; ei = E[ei].next) {
+                if (E[ei ^ (vt ^ 1)].weight == 0) continue;
+                gc_vtx* u = &V[E[ei].dst];
+                if (u->t != vt || u->parent == 0) continue;
+                for (d = 0;;) {   /* distance to the tree root */
+                    if (u->ts == curr_ts) { d += u->dist; break; }
+                    ej = u->parent;
+                    d++;
+                    if (ej < 0) {
+                        if (ej == ORPHAN) d = INT_MAX - 1;
+                        else { u->ts = curr_ts; u->dist = 1; }
+                        break;
+                    }
+                    u = &V[E[ej].dst];
+                }
+                if (++d < INT_MAX) {
+                    if (d < min_dist) { min_dist = d; e0 = ei; }
+                    for (u = &V[E[ei].dst]; u->ts != curr_ts; u = &V[E[u->parent].dst]) {
+                        u->ts = curr_ts;
+                        u->dist = --d;
+                    }
+                }
+            }
+            if ((v2->parent = e0) > 0) {
+                v2->ts = curr_ts;
+                v2->dist = min_dist;
+                continue;
+            }
+            /* no parent: the vertex becomes free, its children orphans, its neighbours active */
+            v2->ts = 0;
+            for (ei = v2->first; ei != 0; ei = E[ei].next) {
+                const int ui = E[ei].dst;
+                gc_vtx* u = &V[ui];
+                ej = u->parent;
+                if (u->t != vt || !ej) continue;
+                if (E[ei ^ (vt ^ 1)].weight != 0 && !u->next) APPEND_ACTIVE(ui);
+                if (ej > 0 && E[ej].dst == v2i) {
+                    PUSH_ORPHAN(ui);
+                    u->parent = ORPHAN;
+                }
+            }
+        }
+    }
+    free(orphans);
+#undef PUSH_ORPHAN
+#undef APPEND_ACTIVE
+}
+
+/* GraphCutSeamFinder::Impl::findInPair + setGraphWeightsColor (stitching/src/seam_finders.cpp): images CV_32FC3,
+ * terminal_cost 10000, bad_region_penalty 1000, gap 10; normL2 there is the SQUARED distance */
+static float gc_norm2(const float* a, const float* b) {
+    float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return dx * dx + dy * dy + dz * dz;
+}
+static void graphcut_in_pair(const float* img1, const float* img2, const int* tl1, const int* tl2, const int* sz1,
+                             const int* sz2, uint8_t* mask1, uint8_t* mask2, const int roi[4]) {
+    const int gap = 10;
+    const float terminal_cost = 10000.f, bad_region_penalty = 1000.f;
+    const int W = roi[2] + 2 * gap, H = roi[3] + 2 * gap;
+    float* s1 = (float*)calloc((size_t)W * H * 3, sizeof(float));
+    float* s2 = (float*)calloc((size_t)W * H * 3, sizeof(float));
+    uint8_t* m1 = (uint8_t*)calloc((size_t)W * H, 1);
+    uint8_t* m2 = (uint8_t*)calloc((size_t)W * H, 1);
+    for (int y = -gap; y < roi[3] + gap; ++y)
+        for (int x = -gap; x < roi[2] + gap; ++x) {
+            const size_t k = (size_t)(y + gap) * W + x + gap;
+            int y1 = roi[1] - tl1[1] + y, x1 = roi[0] - tl1[0] + x;
+            if (y1 >= 0 && x1 >= 0 && y1 < sz1[1] && x1 < sz1[0]) {
+                memcpy(s1 + 3 * k, img1 + ((size_t)y1 * sz1[0] + x1) * 3, 3 * sizeof(float));
+                m1[k] = mask1[(size_t)y1 * sz1[0] + x1];
+            }
+            int y2 = roi[1] - tl2[1] + y, x2 = roi[0] - tl2[0] + x;
+            if (y2 >= 0 && x2 >= 0 && y2 < sz2[1] && x2 < sz2[0]) {
+                memcpy(s2 + 3 * k, img2 + ((size_t)y2 * sz2[0] + x2) * 3, 3 * sizeof(float));
+                m2[k] = mask2[(size_t)y2 * sz2[0] + x2];
+            }
+        }
+    gc_graph g;
+    gc_init(&g, W * H, (H - 1) * W + (W - 1) * H);
+    for (int k = 0; k < W * H; k++) gc_add_term_weights(&g, k, m1[k] ? terminal_cost : 0.f, m2[k] ? terminal_cost : 0.f);
+    const float weight_eps = 1.f;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int v = y * W + x;
+            if (x < W - 1) {
+                float weight = gc_norm2(s1 + 3 * v, s2 + 3 * v) + gc_norm2(s1 + 3 * (v + 1), s2 + 3 * (v + 1)) + weight_eps;
+                if (!m1[v] || !m1[v + 1] || !m2[v] || !m2[v + 1]) weight += bad_region_penalty;
+                gc_add_edges(&g, v, v + 1, weight, weight);
+            }
+            if (y < H - 1) {
+                float weight = gc_norm2(s1 + 3 * v, s2 + 3 * v) + gc_norm2(s1 + 3 * (v + W), s2 + 3 * (v + W)) + weight_eps;
+                if (!m1[v] || !m1[v + W] || !m2[v] || !m2[v + W]) weight += bad_region_penalty;
+                gc_add_edges(&g, v, v + W, weight, weight);
+            }
+        }
+    gc_max_flow(&g);
+    for (int y = 0; y < roi[3]; ++y)
+        for (int x = 0; x < roi[2]; ++x) {
+            const size_t k1 = (size_t)(roi[1] - tl1[1] + y) * sz1[0] + (roi[0] - tl1[0] + x);
+            const size_t k2 = (size_t)(roi[1] - tl2[1] + y) * sz2[0] + (roi[0] - tl2[0] + x);
+            if (g.v[(y + gap) * W + x + gap].t == 0) {   /* inSourceSegment */
+                if (mask1[k1]) mask2[k2] = 0;
+            } else {
+                if (mask2[k2]) mask1[k1] = 0;
+            }
+        }
+    gc_free(&g);
+    free(s1); free(s2); free(m1); free(m2);
+}
+
+/* test hook: the max-flow on a W x H 4-connected grid given as arrays: term[k] = source - sink weight of vertex k
+ * (added as addTermWeights(k, max(t,0), max(-t,0))), wh[k] = weight of edge (k, k+1), wv[k] = weight of (k, k+W), both
+ * directions equal; labels[k] = inSourceSegment.  Returns the flow */
+float po_gc_grid_max_flow(int W, int H, const float* term, const float* wh, const float* wv, uint8_t* labels) {
+    gc_graph g;
+    gc_init(&g, W * H, (H - 1) * W + (W - 1) * H);
+    for (int k = 0; k < W * H; k++) gc_add_term_weights(&g, k, term[k] > 0 ? term[k] : 0.f, term[k] < 0 ? -term[k] : 0.f);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int v = y * W + x;
+            if (x < W - 1) gc_add_edges(&g, v, v + 1, wh[v], wh[v]);
+            if (y < H - 1) gc_add_edges(&g, v, v + W, wv[v], wv[v]);
+        }
+    gc_max_flow(&g);
+    for (int k = 0; k < W * H; k++) labels[k] = g.v[k].t == 0;
+    float f = g.flow;
+    gc_free(&g);
+    return f;
+}
+
+/* PairwiseSeamFinder::run + GraphCutSeamFinder(COST_COLOR)::find: images are the 8UC3 warps (converted to f32 here,
+ * images_warped[i].convertTo(images_warped_f[i], CV_32F), ocvstitcher.hpp:1028-1029) */
+void po_graphcut_find(int n, const int* corners, const int* sizes, const uint8_t* const* images, uint8_t** masks) {
+    float** f = (float**)calloc((size_t)n + 1, sizeof(float*));
+    for (int i = 0; i < n; i++) {
+        const size_t px = (size_t)sizes[2 * i] * sizes[2 * i + 1] * 3;
+        f[i] = (float*)malloc(sizeof(float) * px);
+        for (size_t k = 0; k < px; k++) f[i][k] = (float)images[i][k];
+    }
+    for (int i = 0; i < n - 1; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            int roi[4];
+            if (overlap_roi(corners + 2 * i, corners + 2 * j, sizes + 2 * i, sizes + 2 * j, roi))
+                graphcut_in_pair(f[i], f[j], corners + 2 * i, corners + 2 * j, sizes + 2 * i, sizes + 2 * j, masks[i], masks[j], roi);
+        }
+    for (int i = 0; i < n; i++) free(f[i]);
+    free(f);
+}
+
 /* ======================================================================== A8 */
 
 /* cv::resize CV_32FC1 INTER_LINEAR (resize.cpp resizeGeneric_ with HResizeLinear<float,float,float,1> and
@@ -1175,6 +1455,59 @@ int po_estimate_gains(int n, int kind, int sw, int sh, const uint8_t* const* fra
     for (int i = 0; i < n; i++) { free(iw[i]); free(mw[i]); }
     free(iw); free(mw); free(ones); free(small); free(corners);
     return ok;
+}
+
+/* ocvStitcher::updateMask (ocvstitcher.hpp:1218-1261; the same steps inside initSeam, :981-1101) as the reference
+ * runs it: frames resized by seam_work_aspect (INTER_LINEAR_EXACT), seam-scale LINEAR/REFLECT and NEAREST warps,
+ * GraphCutSeamFinder(COST_COLOR) on the f32 images, then dilate 3x3, resize INTER_LINEAR_EXACT to the ROI, AND with
+ * the full-scale NEAREST mask */
+void po_prepare_masks_graphcut(int n, int kind, int sw, int sh, const uint8_t* const* frames, const float* Ks,
+                               const float* Rs, float wscale, uint8_t** masks_out) {
+    double swa = sqrt(1e5 / ((double)sh * sw));
+    if (swa > 1.0) swa = 1.0;
+    int ssw = cv_round_d(sw * swa), ssh = cv_round_d(sh * swa);
+    float seam_scale = (float)(wscale * swa);
+    float swa_f = (float)swa;
+    int* corners = (int*)calloc((size_t)2 * n + 1, sizeof(int));
+    int* sizes = (int*)calloc((size_t)2 * n + 1, sizeof(int));
+    uint8_t** iw = (uint8_t**)calloc((size_t)n + 1, sizeof(uint8_t*));
+    uint8_t** mw = (uint8_t**)calloc((size_t)n + 1, sizeof(uint8_t*));
+    uint8_t* ones = (uint8_t*)malloc((size_t)sw * sh);
+    uint8_t* small = (uint8_t*)malloc((size_t)ssw * ssh * 3);
+    memset(ones, 255, (size_t)sw * sh);
+    for (int i = 0; i < n; i++) {
+        float K[9];
+        memcpy(K, Ks + 9 * i, sizeof(K));
+        K[0] *= swa_f; K[2] *= swa_f; K[4] *= swa_f; K[5] *= swa_f;
+        po_projector p;
+        po_projector_set(&p, kind, seam_scale, K, Rs + 9 * i);
+        int r[4], c[2];
+        po_warp_roi(&p, ssw, ssh, r);
+        corners[2 * i] = r[0]; corners[2 * i + 1] = r[1];
+        sizes[2 * i] = r[2]; sizes[2 * i + 1] = r[3];
+        if (ssw == sw && ssh == sh) memcpy(small, frames[i], (size_t)sw * sh * 3);
+        else po_resize_linear_exact_8u(frames[i], sw, sh, 3, small, ssw, ssh);
+        iw[i] = (uint8_t*)malloc((size_t)r[2] * r[3] * 3);
+        mw[i] = (uint8_t*)malloc((size_t)r[2] * r[3]);
+        po_warp_8u(&p, small, ssw, ssh, (size_t)ssw * 3, 3, PO_INTER_LINEAR, PO_BORDER_REFLECT, iw[i], c);
+        po_warp_8u(&p, ones, ssw, ssh, (size_t)ssw, 1, PO_INTER_NEAREST, PO_BORDER_CONSTANT, mw[i], c);
+    }
+    po_graphcut_find(n, corners, sizes, (const uint8_t* const*)iw, mw);
+    for (int i = 0; i < n; i++) {
+        po_projector p;
+        po_projector_set(&p, kind, wscale, Ks + 9 * i, Rs + 9 * i);
+        int r[4], c[2];
+        po_warp_roi(&p, sw, sh, r);
+        uint8_t* full = (uint8_t*)malloc((size_t)r[2] * r[3]);
+        po_warp_8u(&p, ones, sw, sh, (size_t)sw, 1, PO_INTER_NEAREST, PO_BORDER_CONSTANT, full, c);
+        uint8_t* dil = (uint8_t*)malloc((size_t)sizes[2 * i] * sizes[2 * i + 1]);
+        po_dilate3x3_8u(mw[i], sizes[2 * i], sizes[2 * i + 1], dil);
+        uint8_t* seam = (uint8_t*)malloc((size_t)r[2] * r[3]);
+        po_resize_linear_exact_8u(dil, sizes[2 * i], sizes[2 * i + 1], 1, seam, r[2], r[3]);
+        for (size_t k = 0; k < (size_t)r[2] * r[3]; k++) masks_out[i][k] = seam[k] & full[k];
+        free(full); free(dil); free(seam); free(mw[i]); free(iw[i]);
+    }
+    free(ones); free(small); free(mw); free(iw); free(corners); free(sizes);
 }
 
 /* ======================================================================== fused undistort front end */

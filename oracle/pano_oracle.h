@@ -95,6 +95,14 @@ void po_blender_last_tile(const po_blender* b, int rect_xywh[4], int tblr[4]);
 
 /* ---- A7: VoronoiSeamFinder::find (seam_finders.cpp) on u8 masks, in place */
 void po_voronoi_find(int n, const int* corners_xy, const int* sizes_wh, uint8_t** masks);
+/* detail::GraphCutSeamFinder(COST_COLOR)::find - the reference's seam finder (ocvstitcher.hpp:1033-1035, :1244):
+ * PairwiseSeamFinder::run order, findInPair with GCGraph<float> (Boykov-Kolmogorov as OpenCV implements it).
+ * images: the 8UC3 warps (dense); masks are updated in place */
+void po_graphcut_find(int n, const int* corners_xy, const int* sizes_wh, const uint8_t* const* images, uint8_t** masks);
+/* ocvStitcher::updateMask with the reference's own seam finder: frames -> m_blenderMask (each warp_roi(i) sized) */
+void po_prepare_masks_graphcut(int n, int kind, int src_w, int src_h, const uint8_t* const* frames, const float* K9s,
+                               const float* R9s, float scale, uint8_t** masks_out);
+float po_gc_grid_max_flow(int W, int H, const float* term, const float* wh, const float* wv, uint8_t* labels);
 
 /* ---- A8: BlocksGainCompensator::apply (exposure_compensate.cpp, 3.4) */
 void po_resize_linear_32f(const float* src, int sw, int sh, float* dst, int dw, int dh);

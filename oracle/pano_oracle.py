@@ -250,6 +250,46 @@ def prepare_masks_voronoi(kind, w, h, Ks, Rs, scale):
     return masks
 
 
+def graphcut_find(corners, images, masks):
+    """detail::GraphCutSeamFinder(COST_COLOR)::find on 8UC3 images: returns the updated masks"""
+    n = len(masks)
+    c = np.ascontiguousarray(np.asarray(corners, dtype=np.int32).reshape(-1))
+    ims = [np.ascontiguousarray(m, dtype=np.uint8) for m in images]
+    ms = [np.ascontiguousarray(m, dtype=np.uint8).copy() for m in masks]
+    s = np.ascontiguousarray(np.asarray([[m.shape[1], m.shape[0]] for m in ms], dtype=np.int32).reshape(-1))
+    ia = (C.c_void_p * n)(*[m.ctypes.data for m in ims])
+    ma = (C.c_void_p * n)(*[m.ctypes.data for m in ms])
+    lib().po_graphcut_find(n, _p(c), _p(s), ia, ma)
+    return ms
+
+
+def gc_grid_max_flow(term, wh, wv):
+    """test hook: GCGraph<float>::maxFlow on a 4-connected grid; (flow, inSourceSegment labels)"""
+    term = np.ascontiguousarray(term, np.float32); wh = np.ascontiguousarray(wh, np.float32); wv = np.ascontiguousarray(wv, np.float32)
+    h, w = term.shape
+    lab = np.zeros((h, w), np.uint8)
+    f = lib().po_gc_grid_max_flow
+    f.restype = C.c_float
+    return float(f(w, h, _p(term), _p(wh), _p(wv), _p(lab))), lab
+
+
+def prepare_masks_graphcut(frames, Ks, Rs, scale, kind=SPHERICAL):
+    """ocvStitcher::updateMask with GraphCutSeamFinder(COST_COLOR): frames -> blend masks"""
+    Ks = np.ascontiguousarray(np.asarray(Ks, dtype=np.float32).reshape(-1, 9))
+    Rs = np.ascontiguousarray(np.asarray(Rs, dtype=np.float32).reshape(-1, 9))
+    n = Ks.shape[0]
+    fr = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+    h, w = fr[0].shape[:2]
+    masks = []
+    for i in range(n):
+        r = warp_roi(projector(kind, scale, Ks[i], Rs[i]), w, h)
+        masks.append(np.zeros((r[3], r[2]), np.uint8))
+    fa = (C.c_void_p * n)(*[f.ctypes.data for f in fr])
+    arr = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
+    lib().po_prepare_masks_graphcut(n, int(kind), int(w), int(h), fa, _p(Ks), _p(Rs), C.c_float(scale), arr)
+    return masks
+
+
 def gain_feed(corners, images, masks):
     """detail::GainCompensator::feed: one gain (float64) per image"""
     n = len(images)

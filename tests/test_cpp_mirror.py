@@ -60,3 +60,6 @@ def test_replay_frames_on_gpu(replay_bin, rig_r, tmp_path):
     r = subprocess.run([replay_bin, str(cfg), "--exposure", "--frames", "1"], capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 0, r.stderr + r.stdout
     assert "stitcher 0: exposure gain maps 11x7 blocks" in r.stdout and "wrote final.ppm 1430x500" in r.stdout
+    # the geometry-only Voronoi seam finder instead of the reference's graph cut
+    r = subprocess.run([replay_bin, str(cfg), "--voronoi", "--frames", "1"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and "wrote final.ppm 1430x500" in r.stdout, r.stderr + r.stdout

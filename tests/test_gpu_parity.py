@@ -833,3 +833,43 @@ def test_single_ring_of_eight_cameras(pano, po, monkeypatch, w, h, f, bands, fir
                 x, y, lw, lh = ctx.live_rect(i, 0)
                 assert x <= gaps[i][0] and gaps[i][0] + gaps[i][1] <= x + lw
     assert two_ended or first != 180.0
+
+
+@pytest.mark.parametrize("case", ["c1", "c1_cylindrical", "rig_r", "c2_1080p", "ties"])
+def test_graphcut_masks_bit_exact(pano, po, c1, rig_r, case):
+    """the reference's own seam finder: ocvStitcher::updateMask with GraphCutSeamFinder(COST_COLOR)
+    (ocvstitcher.hpp:1218-1261, :1033-1035) - seam-scale warps, graph weights and mask update on the GPU, OpenCV's
+    Boykov-Kolmogorov max-flow on the host: blend masks bit-equal to the oracle's, and the panorama composed under them"""
+    kind, bands = 0, 3
+    if case == "c1":
+        d, frames = c1, c1["frames"]
+    elif case == "c1_cylindrical":
+        d, frames, kind = c1, c1["frames"], 1
+    elif case == "rig_r":
+        v = rig_r["stitchers"][0]["cams"]
+        d = {"n": 2, "w": 960, "h": 540, "scale": v[-1], "K": [v[0:9], v[18:27]], "R": [v[9:18], v[27:36]]}
+        frames = [synth_frame(960, 540, 70 + i) for i in range(2)]
+    elif case == "c2_1080p":
+        d = c2_group()
+        frames = [synth_frame(1920, 1080, 80 + i) for i in range(4)]
+    else:   # flat frames: every edge costs the same and the labels of the vertices no tree holds decide
+        d = c2_group(w=640, h=360, f=334.0)
+        frames = [np.full((360, 640, 3), 90 + 20 * i, np.uint8) for i in range(4)]
+    ctx = make_ctx(pano, d, kind, num_bands=bands)
+    ctx.build_masks_graphcut(frames)
+    want = po.prepare_masks_graphcut(frames, d["K"], d["R"], d["scale"], kind)
+    for i in range(d["n"]):
+        got = ctx.get_mask(i)
+        assert got.shape == want[i].shape and np.array_equal(got, want[i]), (case, i, int((got != want[i]).sum()))
+    ref, _ = po.compose(frames, d["K"], d["R"], d["scale"], want, bands, kind=kind)
+    assert np.array_equal(ctx.compose_host(frames), ref)
+    # the seams depend on the frames: other content, other masks; and the Voronoi masks come back on request
+    if case == "c1":
+        other = [np.ascontiguousarray(f[::-1]) for f in frames]
+        ctx.build_masks_graphcut(other)
+        w2 = po.prepare_masks_graphcut(other, d["K"], d["R"], d["scale"], kind)
+        assert all(np.array_equal(ctx.get_mask(i), w2[i]) for i in range(4))
+        assert any(not np.array_equal(w2[i], want[i]) for i in range(4))
+        ctx.build_masks_voronoi()
+        vor = oracle_masks(po, d, kind)
+        assert all(np.array_equal(ctx.get_mask(i), vor[i]) for i in range(4))

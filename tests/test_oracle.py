@@ -340,3 +340,70 @@ def test_estimate_gains_c1(po, c1):
     m2, _ = po.estimate_gains(dark, c1["K"], c1["R"], c1["scale"])
     assert m2[1][:, 0].mean() > maps[1][:, 0].mean() + 0.1 and m2[1][:, -1].mean() > maps[1][:, -1].mean() + 0.1
     assert m2[0][:, 0].mean() < maps[0][:, 0].mean() and m2[2][:, -1].mean() < maps[2][:, -1].mean()
+
+
+def test_graphcut_max_flow_vs_scipy(po):
+    """GCGraph<float>::maxFlow as restated (Boykov-Kolmogorov with OpenCV's bookkeeping) against scipy's max-flow on
+    random integer grids: same flow value, every vertex reachable from the source in the residual graph labelled source,
+    every vertex that still reaches the sink labelled sink (the rest - ties between minimum cuts - is OpenCV's choice)"""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import breadth_first_order, maximum_flow
+    rng = np.random.default_rng(1)
+    for trial in range(40):
+        W, H = int(rng.integers(2, 14)), int(rng.integers(2, 14))
+        n = W * H
+        term = np.where(rng.random(n) < 0.3, rng.integers(-50, 50, n), 0).astype(np.float32)
+        wh = rng.integers(1, 30, n).astype(np.float32)
+        wv = rng.integers(1, 30, n).astype(np.float32)
+        flow, lab = po.gc_grid_max_flow(term.reshape(H, W), wh.reshape(H, W), wv.reshape(H, W))
+        rows, cols, caps = [], [], []
+        for k in range(n):
+            if term[k] > 0: rows.append(n); cols.append(k); caps.append(int(term[k]))
+            if term[k] < 0: rows.append(k); cols.append(n + 1); caps.append(int(-term[k]))
+        for y in range(H):
+            for x in range(W):
+                v = y * W + x
+                if x < W - 1: rows += [v, v + 1]; cols += [v + 1, v]; caps += [int(wh[v])] * 2
+                if y < H - 1: rows += [v, v + W]; cols += [v + W, v]; caps += [int(wv[v])] * 2
+        g = csr_matrix((caps, (rows, cols)), shape=(n + 2, n + 2), dtype=np.int32)
+        r = maximum_flow(g, n, n + 1)
+        resid = (g - r.flow).tocsr()
+        resid.data = np.maximum(resid.data, 0)
+        resid.eliminate_zeros()
+        src = np.zeros(n + 2, bool); src[breadth_first_order(resid, n, return_predecessors=False)] = True
+        snk = np.zeros(n + 2, bool); snk[breadth_first_order(resid.T.tocsr(), n + 1, return_predecessors=False)] = True
+        assert flow == r.flow_value, trial
+        lab = lab.reshape(-1)
+        assert (lab[src[:n]] == 1).all() and (lab[snk[:n]] == 0).all(), trial
+
+
+def test_graphcut_find_properties(po, c1):
+    """GraphCutSeamFinder(COST_COLOR)::find: inside an overlap exactly one of two full masks survives per pixel, a seam
+    follows identical content (zero colour cost) rather than a mismatch, untouched outside the overlap"""
+    rng = np.random.default_rng(3)
+    base = rng.integers(8, 248, (40, 90, 3), dtype=np.uint8)
+    # two noisy views of one scene (identical views would make every edge cost the same and the cut a matter of ties)
+    a = (base[:, :60].astype(np.int16) + rng.integers(-6, 7, (40, 60, 3))).astype(np.uint8)
+    b = (base[:, 30:].astype(np.int16) + rng.integers(-6, 7, (40, 60, 3))).astype(np.uint8)
+    # ... that disagree strongly on a band of columns, which the cut has to stay out of
+    b[:, 5:12] = 255 - b[:, 5:12]
+    ma, mb = np.full((40, 60), 255, np.uint8), np.full((40, 60), 255, np.uint8)
+    ra, rb = po.graphcut_find([(0, 0), (30, 0)], [a, b], [ma, mb])
+    ov_a, ov_b = ra[:, 30:], rb[:, :30]
+    assert ((ov_a != 0) ^ (ov_b != 0)).all()                  # a partition of the overlap
+    assert (ra[:, :30] == 255).all() and (rb[:, 30:] == 255).all()
+    # the band (columns 5..11 of the overlap) lies on one side of the seam: all a or all b
+    band = ov_a[:, 5:12] != 0
+    assert band.all() or not band.any()
+    # and the cut is the cheap one: its colour cost is far below that of a cut through the band
+    lab = ov_a != 0
+    nd = ((a[:, 30:].astype(np.float64) - b[:, :30].astype(np.float64)) ** 2).sum(-1)
+    cost = ((nd[:, :-1] + nd[:, 1:] + 1) * (lab[:, :-1] != lab[:, 1:])).sum() + ((nd[:-1] + nd[1:] + 1) * (lab[:-1] != lab[1:])).sum()
+    assert cost < 40 * 2 * 3 * 12 ** 2 * 2
+    # the whole pipeline on config 1 gives usable masks: every panorama pixel some camera covers keeps an owner
+    masks = po.prepare_masks_graphcut(c1["frames"], c1["K"], c1["R"], c1["scale"])
+    vor = po.prepare_masks_voronoi(po.SPHERICAL, 480, 270, c1["K"], c1["R"], c1["scale"])
+    for m, v in zip(masks, vor):
+        assert m.shape == v.shape and 0.5 < (m != 0).sum() / (v != 0).sum() < 1.5
+    pano, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 3)
+    assert (pano.reshape(-1, 3).max(1) > 0).mean() > 0.9
