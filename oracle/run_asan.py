@@ -26,4 +26,8 @@ rng = np.random.default_rng(0)
 imgs = [rng.integers(0, 256, (37, 53, 3), dtype=np.uint8), rng.integers(0, 256, (41, 47, 3), dtype=np.uint8)]
 po.gain_blocks_feed([(0, 0), (30, 5)], imgs, [np.full(i.shape[:2], 255, np.uint8) for i in imgs], 8, 8)
 po.gain_feed([(0, 0), (1000, 5)], imgs, [np.full(i.shape[:2], 255, np.uint8) for i in imgs])
+# graph-cut seam finder: the whole updateMask restatement, and flat frames (ties: free vertices)
+for kind in (0, 1):
+    po.prepare_masks_graphcut(frames, K, d["R"], d["scale"], kind)
+po.prepare_masks_graphcut([np.full_like(f, 77) for f in frames], K, d["R"], d["scale"])
 print("oracle ran clean under ASan/UBSan")
