@@ -289,6 +289,24 @@ def main():
                         "in_timed_region": dict(timed, frames_in_flight=F),
                         "one_frame_at_a_time_panoramas_per_s": alone_rate,
                         "one_frame_at_a_time_stage_us": alone_stage}
+            # also against a measured device-copy ceiling - a 256 MB device-to-device copy (bytes read + written)
+            try:
+                x = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+                y = torch.empty_like(x)
+                for _ in range(3):
+                    y.copy_(x)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    y.copy_(x)
+                e1.record()
+                torch.cuda.synchronize()
+                copy_gbs = 2 * x.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+                roofline["device_copy_ceiling_GBps"] = round(copy_gbs, 1)
+                roofline["frac_of_copy_ceiling"] = round(alone["achieved"] / copy_gbs, 4)
+                del x, y
+            except Exception:  # the side measurement never breaks the line
+                pass
         if world > 1 and stage_n[0]:
             # N > 1: rank 0's own K1 launches (its cameras of each group, one launch per group it feeds), taken from the
             # event pass; the algorithmic bytes are its cameras' share of the group's
