@@ -54,8 +54,10 @@ struct pano_ctx {
     // gain
     float* gain[kMaxCams] = {};
     int gain_w[kMaxCams] = {}, gain_h[kMaxCams] = {};
-    int2 *gcol[kMaxCams] = {}, *grow[kMaxCams] = {}, *gcol_roi[kMaxCams] = {}, *grow_roi[kMaxCams] = {};
-    float2 *gcolw[kMaxCams] = {}, *groww[kMaxCams] = {}, *gcolw_roi[kMaxCams] = {}, *groww_roi[kMaxCams] = {};
+    int2 *grow[kMaxCams] = {}, *grow_roi[kMaxCams] = {};
+    float2 *groww[kMaxCams] = {}, *groww_roi[kMaxCams] = {};
+    float *ghrow[kMaxCams] = {}, *ghrow_roi[kMaxCams] = {};  // horizontally resized gain map rows (tile / ROI columns)
+    int ghrow_pitch[kMaxCams] = {}, ghrow_roi_pitch[kMaxCams] = {};
 
     // pyramid slots (one allocation), weights, canvas
     char* pyr_base = nullptr;
@@ -209,8 +211,8 @@ void free_device(pano_ctx* c) {
     for (int i = 0; i < kMaxCams; i++) {
         dfree(c->colA[i]); dfree(c->rowB[i]); dfree(c->colA_roi[i]); dfree(c->rowB_roi[i]);
         dfree(c->mask[i]); dfree(c->gain[i]); dfree(c->mask0[i]); dfree(c->lut[i]); dfree(c->lutc[i]); dfree(c->box[i]); dfree(c->k1_flags[i]); dfree(c->d_fe[i]);
-        dfree(c->gcol[i]); dfree(c->grow[i]); dfree(c->gcol_roi[i]); dfree(c->grow_roi[i]);
-        dfree(c->gcolw[i]); dfree(c->groww[i]); dfree(c->gcolw_roi[i]); dfree(c->groww_roi[i]);
+        dfree(c->grow[i]); dfree(c->grow_roi[i]); dfree(c->groww[i]); dfree(c->groww_roi[i]);
+        dfree(c->ghrow[i]); dfree(c->ghrow_roi[i]);
         dfree(c->stage_in[i]);
         for (int l = 0; l < kMaxLevels; l++) dfree(c->wgt[i][l]);
     }
@@ -261,7 +263,7 @@ WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t strid
     if (roi_only) {
         w.colA = c->colA_roi[i]; w.rowB = c->rowB_roi[i];
         w.tw = c->plan.roi[i].w; w.th = c->plan.roi[i].h;
-        w.gcol = c->gcol_roi[i]; w.gcolw = c->gcolw_roi[i]; w.grow = c->grow_roi[i]; w.groww = c->groww_roi[i];
+        w.ghrow = c->ghrow_roi[i]; w.ghrow_pitch = c->ghrow_roi_pitch[i]; w.grow = c->grow_roi[i]; w.groww = c->groww_roi[i];
     } else {
         w.colA = c->colA[i]; w.rowB = c->rowB[i];
         w.tw = c->plan.tile[i].rect.w; w.th = c->plan.tile[i].rect.h;
@@ -273,7 +275,7 @@ WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t strid
         w.lutc = c->use_lut ? c->lutc[i] : nullptr;
         w.box = c->use_lut ? c->box[i] : nullptr;
         w.lutc_pitch = c->lut_pitch[i] / 4;
-        w.gcol = c->gcol[i]; w.gcolw = c->gcolw[i]; w.grow = c->grow[i]; w.groww = c->groww[i];
+        w.ghrow = c->ghrow[i]; w.ghrow_pitch = c->ghrow_pitch[i]; w.grow = c->grow[i]; w.groww = c->groww[i];
     }
     w.gain = c->gain[i];
     w.gw = c->gain_w[i];
@@ -411,7 +413,7 @@ inline void linear_coef(int d, int ssize, int dsize, int& s0, int& s1, float& a0
     a1 = f;
 }
 
-pano_status upload_gain_tables(pano_ctx* c, int i) {
+pano_status upload_gain_tables(pano_ctx* c, int i, const float* h_gain) {
     const Rect& roi = c->plan.roi[i];
     const FeedTile& t = c->plan.tile[i];
     int gw = c->gain_w[i], gh = c->gain_h[i];
@@ -439,18 +441,33 @@ pano_status upload_gain_tables(pano_ctx* c, int i) {
             wv[k] = make_float2(a0, a1);
         }
     };
+    // HResizeLinear<float> of every map row at every column: S[sx] * (1 - fx) + S[sx1] * fx, the f32 expression of
+    // resizeGeneric_'s horizontal pass, once per gain map instead of once per pixel and frame
+    auto hresize = [&](const std::vector<int2>& ix, const std::vector<float2>& wx, int n, std::vector<float>& out, int& pitch) {
+        pitch = (int)align_up((size_t)n, 4);
+        out.assign((size_t)gh * pitch, 0.f);
+        for (int gy = 0; gy < gh; gy++) {
+            const float* S = h_gain + (size_t)gy * gw;
+            float* o = out.data() + (size_t)gy * pitch;
+            for (int x = 0; x < pitch; x++) {
+                const int k = std::min(x, n - 1);
+                o[x] = S[ix[k].x] * wx[k].x + S[ix[k].y] * wx[k].y;
+            }
+        }
+    };
     std::vector<int2> ix;
     std::vector<float2> wx;
+    std::vector<float> hr;
     pano_status s;
     build(t.rect.w, t.left, roi.w, gw, ix, wx, false);
-    if ((s = upload(c, &c->gcol[i], ix.data(), ix.size() * sizeof(int2)))) return s;
-    if ((s = upload(c, &c->gcolw[i], wx.data(), wx.size() * sizeof(float2)))) return s;
+    hresize(ix, wx, t.rect.w, hr, c->ghrow_pitch[i]);
+    if ((s = upload(c, &c->ghrow[i], hr.data(), hr.size() * sizeof(float)))) return s;
     build(t.rect.h, t.top, roi.h, gh, ix, wx, true);
     if ((s = upload(c, &c->grow[i], ix.data(), ix.size() * sizeof(int2)))) return s;
     if ((s = upload(c, &c->groww[i], wx.data(), wx.size() * sizeof(float2)))) return s;
     build(roi.w, 0, roi.w, gw, ix, wx, false);
-    if ((s = upload(c, &c->gcol_roi[i], ix.data(), ix.size() * sizeof(int2)))) return s;
-    if ((s = upload(c, &c->gcolw_roi[i], wx.data(), wx.size() * sizeof(float2)))) return s;
+    hresize(ix, wx, roi.w, hr, c->ghrow_roi_pitch[i]);
+    if ((s = upload(c, &c->ghrow_roi[i], hr.data(), hr.size() * sizeof(float)))) return s;
     build(roi.h, 0, roi.h, gh, ix, wx, true);
     if ((s = upload(c, &c->grow_roi[i], ix.data(), ix.size() * sizeof(int2)))) return s;
     if ((s = upload(c, &c->groww_roi[i], wx.data(), wx.size() * sizeof(float2)))) return s;
@@ -1324,7 +1341,7 @@ pano_status pano_set_gain_map(pano_ctx* c, int i, const float* h_gain, int gw, i
     c->gain_w[i] = gw;
     c->gain_h[i] = gh;
     if ((s = upload(c, &c->gain[i], h_gain, (size_t)gw * gh * sizeof(float)))) return s;
-    return upload_gain_tables(c, i);
+    return upload_gain_tables(c, i, h_gain);
 }
 
 pano_status pano_get_gain_map(pano_ctx* c, int i, float* h_gain, int* gw, int* gh) {
@@ -1432,7 +1449,7 @@ pano_status pano_estimate_gains(pano_ctx* c, const uint8_t* const* h_frames, con
         c->gain_w[i] = per_w[i];
         c->gain_h[i] = per_h[i];
         if ((st = upload(c, &c->gain[i], map.data(), map.size() * sizeof(float)))) return st;
-        if ((st = upload_gain_tables(c, i))) return st;
+        if ((st = upload_gain_tables(c, i, map.data()))) return st;
     }
     return PANO_OK;
 }

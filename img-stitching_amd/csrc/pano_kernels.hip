@@ -152,15 +152,11 @@ __device__ __forceinline__ void sample_bilinear_reflect(const uint8_t* __restric
 // BlocksGainCompensator::apply: gain = bilinear (cv::resize INTER_LINEAR, f32) of the block map,
 // px = saturate_cast<uchar>(px * gain)
 __device__ __forceinline__ void apply_gain(const WarpCam& c, int x, int y, int v[3]) {
-    int2 gx = c.gcol[x];
-    float2 ax = c.gcolw[x];
-    int2 gy = c.grow[y];
-    float2 by = c.groww[y];
-    const float* S0 = c.gain + (size_t)gy.x * c.gw;
-    const float* S1 = c.gain + (size_t)gy.y * c.gw;
-    float h0 = S0[gx.x] * ax.x + S0[gx.y] * ax.y;
-    float h1 = S1[gx.x] * ax.x + S1[gx.y] * ax.y;
-    float g = h0 * by.x + h1 * by.y;
+    const int2 gy = c.grow[y];
+    const float2 by = c.groww[y];
+    const float h0 = c.ghrow[(unsigned)(gy.x * c.ghrow_pitch + x)];
+    const float h1 = c.ghrow[(unsigned)(gy.y * c.ghrow_pitch + x)];
+    const float g = h0 * by.x + h1 * by.y;
 #pragma unroll
     for (int k = 0; k < 3; k++) v[k] = sat8i(cv_round_dev((float)v[k] * g));
 }
@@ -759,23 +755,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     unsigned r[4][3];
 #pragma unroll
     for (int j = 0; j < 4; j++) bilinear_b2(t[j], u[j], X[j] & 31u, Y[j] & 31u, r[j]);
+    unsigned pk[3];
     if (GAIN && cg->gain != nullptr) {  // per camera: workgroup-uniform
+        // the gains of the lane's four pixels: two 16-byte reads of the horizontally resized map rows, then the vertical pass
+        const int2 gy = cg->grow[y];
+        const float2 by = cg->groww[y];
+        const int gp = cg->ghrow_pitch;
+        const float4 h0 = *reinterpret_cast<const float4*>(cg->ghrow + (unsigned)(gy.x * gp + x0));
+        const float4 h1 = *reinterpret_cast<const float4*>(cg->ghrow + (unsigned)(gy.y * gp + x0));
+        const float g[4] = {h0.x * by.x + h1.x * by.y, h0.y * by.x + h1.y * by.y, h0.z * by.x + h1.z * by.y, h0.w * by.x + h1.w * by.y};
+        // saturate_cast<uchar>(px * gain) = round-half-even + clamp is what v_cvt_pk_u8_f32 does, and it drops the byte
+        // where the plane dword wants it: three instructions per value (v_cvt_f32_ubyte2, v_mul_f32, v_cvt_pk_u8_f32)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            int v[3] = {(int)(r[j][0] >> 16), (int)(r[j][1] >> 16), (int)(r[j][2] >> 16)};
-            apply_gain(*cg, min(x0 + j, tw - 1), y, v);
+        for (int ch = 0; ch < 3; ch++) {
+            pk[ch] = 0u;
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) r[j][ch] = (unsigned)v[ch] << 16;
+            for (int j = 0; j < 4; j++)
+                pk[ch] = __builtin_amdgcn_cvt_pk_u8_f32((float)((r[j][ch] >> 16) & 0xffu) * g[j], (unsigned)j, pk[ch]);
+        }
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            // byte 2 of r[0..3][ch] -> bytes 0..3
+            const unsigned lo = __builtin_amdgcn_perm(r[1][ch], r[0][ch], 0x0c0c0602u);
+            const unsigned hi = __builtin_amdgcn_perm(r[3][ch], r[2][ch], 0x06020c0cu);
+            pk[ch] = lo | hi;
         }
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
-        // byte 2 of r[0..3][ch] -> bytes 0..3
-        const unsigned lo = __builtin_amdgcn_perm(r[1][ch], r[0][ch], 0x0c0c0602u);
-        const unsigned hi = __builtin_amdgcn_perm(r[3][ch], r[2][ch], 0x06020c0cu);
-        const unsigned pk = lo | hi;
-        if ((ABL == 4 || ABL == 17) && pk != 0x12345678u) continue;  // diagnostic: no stores
-        *reinterpret_cast<unsigned PANO_GLOBAL*>(d + (unsigned)ch * dst_plane) = pk;  // rows are padded to 16 bytes
+        if ((ABL == 4 || ABL == 17) && pk[ch] != 0x12345678u) continue;  // diagnostic: no stores
+        *reinterpret_cast<unsigned PANO_GLOBAL*>(d + (unsigned)ch * dst_plane) = pk[ch];  // rows are padded to 16 bytes
     }
 }
 

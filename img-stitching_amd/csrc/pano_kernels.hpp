@@ -49,9 +49,11 @@ struct alignas(64) WarpCam {
     const float2* rowB;   // [th] {sin(pi - v/s) | 1, cos(pi - v/s) | v/s}
     const FrontEndDev* fe; // nullptr, or the undistort front end: src is then the RAW frame (src_w x src_h raw)
     int out_w, out_h;     // the stitcher's frame size (mask warp inside test); == src_w x src_h without a front end
-    // optional exposure gain: bilinear resize of the block map on the fly
-    const int2* gcol;     // [tw] {sx, sx1}   (REFLECT folded like colA)
-    const float2* gcolw;  // [tw] {1-fx, fx}
+    // optional exposure gain: cv::resize(INTER_LINEAR) of the block map on the fly.  The horizontal pass is a table -
+    // ghrow[gy][x] = S[gy][sx] * (1 - fx) + S[gy][sx1] * fx for every map row gy and tile column x (REFLECT folded like
+    // colA) - so a pixel needs two coalesced reads and the vertical pass h0 * (1 - fy) + h1 * fy
+    const float* ghrow;   // [gain_h][ghrow_pitch]
+    int ghrow_pitch;      // floats per row, a multiple of 4; columns past tw repeat the last one
     const int2* grow;     // [th] {sy0, sy1}
     const float2* groww;  // [th] {1-fy, fy}
     int gw;
