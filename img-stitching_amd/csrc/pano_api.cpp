@@ -480,6 +480,9 @@ pano_status ensure_weights(pano_ctx* c, hipStream_t s) {
     const Plan& P = c->plan;
     for (int i = 0; i < P.n; i++)
         if (!c->mask_set[i]) return fail(c, PANO_ESTATE, "blend masks not set (pano_set_mask / pano_build_masks_voronoi)");
+    // the weights, bordered masks and owner maps are shared by every frame slot: frames still in flight on other streams
+    // (composed under the old masks) have to finish before they are rewritten
+    HIP_TRY(c, hipDeviceSynchronize());
     for (int i = 0; i < P.n; i++) {
         const FeedTile& t = P.tile[i];
         launch_mask_to_weight(c->mask[i], P.roi[i].w, P.roi[i].h, P.roi[i].w, t.left, t.top, c->wgt[i][0], c->wpitch[i][0],

@@ -873,3 +873,32 @@ def test_graphcut_masks_bit_exact(pano, po, c1, rig_r, case):
         ctx.build_masks_voronoi()
         vor = oracle_masks(po, d, kind)
         assert all(np.array_equal(ctx.get_mask(i), vor[i]) for i in range(4))
+
+
+def test_mask_refresh_with_frames_in_flight(pano, po, torch):
+    """the updateMask cadence (ocvstitcher.hpp:1152-1159) under frames in flight: the weights are shared by all frame
+    slots, so a mask change while earlier frames are still running has to let them finish under the OLD masks - every
+    frame equals the oracle under the masks that were current when it was submitted"""
+    d = c2_group(w=960, h=540, f=501.0)
+    n, nslot = d["n"], 4
+    ctx = make_ctx(pano, d, 0, num_bands=4)
+    ctx.build_masks_voronoi()
+    ctx.set_frame_slots(nslot)
+    vor = [ctx.get_mask(i) for i in range(n)]
+    frames = [[synth_frame(d["w"], d["h"], 700 + 10 * k + i) for i in range(n)] for k in range(10)]
+    frames_d = [[torch.from_numpy(f).cuda() for f in fr] for fr in frames]
+    ow, oh = ctx.output_size()
+    streams = [torch.cuda.Stream() for _ in range(nslot)]
+    outs = [torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in frames]
+    gc_masks = po.prepare_masks_graphcut(frames[5], d["K"], d["R"], d["scale"])
+    assert any(not np.array_equal(a, b) for a, b in zip(vor, gc_masks))
+    torch.cuda.synchronize()
+    for k, fr in enumerate(frames_d):
+        if k == 5:      # no synchronisation by the caller: frames 2..4 are still in flight
+            ctx.build_masks_graphcut(frames[5])
+        ctx.select_frame_slot(k % nslot)
+        ctx.compose([t.data_ptr() for t in fr], [d["w"] * 3] * n, outs[k].data_ptr(), ow * 3, streams[k % nslot].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(len(frames)):
+        want, _ = po.compose(frames[k], d["K"], d["R"], d["scale"], vor if k < 5 else gc_masks, 4)
+        assert np.array_equal(outs[k].cpu().numpy(), want), k
