@@ -1650,7 +1650,14 @@ pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b, const uint8_t* const* fa
     for (int i = 0; i < B.n; i++) pp.cam[A.n + i] = b->pyr.cam[i];
     pp.ncam = A.n + B.n;
     const unsigned all = (1u << pp.ncam) - 1u;
+#ifdef PANO_DIAG
+    // diagnostic (wrong pictures, timing only): what would fewer pyramid launches be worth?  PANO_PYR_LEVELS=n launches only
+    // the first n levels
+    static const int kpyr = getenv("PANO_PYR_LEVELS") ? atoi(getenv("PANO_PYR_LEVELS")) : 99;
+    for (int l = 0; l < A.bands && l < kpyr; l++) launch_pyr_down(pp, all, l, s);
+#else
     for (int l = 0; l < A.bands; l++) launch_pyr_down(pp, all, l, s);
+#endif
     if (prof && (st = record(a, 2, s)) != PANO_OK) return st;
     // K3: both canvases per launch
     CanvasSet cs{};
