@@ -1274,8 +1274,20 @@ __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0
 template <bool L0, int ABL = 0, int NPL = 3>
 __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, CanvasSet CS, int lvl) {
     static_assert(NPL == 3 || !L0, "level 0 writes interleaved BGR");
-    const int pb = NPL == 3 ? 0 : (int)(blockIdx.z % 3);  // first plane of this lane
-    const CanvasParams& C = CS.c[NPL == 3 ? blockIdx.z : blockIdx.z / 3];
+    unsigned bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+    if (((lvl >> 8) & 15) == 3) {
+        // XCD bands (shape 3, the default): a 1-D grid of 8 * per workgroups; the hardware deals consecutive ids round-robin
+        // over the 8 XCDs, so XCD k is given the logical workgroups [k * per, (k + 1) * per) - a contiguous band of canvas
+        // rows, whose neighbouring workgroups share their cache lines and pyrUp halos in ONE L2
+        const unsigned gx = ((unsigned)lvl >> 12) & 0x3ffu, gy = ((unsigned)lvl >> 22) & 0x3ffu;
+        const unsigned total = gx * gy * (unsigned)(NPL == 3 ? CS.n : CS.n * 3);
+        const unsigned per = (total + 7u) / 8u;
+        const unsigned logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= per || logical >= total) return;
+        bxi = logical % gx; byi = (logical / gx) % gy; bzi = logical / (gx * gy);
+    }
+    const int pb = NPL == 3 ? 0 : (int)(bzi % 3);  // first plane of this lane
+    const CanvasParams& C = CS.c[NPL == 3 ? bzi : bzi / 3];
     const int cam_lo = C.cam_lo, cam_n = C.cam_n;
     const int l = L0 ? 0 : (lvl & 0xff);
     const int cw = C.w0 >> l, ch = C.h0 >> l;
@@ -1289,18 +1301,19 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     // ~45 MB it uses; side by side (256 x 8, shape 0) it fetches 74 MB.  Measured per frame (levels 0-2, C2), stacked /
     // side by side / 2 x 2: HBM bytes of these launches 247 / 145 / 182 MB, panoramas/s one frame at a time 7.18 / 7.35 /
     // 7.27 k, with four frames in flight 11.77 / 11.64 / 11.83 k (same box, alternating): bytes are not what bounds the
-    // pipeline, and 2 x 2 is the fastest where it counts.  PANO_K3_SHAPE=0|1|2.
+    // pipeline, and 2 x 2 is the fastest of the three.  On top of 2 x 2, XCD bands (above): blend stage 76.6 -> 72.8 us,
+    // 7.24 -> 7.46 k one frame at a time, 11.71 -> 11.92 k in flight.  PANO_K3_SHAPE=0|1|2|3.
     int X0, Y0;
-    if ((lvl >> 8) == 1) {         // stacked
+    if (((lvl >> 8) & 15) == 1) {         // stacked
         const int tid = threadIdx.y * 64 + threadIdx.x;
-        X0 = bx0 + (blockIdx.x * 16 + (tid & 15)) * 4;
-        Y0 = by0 + (blockIdx.y * 16 + (tid >> 4)) * 2;
-    } else if ((lvl >> 8) == 0) {  // side by side
-        X0 = bx0 + ((blockIdx.x * 4 + threadIdx.y) * 16 + (threadIdx.x & 15)) * 4;
-        Y0 = by0 + (blockIdx.y * 4 + (threadIdx.x >> 4)) * 2;
-    } else {                       // 2 x 2
-        X0 = bx0 + ((blockIdx.x * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
-        Y0 = by0 + ((blockIdx.y * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * 2;
+        X0 = bx0 + (bxi * 16 + (tid & 15)) * 4;
+        Y0 = by0 + (byi * 16 + (tid >> 4)) * 2;
+    } else if (((lvl >> 8) & 15) == 0) {  // side by side
+        X0 = bx0 + ((bxi * 4 + threadIdx.y) * 16 + (threadIdx.x & 15)) * 4;
+        Y0 = by0 + (byi * 4 + (threadIdx.x >> 4)) * 2;
+    } else {                              // 2 x 2
+        X0 = bx0 + ((bxi * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
+        Y0 = by0 + ((byi * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * 2;
     }
     if (L0) {
         if (X0 >= C.cut_x + C.cut_w || Y0 >= C.cut_y + C.cut_h) return;
@@ -1771,12 +1784,18 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
                 h = max(h, cg.h0 >> l);
             }
         }
-        // workgroup shape (see the kernel): 2 = 2 x 2 waves (default), 0 = side by side, 1 = stacked
-        static const int stacked = getenv("PANO_K3_SHAPE") ? atoi(getenv("PANO_K3_SHAPE")) & 3 : 2;
+        // workgroup shape (see the kernel): 3 = 2 x 2 waves in XCD bands (default), 2 = 2 x 2 waves, 0 = side by side, 1 = stacked
+        static const int stacked = getenv("PANO_K3_SHAPE") ? atoi(getenv("PANO_K3_SHAPE")) & 3 : 3;
         dim3 block(64, 4, 1), grid((w + 127) / 128, (h + 15) / 16, cs.n);
         if (stacked == 0) grid = dim3((w + 255) / 256, (h + 7) / 8, cs.n);
         if (stacked == 1) grid = dim3((w + 63) / 64, (h + 31) / 32, cs.n);
-        const int larg = l | ((stacked == 3 ? 2 : stacked) << 8);
+        int larg = l | (stacked << 8);
+        const dim3 grid3 = grid;  // the logical extents
+        if (stacked == 3) {       // XCD bands over the 2 x 2 shape: a 1-D grid of 8 * ceil(workgroups / 8)
+            larg |= (int)((grid3.x & 0x3ffu) << 12) | (int)((grid3.y & 0x3ffu) << 22);
+            const unsigned zext = (l == 0 || (getenv("PANO_BLEND_PLANES") && atoi(getenv("PANO_BLEND_PLANES")) == 0)) ? cs.n : cs.n * 3;
+            grid = dim3(8u * ((grid3.x * grid3.y * zext + 7u) / 8u), 1, 1);
+        }
 #ifdef PANO_DIAG
         static const int kabl = getenv("PANO_K3_ABL") ? atoi(getenv("PANO_K3_ABL")) : 0;
         if (l == 0 && kabl == 1) { hipLaunchKernelGGL((blend_level_vec_kernel<true, 1>), grid, block, 0, s, p, cs, larg); return; }
@@ -1796,7 +1815,7 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
             // one plane per lane on the canvas levels >= 1 (measured: levels 1 + 2 29 -> 23 us, in flight no worse);
             // PANO_BLEND_PLANES=0 keeps three planes per lane
             static const bool split = !(getenv("PANO_BLEND_PLANES") && atoi(getenv("PANO_BLEND_PLANES")) == 0);
-            if (split) hipLaunchKernelGGL((blend_level_vec_kernel<false, 0, 1>), dim3(grid.x, grid.y, cs.n * 3), block, 0, s, p, cs, larg);
+            if (split) hipLaunchKernelGGL((blend_level_vec_kernel<false, 0, 1>), stacked == 3 ? grid : dim3(grid.x, grid.y, cs.n * 3), block, 0, s, p, cs, larg);
             else hipLaunchKernelGGL((blend_level_vec_kernel<false, 0, 3>), grid, block, 0, s, p, cs, larg);
         }
         return;
