@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-paths", action="store_true",
+                    help="skip the PCIe-inclusive side measurements (host-buffer and streaming entries); used under rocprofv3 so that "
+                         "the kernel summary covers the device-resident loop only")
     ap.add_argument("--bands", type=int, default=5)
     ap.add_argument("--one-stream", action="store_true", help="both groups on one stream (no overlap)")
     ap.add_argument("--force-sharded-path", action="store_true", help="diagnostic: run the N>1 step code at N=1")
@@ -338,7 +341,7 @@ def main():
             "stage_us_per_launch": {k: round(stage_ms[i] / max(stage_n[i], 1) * 1e3, 2)
                                     for i, k in enumerate(("warp", "pyramid", "blend"))},
         }
-        if world == 1:
+        if world == 1 and not args.no_host_paths:
             # the reference-shaped entry (host cv::Mat in, host cv::Mat out; H2D + compose + D2H, synchronous):
             # reported for DESIGN.md, never the `value`
             for c in ctxs:
