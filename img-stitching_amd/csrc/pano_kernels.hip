@@ -1785,15 +1785,20 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
             }
         }
         // workgroup shape (see the kernel): 3 = 2 x 2 waves in XCD bands (default), 2 = 2 x 2 waves, 0 = side by side, 1 = stacked
-        static const int stacked = getenv("PANO_K3_SHAPE") ? atoi(getenv("PANO_K3_SHAPE")) & 3 : 3;
+        static const int shape_env = getenv("PANO_K3_SHAPE") ? atoi(getenv("PANO_K3_SHAPE")) & 3 : 3;
+        // one plane per lane on the canvas levels >= 1 (measured: levels 1 + 2 29 -> 23 us, in flight no worse);
+        // PANO_BLEND_PLANES=0 keeps three planes per lane
+        static const bool split = !(getenv("PANO_BLEND_PLANES") && atoi(getenv("PANO_BLEND_PLANES")) == 0);
+        int shape = shape_env;
+        if (shape == 3 && ((w + 127) / 128 > 1023 || (h + 15) / 16 > 1023)) shape = 2;  // the band form packs the extents in 10 bits each
         dim3 block(64, 4, 1), grid((w + 127) / 128, (h + 15) / 16, cs.n);
-        if (stacked == 0) grid = dim3((w + 255) / 256, (h + 7) / 8, cs.n);
-        if (stacked == 1) grid = dim3((w + 63) / 64, (h + 31) / 32, cs.n);
-        int larg = l | (stacked << 8);
+        if (shape == 0) grid = dim3((w + 255) / 256, (h + 7) / 8, cs.n);
+        if (shape == 1) grid = dim3((w + 63) / 64, (h + 31) / 32, cs.n);
+        int larg = l | (shape << 8);
         const dim3 grid3 = grid;  // the logical extents
-        if (stacked == 3) {       // XCD bands over the 2 x 2 shape: a 1-D grid of 8 * ceil(workgroups / 8)
+        if (shape == 3) {       // XCD bands over the 2 x 2 shape: a 1-D grid of 8 * ceil(workgroups / 8)
             larg |= (int)((grid3.x & 0x3ffu) << 12) | (int)((grid3.y & 0x3ffu) << 22);
-            const unsigned zext = (l == 0 || (getenv("PANO_BLEND_PLANES") && atoi(getenv("PANO_BLEND_PLANES")) == 0)) ? cs.n : cs.n * 3;
+            const unsigned zext = (l == 0 || !split) ? cs.n : cs.n * 3;
             grid = dim3(8u * ((grid3.x * grid3.y * zext + 7u) / 8u), 1, 1);
         }
 #ifdef PANO_DIAG
@@ -1812,10 +1817,7 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
 #endif
         if (l == 0) hipLaunchKernelGGL((blend_level_vec_kernel<true, 0>), grid, block, 0, s, p, cs, larg);
         else {
-            // one plane per lane on the canvas levels >= 1 (measured: levels 1 + 2 29 -> 23 us, in flight no worse);
-            // PANO_BLEND_PLANES=0 keeps three planes per lane
-            static const bool split = !(getenv("PANO_BLEND_PLANES") && atoi(getenv("PANO_BLEND_PLANES")) == 0);
-            if (split) hipLaunchKernelGGL((blend_level_vec_kernel<false, 0, 1>), stacked == 3 ? grid : dim3(grid.x, grid.y, cs.n * 3), block, 0, s, p, cs, larg);
+            if (split) hipLaunchKernelGGL((blend_level_vec_kernel<false, 0, 1>), shape == 3 ? grid : dim3(grid.x, grid.y, cs.n * 3), block, 0, s, p, cs, larg);
             else hipLaunchKernelGGL((blend_level_vec_kernel<false, 0, 3>), grid, block, 0, s, p, cs, larg);
         }
         return;
