@@ -6,6 +6,8 @@ reference (which ships none and cannot be built here).
 
   c1_golden.json   sha256 of: per-camera warped image and Voronoi blend mask, panorama for bands 0/2/4 and
                    Blender::NO, cut panorama; plus ROI / size integers
+                   graph-cut blend masks (the reference's seam finder) and the panorama under them; block gain maps
+                   (BlocksGainCompensator::feed as initSeam runs it, raw f32 bytes) and the panorama with them applied
   c1_pano_b4.png   the 1333x257 4-band panorama (RGB PNG) for eyeballing and byte comparison
 """
 import hashlib
@@ -47,6 +49,15 @@ def main():
     out["cut"] = list(cut)
     out["pano_cut_sha256"] = sha(pano)
     out["pano_size"] = [1333, 257]
+    # the reference's own seam finder and its exposure compensator, fed the way initSeam feeds them
+    gc = po.prepare_masks_graphcut(frames, K, d["R"], d["scale"])
+    out["graphcut_mask_sha256"] = [sha(m) for m in gc]
+    out["graphcut_pano_b4_sha256"] = sha(po.compose(frames, K, d["R"], d["scale"], gc, 4)[0])
+    gains, sizes = po.estimate_gains(frames, K, d["R"], d["scale"])
+    out["gain_map_shape"] = [list(g.shape) for g in gains]
+    out["gain_map_sha256"] = [sha(g) for g in gains]
+    full = [po.resize_linear_32f(g, r[2], r[3]) for g, r in zip(gains, out["rois"])]
+    out["gain_pano_b4_sha256"] = sha(po.compose(frames, K, d["R"], d["scale"], masks, 4, gain_maps=full)[0])
     json.dump(out, open(os.path.join(HERE, "c1_golden.json"), "w"), indent=1)
 
 

@@ -321,6 +321,15 @@ def test_c1_against_committed_golden(pano, c1):
         if nb == 2:
             ctx.set_cut(g["cut"])
             assert sha(ctx.compose_host(c1["frames"])) == g["pano_cut_sha256"]
+    # the reference's seam finder and exposure compensator against the committed vectors
+    ctx = make_ctx(pano, c1, 0, num_bands=4)
+    ctx.build_masks_graphcut(c1["frames"])
+    assert [sha(ctx.get_mask(i)) for i in range(4)] == g["graphcut_mask_sha256"]
+    assert sha(ctx.compose_host(c1["frames"])) == g["graphcut_pano_b4_sha256"]
+    ctx.build_masks_voronoi()
+    gains = ctx.estimate_gains(c1["frames"])
+    assert [list(x.shape) for x in gains] == g["gain_map_shape"] and [sha(x) for x in gains] == g["gain_map_sha256"]
+    assert sha(ctx.compose_host(c1["frames"])) == g["gain_pano_b4_sha256"]
 
 
 def _rig(n, w, h, f, yaw0, step, pitch_deg=0.0):

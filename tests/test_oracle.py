@@ -216,6 +216,11 @@ def test_oracle_reproduces_committed_golden(po, c1):
         assert sha(pano) == g["pano_sha256"][str(nb)]
         if nb == 4:
             assert np.array_equal(pano, load_png_bgr(os.path.join(GOLDEN, "c1_pano_b4.png")))
+    gc = po.prepare_masks_graphcut(c1["frames"], c1["K"], c1["R"], c1["scale"])
+    assert [sha(m) for m in gc] == g["graphcut_mask_sha256"]
+    assert sha(po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], gc, 4)[0]) == g["graphcut_pano_b4_sha256"]
+    gains, _ = po.estimate_gains(c1["frames"], c1["K"], c1["R"], c1["scale"])
+    assert [list(x.shape) for x in gains] == g["gain_map_shape"] and [sha(x) for x in gains] == g["gain_map_sha256"]
 
 
 def test_caller_side_assembly_known_answers(po):
