@@ -14,6 +14,8 @@
 #include <cstring>
 #include <ctime>
 #include <fstream>
+#include <new>
+#include <stdexcept>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -763,6 +765,20 @@ pano_status finish_seam_masks(pano_ctx* c, const SeamWarps& sm, Scratch& tmp, hi
     return PANO_OK;
 }
 
+// run an entry point's body; an exception becomes a status instead of crossing the C boundary
+template <typename F>
+pano_status guarded(pano_ctx* c, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return c ? fail(c, PANO_ENOMEM, "out of host memory") : PANO_ENOMEM;
+    } catch (const std::exception& e) {
+        return c ? fail(c, PANO_ERR, e.what()) : PANO_ERR;
+    } catch (...) {
+        return c ? fail(c, PANO_ERR, "unknown exception") : PANO_ERR;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -771,7 +787,7 @@ const char* pano_version(void) { return "pano-hip 0.1 (gfx950)"; }
 
 const char* pano_last_error(const pano_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-pano_status pano_create(const pano_config* cfg, pano_ctx** out) {
+static pano_status create_impl(const pano_config* cfg, pano_ctx** out) {
     if (!cfg || !out) return PANO_EINVAL;
     *out = nullptr;
     if (cfg->num_images < 1 || cfg->num_images > PANO_MAX_CAMS || cfg->width < 2 || cfg->height < 2) return PANO_EINVAL;
@@ -815,7 +831,7 @@ pano_status pano_set_camera(pano_ctx* c, int i, const float K[9], const float R[
     return PANO_OK;
 }
 
-pano_status pano_set_cameras_from_list(pano_ctx* c, const char* list) {
+static pano_status set_cameras_from_list_impl(pano_ctx* c, const char* list) {
     if (!c || !list) return PANO_EINVAL;
     std::vector<float> v;
     if (!parse_floats(list, v)) return fail(c, PANO_ERR, "camera list: not a number");
@@ -830,7 +846,7 @@ pano_status pano_set_cameras_from_list(pano_ctx* c, const char* list) {
     return PANO_OK;
 }
 
-pano_status pano_load_camera_file(pano_ctx* c, const char* path) {
+static pano_status load_camera_file_impl(pano_ctx* c, const char* path) {
     if (!c || !path) return PANO_EINVAL;
     std::ifstream fin(path);
     if (!fin.is_open()) return fail(c, PANO_ERR, "cannot open camera parameter file");
@@ -875,7 +891,7 @@ pano_status pano_load_camera_file(pano_ctx* c, const char* path) {
     return PANO_OK;
 }
 
-pano_status pano_set_undistort(pano_ctx* c, int cam, const pano_undistort* u) {
+static pano_status set_undistort_impl(pano_ctx* c, int cam, const pano_undistort* u) {
     if (!c || !u || cam < 0 || cam >= c->cfg.num_images) return PANO_EINVAL;
     if (c->prepared) return fail(c, PANO_ESTATE, "the front end is fixed after pano_prepare");
     if (u->raw_w < 2 || u->raw_h < 2 || u->undist_w < 2 || u->undist_h < 2 || u->rect[2] < 1 || u->rect[3] < 1 ||
@@ -895,7 +911,7 @@ pano_status pano_get_new_camera_matrix(const pano_ctx* c, int cam, double newK[9
     return PANO_OK;
 }
 
-pano_status pano_save_camera_file(pano_ctx* c, const char* path) {
+static pano_status save_camera_file_impl(pano_ctx* c, const char* path) {
     if (!c || !path) return PANO_EINVAL;
     for (int i = 0; i < c->cfg.num_images; i++)
         if (!c->have_cam[i]) return fail(c, PANO_ESTATE, "camera parameters missing");
@@ -917,7 +933,7 @@ pano_status pano_save_camera_file(pano_ctx* c, const char* path) {
     return PANO_OK;
 }
 
-pano_status pano_prepare(pano_ctx* c) {
+static pano_status prepare_impl(pano_ctx* c) {
     if (!c) return PANO_EINVAL;
     if (c->prepared) return fail(c, PANO_ESTATE, "already prepared");
     const int n = c->cfg.num_images;
@@ -1145,7 +1161,7 @@ static void bind_slot(pano_ctx* c, int k) {
             c->pyr.cam[i].lvl[l] = (uint8_t*)(c->pyr_base + (size_t)i * c->slot_bytes + c->lvl_off[i][l]);
 }
 
-pano_status pano_set_frame_slots(pano_ctx* c, int n) {
+static pano_status set_frame_slots_impl(pano_ctx* c, int n) {
     pano_status st = check_compute(c);
     if (st != PANO_OK) return st;
     if (n < 1 || n > PANO_MAX_FRAME_SLOTS) return fail(c, PANO_EINVAL, "frame slots: 1 .. PANO_MAX_FRAME_SLOTS");
@@ -1229,7 +1245,7 @@ pano_status pano_get_output_size(const pano_ctx* c, int* w, int* h) {
     return PANO_OK;
 }
 
-pano_status pano_set_mask(pano_ctx* c, int i, const uint8_t* h_mask, int w, int h, size_t stride) {
+static pano_status set_mask_impl(pano_ctx* c, int i, const uint8_t* h_mask, int w, int h, size_t stride) {
     pano_status s = check_compute(c);
     if (s != PANO_OK) return s;
     if (!h_mask || i < 0 || i >= c->plan.n) return PANO_EINVAL;
@@ -1255,7 +1271,7 @@ pano_status pano_get_mask(pano_ctx* c, int i, uint8_t* h_mask, size_t stride) {
     return PANO_OK;
 }
 
-pano_status pano_build_masks_voronoi(pano_ctx* c) {
+static pano_status build_masks_voronoi_impl(pano_ctx* c) {
     pano_status st = check_compute(c);
     if (st != PANO_OK) return st;
     const int n = c->plan.n;
@@ -1279,7 +1295,7 @@ pano_status pano_build_masks_voronoi(pano_ctx* c) {
     return finish_seam_masks(c, sm, tmp, s);
 }
 
-pano_status pano_build_masks_graphcut(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides) {
+static pano_status build_masks_graphcut_impl(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides) {
     pano_status st = check_compute(c);
     if (st != PANO_OK) return st;
     if (!h_frames || !strides) return PANO_EINVAL;
@@ -1359,7 +1375,7 @@ pano_status pano_get_gain_map(pano_ctx* c, int i, float* h_gain, int* gw, int* g
     return PANO_OK;
 }
 
-pano_status pano_estimate_gains(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides, int block_w,
+static pano_status estimate_gains_impl(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides, int block_w,
                                 int block_h) {
     pano_status st = check_compute(c);
     if (st != PANO_OK) return st;
@@ -1687,7 +1703,7 @@ pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b, const uint8_t* const* fa
     return PANO_OK;
 }
 
-pano_status pano_compose_host(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides, uint8_t* h_out,
+static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides, uint8_t* h_out,
                               size_t out_stride) {
     pano_status st = check_compute(c);
     if (st != PANO_OK) return st;
@@ -2010,6 +2026,56 @@ pano_status pano_debug_get_canvas(pano_ctx* c, int level, int16_t* h_dst, int* w
         for (size_t k = 0; k < tmp.size(); k++) h_dst[k * 3 + pl] = tmp[k];
     }
     return PANO_OK;
+}
+
+// ---- entry points that allocate on the host: nothing may unwind through the C boundary ("no exceptions across
+// the ABI") - std::bad_alloc and friends become a status
+pano_status pano_create(const pano_config* cfg, pano_ctx** out) {
+    return guarded(nullptr, [&]() { return create_impl(cfg, out); });
+}
+
+pano_status pano_set_cameras_from_list(pano_ctx* c, const char* list) {
+    return guarded(c, [&]() { return set_cameras_from_list_impl(c, list); });
+}
+
+pano_status pano_load_camera_file(pano_ctx* c, const char* path) {
+    return guarded(c, [&]() { return load_camera_file_impl(c, path); });
+}
+
+pano_status pano_save_camera_file(pano_ctx* c, const char* path) {
+    return guarded(c, [&]() { return save_camera_file_impl(c, path); });
+}
+
+pano_status pano_prepare(pano_ctx* c) {
+    return guarded(c, [&]() { return prepare_impl(c); });
+}
+
+pano_status pano_set_frame_slots(pano_ctx* c, int n) {
+    return guarded(c, [&]() { return set_frame_slots_impl(c, n); });
+}
+
+pano_status pano_set_mask(pano_ctx* c, int i, const uint8_t* h_mask, int w, int h, size_t stride) {
+    return guarded(c, [&]() { return set_mask_impl(c, i, h_mask, w, h, stride); });
+}
+
+pano_status pano_build_masks_voronoi(pano_ctx* c) {
+    return guarded(c, [&]() { return build_masks_voronoi_impl(c); });
+}
+
+pano_status pano_build_masks_graphcut(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides) {
+    return guarded(c, [&]() { return build_masks_graphcut_impl(c, h_frames, strides); });
+}
+
+pano_status pano_estimate_gains(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides, int block_w, int block_h) {
+    return guarded(c, [&]() { return estimate_gains_impl(c, h_frames, strides, block_w, block_h); });
+}
+
+pano_status pano_compose_host(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides, uint8_t* h_out, size_t out_stride) {
+    return guarded(c, [&]() { return compose_host_impl(c, h_frames, strides, h_out, out_stride); });
+}
+
+pano_status pano_set_undistort(pano_ctx* c, int cam, const pano_undistort* u) {
+    return guarded(c, [&]() { return set_undistort_impl(c, cam, u); });
 }
 
 }  // extern "C"
