@@ -84,7 +84,7 @@ struct pano_ctx {
     uint32_t* k1_flags[kMaxCams] = {};  // per K1 workgroup: the table holds marked pixels there
     long long k1_blocks[kMaxCams] = {}, k1_flagged[kMaxCams] = {};
     bool use_lut = true;
-    uint8_t* owner[kMaxLevels] = {};
+    uint16_t* owner[kMaxLevels] = {};
     float* wsum[kMaxLevels] = {};
     int16_t* canvas[kMaxLevels] = {};
 
@@ -1122,7 +1122,7 @@ static pano_status prepare_impl(pano_ctx* c) {
         c->cv.fast[l] = fast ? 1 : 0;
         if (fast) {
             c->cv.opitch[l] = (int)align_up((size_t)(P.canvas.w >> l) / 4, 64);
-            HIP_TRY(c, hipMalloc((void**)&c->owner[l], (size_t)c->cv.opitch[l] * ((P.canvas.h >> l) / 2)));
+            HIP_TRY(c, hipMalloc((void**)&c->owner[l], (size_t)c->cv.opitch[l] * ((P.canvas.h >> l) / 2) * sizeof(uint16_t)));
             c->cv.owner[l] = c->owner[l];
         }
     }

@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     }
     const int pb = NPL == 3 ? 0 : (int)(bzi % 3);  // first plane of this lane
     const CanvasParams& C = CS.c[NPL == 3 ? bzi : bzi / 3];
-    const int cam_lo = C.cam_lo, cam_n = C.cam_n;
+    const int cam_lo = C.cam_lo;
     const int l = L0 ? 0 : (lvl & 0xff);
     const int cw = C.w0 >> l, ch = C.h0 >> l;
     // level 0 covers only the block-aligned hull of the cut rectangle
@@ -1323,7 +1323,9 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     // Away from the seams a block belongs to exactly one camera with weight 1.0f everywhere (or to none):
     // the static owner map says so in one byte, and the block needs no weights, no float math and no division:
     //   acc = lap, W = 1  =>  norm = lap - sign(lap)  (see below)
-    const unsigned code = C.owner[l][(unsigned)(__mul24(Y0 >> 1, C.opitch[l]) + (X0 >> 2))];
+    // one 16-bit entry per block: low byte = owner code, high byte = the cameras that carry weight anywhere on the block
+    const unsigned entry = C.owner[l][(unsigned)(__mul24(Y0 >> 1, C.opitch[l]) + (X0 >> 2))];
+    const unsigned code = entry & 0xffu;
     const unsigned ucode = __builtin_amdgcn_readfirstlane(code);
     if (ucode != 0xffu && __builtin_amdgcn_ballot_w64(code != ucode) == 0) {
         // the whole wave (a 256 x 2 strip) has one owner: its parameters are scalar, the code is straight-line
@@ -1417,31 +1419,9 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         return;
     }
     if (ABL == 5) return;  // diagnostic: only the single-owner fast path
-    // phase A: which cameras carry weight on this 4 x 2 block.  All weight loads are issued together.
-    // Level 0 keeps the mask bytes (2 dwords per camera); coarser levels only keep the verdict and
-    // re-read the (cached) f32 weights in phase B, which costs no extra round trip.
-    unsigned mk[kCams][2];
-    unsigned live = 0;
-#pragma unroll
-    for (int i = 0; i < kCams; i++) {
-        mk[i][0] = mk[i][1] = 0;
-        if (i < cam_n) {
-            const PyrCam& c = P.cam[cam_lo + i];
-            const int x = X0 - (c.tx >> l), y = Y0 - (c.ty >> l);
-            if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l)) {  // blocks never straddle a tile edge
-                if (L0) {
-                    mk[i][0] = *reinterpret_cast<const unsigned*>(c.mask0 + (size_t)y * c.pitch[0] + x);
-                    mk[i][1] = *reinterpret_cast<const unsigned*>(c.mask0 + (size_t)(y + 1) * c.pitch[0] + x);
-                } else {
-                    const float4 f0 = *reinterpret_cast<const float4*>(c.wgt[l] + (size_t)y * c.wpitch[l] + x);
-                    const float4 f1 = *reinterpret_cast<const float4*>(c.wgt[l] + (size_t)(y + 1) * c.wpitch[l] + x);
-                    mk[i][0] = (f0.x != 0.f) | (f0.y != 0.f) | (f0.z != 0.f) | (f0.w != 0.f) | (f1.x != 0.f) |
-                               (f1.y != 0.f) | (f1.z != 0.f) | (f1.w != 0.f);
-                }
-            }
-        }
-        if (mk[i][0] | mk[i][1]) live |= 1u << i;
-    }
+    // which cameras carry weight on this 4 x 2 block is static (it follows the masks): the high byte of the owner entry.
+    // A seam wave used to spend its first round trip loading every covering camera's weights only to find that out
+    const unsigned live = entry >> 8;
     // the coarser canvas level: early on the latency-bound small levels, late (fewer live registers) on level 0
     unsigned cp[3][3][2];
     if (!L0 && l < C.bands) {
@@ -1468,10 +1448,12 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         const int tw = c.w0 >> l, th = c.h0 >> l;
         float w[2][4];
         if (L0) {
+            const unsigned mk[2] = {*reinterpret_cast<const unsigned*>(c.mask0 + (unsigned)(__mul24(y, c.pitch[0]) + x)),
+                                    *reinterpret_cast<const unsigned*>(c.mask0 + (unsigned)(__mul24(y + 1, c.pitch[0]) + x))};
 #pragma unroll
             for (int r = 0; r < 2; r++)
 #pragma unroll
-                for (int k = 0; k < 4; k++) w[r][k] = (float)((mk[i][r] >> (8 * k)) & 0xffu) * (float)(1. / 255.);
+                for (int k = 0; k < 4; k++) w[r][k] = (float)((mk[r] >> (8 * k)) & 0xffu) * (float)(1. / 255.);
         } else {
 #pragma unroll
             for (int r = 0; r < 2; r++) {
@@ -1568,11 +1550,12 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
 }
 
 // owner map of a vector level: one byte per 4 x 2 block (see CanvasParams::owner)
-__global__ __launch_bounds__(256) void build_owner_kernel(PyrParams P, CanvasParams C, int l, uint8_t* owner) {
+__global__ __launch_bounds__(256) void build_owner_kernel(PyrParams P, CanvasParams C, int l, uint16_t* owner) {
     const int cw = C.w0 >> l, ch = C.h0 >> l;
     const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
     if (bx * 4 >= cw || by * 2 >= ch) return;
     int holders = 0, unit_cam = -1;
+    unsigned mask = 0;
     bool all_unit = true;
     for (int i = 0; i < P.ncam; i++) {
         const PyrCam& c = P.cam[i];
@@ -1588,15 +1571,16 @@ __global__ __launch_bounds__(256) void build_owner_kernel(PyrParams P, CanvasPar
         if (any) {
             holders++;
             unit_cam = i;
+            mask |= 1u << i;
             all_unit &= unit;
         }
     }
     uint8_t code = 0xff;
     if (holders == 0) code = 0xfe;
     else if (holders == 1 && all_unit) code = (uint8_t)unit_cam;
-    owner[(size_t)by * C.opitch[l] + bx] = code;
+    owner[(size_t)by * C.opitch[l] + bx] = (uint16_t)(code | (mask << 8));
 }
-void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint8_t* owner, hipStream_t s) {
+void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint16_t* owner, hipStream_t s) {
     const int bw = (c.w0 >> l) / 4, bh = (c.h0 >> l) / 2;
     dim3 block(64, 4, 1), grid((bw + 63) / 64, (bh + 3) / 4, 1);
     hipLaunchKernelGGL(build_owner_kernel, grid, block, 0, s, p, c, l, owner);

@@ -88,8 +88,9 @@ struct CanvasParams {
     int cpitch[kLevels];       // int16 elements per row
     int cplane[kLevels];       // int16 elements per plane
     int fast[kLevels];         // 1: every tile origin / size of this level is 4x2 aligned -> vector kernel
-    const uint8_t* owner[kLevels];  // vector levels: per 4x2 block, the single unit-weight camera (0..7), 0xFE none, 0xFF mixed
-    int opitch[kLevels];       // owner bytes per block row
+    const uint16_t* owner[kLevels]; // vector levels, per 4x2 block: low byte = the single unit-weight camera (0..7), 0xFE none,
+                               // 0xFF mixed; high byte = bit i set when camera i carries weight anywhere on the block
+    int opitch[kLevels];       // owner entries per block row
     int small_base;            // >0: levels small_base..bands run as one normalise launch + one LDS collapse launch
     int cam_lo, cam_n;         // this canvas blends cameras [cam_lo, cam_lo + cam_n) of the PyrParams it is launched with
     int w0, h0;                // padded canvas size
@@ -130,7 +131,7 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
 // the small levels small_base..bands in two launches
 void launch_blend_small(const PyrParams& p, const CanvasSet& cs, hipStream_t s);
 // owner map of a vector level (run when masks change)
-void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint8_t* owner, hipStream_t s);
+void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint16_t* owner, hipStream_t s);
 // Blender::NO path
 void launch_no_blend(const PyrParams& p, const CanvasSet& cs, hipStream_t s);
 
