@@ -191,7 +191,10 @@ pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b,
  *   pano_set_frame_slots(ctx, n)    after pano_prepare; 1 <= n <= PANO_MAX_FRAME_SLOTS; synchronises the device
  *   pano_select_frame_slot(ctx, k)  the slot the following feed / blend / compose calls work in (a host-side switch)
  * The caller keeps one stream per slot and does not reuse a slot before its previous frame is done (stream order
- * guarantees that when slot k always runs on stream k).  pano_compose_host and the pano_stream_* calls use slot 0. */
+ * guarantees that when slot k always runs on stream k).  pano_compose_host and the pano_stream_* calls use slot 0.
+ * Changing what the slots share - masks (pano_set_mask, pano_build_masks_*: the updateMask cadence of
+ * ocvstitcher.hpp:1152-1159), gain maps, the cut - needs no synchronisation by the caller: the library lets the frames
+ * in flight finish under the old state (a device-wide wait, once per change) before it rewrites it. */
 #define PANO_MAX_FRAME_SLOTS 4
 pano_status pano_set_frame_slots(pano_ctx* ctx, int n);
 pano_status pano_select_frame_slot(pano_ctx* ctx, int k);
