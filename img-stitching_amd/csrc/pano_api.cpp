@@ -576,9 +576,12 @@ bool parse_floats(const std::string& s, std::vector<float>& out) {
     return true;
 }
 
-// INTER_LINEAR_EXACT coefficient tables (resize.cpp interpolationLinear<uchar>::getCoeffs), IEEE double
-void linearExactCoeffs(int ssize, int dsize, std::vector<int>& ofs, std::vector<int>& c1, int& mn, int& mx) {
-    double scale = 1.0 / ((double)dsize / ssize);
+// INTER_LINEAR_EXACT coefficient tables (resize.cpp interpolationLinear<uchar>::getCoeffs), IEEE double.
+// inv_scale is what cv::resize hands down: dsize/ssize when the caller gave a dsize (pass 0), but the caller's fx when
+// dsize was empty - resize(src, dst, Size(), fx, fy) samples on a 1/fx grid although dsize = cvRound(ssize*fx)
+void linearExactCoeffs(int ssize, int dsize, double inv_scale, std::vector<int>& ofs, std::vector<int>& c1, int& mn, int& mx) {
+    if (!(inv_scale > 0)) inv_scale = (double)dsize / ssize;
+    double scale = 1.0 / inv_scale;
     ofs.assign(dsize, 0);
     c1.assign(dsize, 0);
     mn = 0;
@@ -685,8 +688,8 @@ pano_status seam_scale_warps(pano_ctx* c, const uint8_t* const* h_frames, const 
     int *dxo = nullptr, *dxc = nullptr, *dyo = nullptr, *dyc = nullptr;
     const bool shrink = h_frames && (ssw != sw || ssh != sh);
     if (shrink) {
-        linearExactCoeffs(sw, ssw, xo, xc, mnx, mxx);
-        linearExactCoeffs(sh, ssh, yo, yc, mny, mxy);
+        linearExactCoeffs(sw, ssw, swa, xo, xc, mnx, mxx);  // Size(), seam_work_aspect, seam_work_aspect
+        linearExactCoeffs(sh, ssh, swa, yo, yc, mny, mxy);
         if (!tmp.put(&dxo, xo.data(), xo.size() * sizeof(int)) || !tmp.put(&dxc, xc.data(), xc.size() * sizeof(int)) ||
             !tmp.put(&dyo, yo.data(), yo.size() * sizeof(int)) || !tmp.put(&dyc, yc.data(), yc.size() * sizeof(int)))
             return oom();
@@ -747,8 +750,8 @@ pano_status finish_seam_masks(pano_ctx* c, const SeamWarps& sm, Scratch& tmp, hi
         launch_dilate3x3(sm.mask[i], dil, q.w, q.h, s);
         std::vector<int> xo, xc, yo, yc;
         int mnx, mxx, mny, mxy;
-        linearExactCoeffs(q.w, r.w, xo, xc, mnx, mxx);
-        linearExactCoeffs(q.h, r.h, yo, yc, mny, mxy);
+        linearExactCoeffs(q.w, r.w, 0, xo, xc, mnx, mxx);  // explicit dsize (:1099, :1256)
+        linearExactCoeffs(q.h, r.h, 0, yo, yc, mny, mxy);
         int *dxo = nullptr, *dxc = nullptr, *dyo = nullptr, *dyc = nullptr;
         if (!tmp.put(&dxo, xo.data(), xo.size() * sizeof(int)) || !tmp.put(&dxc, xc.data(), xc.size() * sizeof(int)) ||
             !tmp.put(&dyo, yo.data(), yo.size() * sizeof(int)) || !tmp.put(&dyc, yc.data(), yc.size() * sizeof(int)))

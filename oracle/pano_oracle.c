@@ -452,8 +452,12 @@ void po_dilate3x3_8u(const uint8_t* src, int w, int h, uint8_t* dst) {
  * horizontal pass keeps 8.8, vertical pass 16.16, final (v + 32768) >> 16.
  * reference ocvstitcher.hpp:1099,1256 (mask upscale), :988 (seam-size frames) */
 typedef struct { int ofs; int c0, c1; } lin_coef;
-static void linear_exact_coeffs(int ssize, int dsize, lin_coef* co, int* pmin, int* pmax) {
-    double inv_scale = (double)dsize / ssize;
+/* inv_scale: what cv::resize hands to resize_bitExact.  With an explicit dsize cv::resize recomputes it as
+ * dsize/ssize; with an EMPTY dsize (resize(src, dst, Size(), fx, fy)) it stays fx, while dsize = cvRound(ssize*fx)
+ * - so the sampling grid is 1/fx, NOT ssize/dsize (found and fixed in round 2: ocvstitcher.hpp:988,1230 pass
+ * Size(), seam_work_aspect).  inv_scale <= 0 here means "explicit dsize". */
+static void linear_exact_coeffs(int ssize, int dsize, double inv_scale, lin_coef* co, int* pmin, int* pmax) {
+    if (!(inv_scale > 0)) inv_scale = (double)dsize / ssize;
     double scale = 1.0 / inv_scale;
     int minofst = 0, maxofst = dsize;
     for (int val = 0; val < dsize; val++) {
@@ -477,11 +481,18 @@ static void linear_exact_coeffs(int ssize, int dsize, lin_coef* co, int* pmin, i
     *pmax = maxofst;
 }
 void po_resize_linear_exact_8u(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh) {
+    po_resize_linear_exact_8u_fxy(src, sw, sh, cn, dst, dw, dh, 0.0, 0.0);
+}
+/* resize(src, dst, Size(), fx, fy, INTER_LINEAR_EXACT): dw, dh must be cvRound(sw*fx), cvRound(sh*fy) (po_resize_dsize);
+ * fx, fy <= 0: resize(src, dst, Size(dw, dh), 0, 0, INTER_LINEAR_EXACT) */
+int po_resize_dsize(int ssize, double f) { return cv_round_d(ssize * f); }
+void po_resize_linear_exact_8u_fxy(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh, double fx,
+                                   double fy) {
     lin_coef* cx = (lin_coef*)malloc(sizeof(lin_coef) * dw);
     lin_coef* cy = (lin_coef*)malloc(sizeof(lin_coef) * dh);
     int minx, maxx, miny, maxy;
-    linear_exact_coeffs(sw, dw, cx, &minx, &maxx);
-    linear_exact_coeffs(sh, dh, cy, &miny, &maxy);
+    linear_exact_coeffs(sw, dw, fx, cx, &minx, &maxx);
+    linear_exact_coeffs(sh, dh, fy, cy, &miny, &maxy);
     if (maxx < minx) maxx = minx;
     if (maxy < miny) maxy = miny;
     /* horizontal pass of every source row into 8.8 */
@@ -1445,7 +1456,7 @@ int po_estimate_gains(int n, int kind, int sw, int sh, const uint8_t* const* fra
         corners[2 * i] = r[0]; corners[2 * i + 1] = r[1];
         seam_sizes[2 * i] = r[2]; seam_sizes[2 * i + 1] = r[3];
         if (ssw == sw && ssh == sh) memcpy(small, frames[i], (size_t)sw * sh * 3);
-        else po_resize_linear_exact_8u(frames[i], sw, sh, 3, small, ssw, ssh);
+        else po_resize_linear_exact_8u_fxy(frames[i], sw, sh, 3, small, ssw, ssh, swa, swa);
         iw[i] = (uint8_t*)malloc((size_t)r[2] * r[3] * 3);
         mw[i] = (uint8_t*)malloc((size_t)r[2] * r[3]);
         po_warp_8u(&p, small, ssw, ssh, (size_t)ssw * 3, 3, PO_INTER_LINEAR, PO_BORDER_REFLECT, iw[i], c);
@@ -1486,7 +1497,7 @@ void po_prepare_masks_graphcut(int n, int kind, int sw, int sh, const uint8_t* c
         corners[2 * i] = r[0]; corners[2 * i + 1] = r[1];
         sizes[2 * i] = r[2]; sizes[2 * i + 1] = r[3];
         if (ssw == sw && ssh == sh) memcpy(small, frames[i], (size_t)sw * sh * 3);
-        else po_resize_linear_exact_8u(frames[i], sw, sh, 3, small, ssw, ssh);
+        else po_resize_linear_exact_8u_fxy(frames[i], sw, sh, 3, small, ssw, ssh, swa, swa);
         iw[i] = (uint8_t*)malloc((size_t)r[2] * r[3] * 3);
         mw[i] = (uint8_t*)malloc((size_t)r[2] * r[3]);
         po_warp_8u(&p, small, ssw, ssh, (size_t)ssw * 3, 3, PO_INTER_LINEAR, PO_BORDER_REFLECT, iw[i], c);

@@ -69,7 +69,13 @@ void po_copy_make_border_16s(const int16_t* src, int w, int h, int cn, int top, 
                              int border, int16_t* dst);
 void po_copy_make_border_32f(const float* src, int w, int h, int top, int bottom, int left, int right, float* dst);
 void po_dilate3x3_8u(const uint8_t* src, int w, int h, uint8_t* dst);
+/* resize(src, dst, Size(dw, dh), 0, 0, INTER_LINEAR_EXACT): sampling grid from dsize/ssize (ocvstitcher.hpp:1099,1256) */
 void po_resize_linear_exact_8u(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh);
+/* resize(src, dst, Size(), fx, fy, INTER_LINEAR_EXACT): dsize = cvRound(ssize*f) but the sampling grid is 1/f
+ * (cv::resize keeps inv_scale = fx when dsize is empty; ocvstitcher.hpp:988,1230).  fx, fy <= 0: same as above */
+int po_resize_dsize(int ssize, double f);
+void po_resize_linear_exact_8u_fxy(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh, double fx,
+                                   double fy);
 void po_distance_l1(const uint8_t* src, int w, int h, float* dst);
 
 /* ---- A5: band rule of the callers (ocvstitcher.hpp:1188-1195).  Returns -1 for Blender::NO */

@@ -186,6 +186,18 @@ def resize_linear_exact(a, dw, dh):
     return d
 
 
+def resize_linear_exact_fxy(a, fx, fy):
+    """resize(a, Size(), fx, fy, INTER_LINEAR_EXACT): dsize = cvRound(ssize*f), sampling grid 1/f"""
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    h, w = a.shape[:2]; cn = 1 if a.ndim == 2 else a.shape[2]
+    L = lib()
+    L.po_resize_dsize.restype = C.c_int
+    dw = L.po_resize_dsize(int(w), C.c_double(fx)); dh = L.po_resize_dsize(int(h), C.c_double(fy))
+    d = np.empty((dh, dw) + (() if a.ndim == 2 else (cn,)), np.uint8)
+    L.po_resize_linear_exact_8u_fxy(_p(a), w, h, cn, _p(d), int(dw), int(dh), C.c_double(fx), C.c_double(fy))
+    return d
+
+
 def resize_linear_32f(a, dw, dh):
     a = np.ascontiguousarray(a, dtype=np.float32)
     d = np.empty((dh, dw), np.float32)

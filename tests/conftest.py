@@ -44,6 +44,27 @@ def c1():
 
 
 @pytest.fixture(scope="session")
+def c1b():
+    """the other half of the bundled set: 4 x 480x270 frames of 2222/5..8.png + last record of 2222/cameraparaout_2.txt"""
+    d = json.load(open(os.path.join(GOLDEN, "c1b_cams.json")))
+    frames = [load_png_bgr(os.path.join(GOLDEN, f"c1b_cam{i}.png")) for i in range(4)]
+    return {"frames": frames, "K": [d["K"]] * 4, "R": d["R"], "scale": d["scale"], "w": 480, "h": 270, "n": 4}
+
+
+@pytest.fixture(scope="session")
+def rig_r_real(rig_r):
+    """rig R with its REAL frames 2222/4cam/0..3.png (960x540): replay.cpp:211-215 gives 0,1 to the "up" stitcher and 2,3
+    to the "down" one.  Returns the two stitchers as dicts like c1 (+ "cut")"""
+    out = []
+    for s, st in enumerate(rig_r["stitchers"]):
+        v = st["cams"]
+        out.append({"n": 2, "w": 960, "h": 540, "scale": v[-1], "K": [v[0:9], v[18:27]], "R": [v[9:18], v[27:36]],
+                    "cut": st["cut"], "cams": v,
+                    "frames": [load_png_bgr(os.path.join(GOLDEN, f"r_cam{2 * s + i}.png")) for i in range(2)]})
+    return out
+
+
+@pytest.fixture(scope="session")
 def rig_r():
     """reference rig R: cfg/cameras.yaml 4cam-black/960, stitcher 0 and 1 (2 cams each) + cut"""
     return json.load(open(os.path.join(GOLDEN, "r_cams.json")))

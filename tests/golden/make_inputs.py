@@ -13,6 +13,11 @@ executed on the GPU box; the outputs are committed:
                      -> floats.
   r_cams.json        cfg/cameras.yaml `4cam-black / inputsz 960` structure
                      (2 stitchers x 2 cams, 18*N+1 floats + cut) - data only.
+  c1b_cam{0..3}.png  the other half of the bundled set: 2222/{5..8}.png, same 4x4 box
+  c1b_cams.json      last record of 2222/cameraparaout_2.txt (f=535.415, scale 591.584)
+  r_cam{0..3}.png    /root/reference/2222/4cam/{0..3}.png (960x540, pixels unchanged,
+                     re-encoded): the real rig-R frames; replay.cpp:211-215 gives 0,1 to the
+                     "up" stitcher and 2,3 to the "down" one.
 
 These are data (inputs), not reference source.
 """
@@ -35,7 +40,7 @@ def box4(path):
     return ((a + 8) // 16).astype(np.uint8)
 
 
-def last_record_old_format(path):
+def last_record_old_format(path, source="2222/cameraparaout_1.txt (last record)"):
     lines = [l.strip() for l in open(path) if l.strip()]
     idx = max(i for i, l in enumerate(lines) if ":" in l)
     rec = lines[idx:]
@@ -49,7 +54,7 @@ def last_record_old_format(path):
         Rs.append(r)
     scale = float(rec[6])
     return {"timestamp": stamp, "K": K, "R": Rs, "scale": scale,
-            "width": 480, "height": 270, "source": "2222/cameraparaout_1.txt (last record)"}
+            "width": 480, "height": 270, "source": source}
 
 
 def structure_4cam_black_960(path):
@@ -78,6 +83,15 @@ def main():
               open(f"{OUT}/c1_cams.json", "w"), indent=1)
     json.dump(structure_4cam_black_960(f"{REF}/cfg/cameras.yaml"),
               open(f"{OUT}/r_cams.json", "w"), indent=1)
+    for i in range(4):
+        im = box4(f"{REF}/2222/{i + 5}.png")
+        Image.fromarray(im, "RGB").save(f"{OUT}/c1b_cam{i}.png", optimize=True)
+    json.dump(last_record_old_format(f"{REF}/2222/cameraparaout_2.txt", "2222/cameraparaout_2.txt (last record)"),
+              open(f"{OUT}/c1b_cams.json", "w"), indent=1)
+    for i in range(4):
+        im = Image.open(f"{REF}/2222/4cam/{i}.png").convert("RGB")
+        assert im.size == (960, 540)
+        im.save(f"{OUT}/r_cam{i}.png", optimize=True)
 
 
 if __name__ == "__main__":

@@ -911,3 +911,114 @@ def test_mask_refresh_with_frames_in_flight(pano, po, torch):
     for k in range(len(frames)):
         want, _ = po.compose(frames[k], d["K"], d["R"], d["scale"], vor if k < 5 else gc_masks, 4)
         assert np.array_equal(outs[k].cpu().numpy(), want), k
+
+
+def test_bench_shape_bit_exact(pano, po, torch):
+    """the exact launch shape bench.py times (config 2): pano_compose_pair over 2 x 4 x 1080p, 5 bands, Voronoi seams,
+    pano_set_frame_slots(4) with step k in slot k % 4 on stream k % 4 - three distinct frame sets dealt over 12 steps in
+    flight, EVERY panorama of every step against the oracle"""
+    g = c2_group()
+    W, H, NG, NC, F = g["w"], g["h"], 2, 4, 4
+    ctxs = []
+    for grp in range(NG):
+        ctx = make_ctx(pano, g, 0, num_bands=5)
+        ctx.build_masks_voronoi()
+        ctx.set_frame_slots(F)
+        ctxs.append(ctx)
+    ow, oh = ctxs[0].output_size()
+    assert (ow, oh) == (3893, 991)
+    masks = [ctxs[0].get_mask(i) for i in range(NC)]
+    sets = [[[synth_frame(W, H, 900 + 100 * s + grp * NC + i) for i in range(NC)] for grp in range(NG)] for s in range(3)]
+    sets_d = [[[torch.from_numpy(f).cuda() for f in fr] for fr in st] for st in sets]
+    po.set_threads(16)
+    wants = [[po.compose(st[grp], g["K"], g["R"], g["scale"], masks, 5)[0] for grp in range(NG)] for st in sets]
+    po.set_threads(1)
+    steps = 12
+    streams = [torch.cuda.Stream() for _ in range(F)]
+    outs = [[torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in range(NG)] for _ in range(steps)]
+    strides = [W * 3] * NC
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for k in range(steps):
+            f = k % F
+            fr = sets_d[k % 3]
+            ctxs[0].select_frame_slot(f)
+            ctxs[1].select_frame_slot(f)
+            ctxs[0].compose_pair(ctxs[1], [t.data_ptr() for t in fr[0]], strides, outs[k][0].data_ptr(), ow * 3,
+                                 [t.data_ptr() for t in fr[1]], strides, outs[k][1].data_ptr(), ow * 3, streams[f].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(steps):
+            for grp in range(NG):
+                got = outs[k][grp].cpu().numpy()
+                assert np.array_equal(got, wants[k % 3][grp]), (rep, k, grp, int((got != wants[k % 3][grp]).sum()))
+                outs[k][grp].zero_()
+
+
+def test_bundled_set_second_half_c1b(pano, po, c1b):
+    """the other half of the bundled set (2222/5..8.png under the last record of 2222/cameraparaout_2.txt): every stage
+    against the oracle and against the committed golden vectors (tests/golden/c1b_golden.json)"""
+    import hashlib
+    import json
+    from conftest import GOLDEN
+    g = json.load(open(os.path.join(GOLDEN, "c1b_golden.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    d = c1b
+    ctx = make_ctx(pano, d, 0, num_bands=4)
+    assert [list(ctx.roi(i)) for i in range(4)] == g["rois"]
+    ctx.build_masks_voronoi()
+    vor = oracle_masks(po, d)
+    for i in range(4):
+        assert np.array_equal(ctx.get_mask(i), vor[i]) and sha(vor[i]) == g["mask_sha256"][i]
+    got = ctx.compose_host(d["frames"])
+    assert [got.shape[1], got.shape[0]] == g["pano_size"]
+    assert np.array_equal(got, po.compose(d["frames"], d["K"], d["R"], d["scale"], vor, 4)[0])
+    assert sha(got) == g["pano_sha256"]["4"]
+    # the reference's own seam finder and compensator on these frames
+    ctx.build_masks_graphcut(d["frames"])
+    gc = po.prepare_masks_graphcut(d["frames"], d["K"], d["R"], d["scale"])
+    for i in range(4):
+        assert np.array_equal(ctx.get_mask(i), gc[i])
+    assert [sha(ctx.get_mask(i)) for i in range(4)] == g["graphcut_mask_sha256"]
+    assert sha(ctx.compose_host(d["frames"])) == g["graphcut_pano_b4_sha256"]
+    ctx.build_masks_voronoi()
+    gains = ctx.estimate_gains(d["frames"])
+    want, _ = po.estimate_gains(d["frames"], d["K"], d["R"], d["scale"])
+    assert all(np.array_equal(a, b) for a, b in zip(gains, want))
+    assert [sha(x) for x in gains] == g["gain_map_sha256"]
+    assert sha(ctx.compose_host(d["frames"])) == g["gain_pano_b4_sha256"]
+
+
+def test_rig_r_on_its_real_frames(pano, po, torch, rig_r_real):
+    """rig R (cfg/cameras.yaml 4cam-black/960) on the REAL frames 2222/4cam/0..3.png, driven like replay.cpp:206-290: two
+    2-camera stitchers from the 18N+1 lists, graph-cut masks from the frames (calibration), bands from strength 1, yaml
+    cut, process, then master.cpp:321-326's resize + vconcat + divider - against the oracle and the committed vectors"""
+    import hashlib
+    import json
+    from conftest import GOLDEN, load_png_bgr
+    g = json.load(open(os.path.join(GOLDEN, "r_golden.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    halves, halves_d = [], []
+    for st, gs in zip(rig_r_real, g["stitchers"]):
+        ctx = pano.Context(2, 960, 540, scale=1.0, num_bands=pano.BANDS_FROM_STRENGTH, blend_strength=1.0, cut=st["cut"], device=0)
+        ctx.set_cameras_from_list(",".join(repr(float(x)) for x in st["cams"]))   # the yaml's `cams: [...]` text
+        ctx.prepare()
+        assert [list(ctx.roi(i)) for i in range(2)] == gs["rois"] and ctx.num_bands() == gs["bands"] == 3
+        ctx.build_masks_graphcut(st["frames"])
+        gc = po.prepare_masks_graphcut(st["frames"], st["K"], st["R"], st["scale"])
+        for i in range(2):
+            assert np.array_equal(ctx.get_mask(i), gc[i])
+        assert [sha(ctx.get_mask(i)) for i in range(2)] == gs["graphcut_mask_sha256"]
+        got = ctx.compose_host(st["frames"])
+        want, _ = po.compose(st["frames"], st["K"], st["R"], st["scale"], gc, 3, cut=tuple(st["cut"]))
+        assert [got.shape[1], got.shape[0]] == gs["pano_cut_size"]
+        assert np.array_equal(got, want) and sha(got) == gs["pano_cut_sha256"]
+        halves.append(got)
+        halves_d.append(torch.from_numpy(got).cuda())
+    (uh, uw), (dh, dw) = halves[0].shape[:2], halves[1].shape[:2]
+    out = torch.zeros((2 * dh, dw, 3), dtype=torch.uint8, device="cuda")
+    ctx.stack_master(halves_d[0].data_ptr(), uw, uh, uw * 3, halves_d[1].data_ptr(), dw, dh, dw * 3, out.data_ptr(), dw * 3,
+                     torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    stacked = out.cpu().numpy()
+    assert np.array_equal(stacked, po.stack_master(halves[0], halves[1]))
+    assert sha(stacked) == g["stack_master_sha256"] and np.array_equal(stacked, load_png_bgr(os.path.join(GOLDEN, "r_stacked.png")))

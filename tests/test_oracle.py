@@ -159,6 +159,14 @@ def test_mask_primitives(po):
     assert np.array_equal(po.resize_linear_exact(a, 2, 1), a)
     up = po.resize_linear_exact(a, 4, 1)
     assert up.tolist() == [[0, 64, 191, 255]]
+    # resize(src, dst, Size(), fx, fy, INTER_LINEAR_EXACT) (ocvstitcher.hpp:988,1230): dsize = cvRound(10*0.37) = 4 but the
+    # sampling grid is 1/0.37 = 2.7027, NOT 10/4 = 2.5.  Hand-computed: fval = 2.7027*(v+.5)-.5 = .8514, 3.5541, 6.2568,
+    # 8.9595 -> taps (0,1) (3,4) (6,7) (8,9), c1 = round(frac*256) = 218, 142, 66, 246; columns 25*x, all rows equal:
+    # (25*218+128)>>8 = 21, (75*114+100*142+128)>>8 = 89, (150*190+175*66+128)>>8 = 156, (200*10+225*246+128)>>8 = 224
+    ramp = np.tile((np.arange(10) * 25).astype(np.uint8), (10, 1))
+    got = po.resize_linear_exact_fxy(ramp, 0.37, 0.37)
+    assert got.shape == (4, 4) and all(row == [21, 89, 156, 224] for row in got.tolist())
+    assert po.resize_linear_exact(ramp, 4, 4)[0].tolist() == [19, 81, 144, 206]   # explicit dsize: grid 10/4 (.75, 3.25, ..)
     # L1 distance: city-block to the nearest zero
     z = np.full((5, 7), 255, np.uint8); z[2, 1] = 0
     dist = po.distance_l1(z)
@@ -221,6 +229,47 @@ def test_oracle_reproduces_committed_golden(po, c1):
     assert sha(po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], gc, 4)[0]) == g["graphcut_pano_b4_sha256"]
     gains, _ = po.estimate_gains(c1["frames"], c1["K"], c1["R"], c1["scale"])
     assert [list(x.shape) for x in gains] == g["gain_map_shape"] and [sha(x) for x in gains] == g["gain_map_sha256"]
+
+
+def test_oracle_reproduces_committed_golden_c1b_and_rig_r(po, c1b, rig_r_real):
+    """the rest of the bundled set: 2222/5..8.png under cameraparaout_2.txt, and rig R on its real 2222/4cam frames the way
+    replay.cpp drives it (two 2-camera stitchers, graph-cut masks, bands from strength 1, yaml cut, master.cpp stacking)"""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN, load_png_bgr
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    g = json.load(open(os.path.join(GOLDEN, "c1b_golden.json")))
+    d = c1b
+    masks = po.prepare_masks_voronoi(0, 480, 270, d["K"], d["R"], d["scale"])
+    for i in range(4):
+        p = po.projector(0, d["scale"], d["K"][i], d["R"][i])
+        assert list(po.warp_roi(p, 480, 270)) == g["rois"][i]
+        assert sha(po.warp(p, d["frames"][i])[1]) == g["warp_sha256"][i]
+        assert sha(masks[i]) == g["mask_sha256"][i]
+    pano, _ = po.compose(d["frames"], d["K"], d["R"], d["scale"], masks, 4)
+    assert [pano.shape[1], pano.shape[0]] == g["pano_size"] and sha(pano) == g["pano_sha256"]["4"]
+    gc = po.prepare_masks_graphcut(d["frames"], d["K"], d["R"], d["scale"])
+    assert [sha(m) for m in gc] == g["graphcut_mask_sha256"]
+    gains, _ = po.estimate_gains(d["frames"], d["K"], d["R"], d["scale"])
+    assert [sha(x) for x in gains] == g["gain_map_sha256"]
+    g = json.load(open(os.path.join(GOLDEN, "r_golden.json")))
+    halves = []
+    for st, gs in zip(rig_r_real, g["stitchers"]):
+        rois = [list(po.warp_roi(po.projector(0, st["scale"], st["K"][i], st["R"][i]), 960, 540)) for i in range(2)]
+        assert rois == gs["rois"]
+        full = po.result_roi([q[:2] for q in rois], [q[2:] for q in rois])
+        assert list(full) == gs["pano_roi"] and po.bands_from_strength(full[2], full[3], 1.0) == gs["bands"] == 3
+        gc = po.prepare_masks_graphcut(st["frames"], st["K"], st["R"], st["scale"])
+        assert [sha(m) for m in gc] == gs["graphcut_mask_sha256"]
+        pano, _ = po.compose(st["frames"], st["K"], st["R"], st["scale"], gc, 3, cut=tuple(st["cut"]))
+        assert sha(pano) == gs["pano_cut_sha256"]
+        halves.append(pano)
+    # SURVEY appendix C pins of rig R, stitcher 0
+    assert g["stitchers"][0]["rois"] == [[-721, 525, 773, 495], [-59, 497, 790, 496]] and g["stitchers"][0]["pano_roi"][2:] == [1452, 523]
+    stacked = po.stack_master(halves[0], halves[1])
+    assert sha(stacked) == g["stack_master_sha256"]
+    assert np.array_equal(stacked, load_png_bgr(os.path.join(GOLDEN, "r_stacked.png")))
 
 
 def test_caller_side_assembly_known_answers(po):
