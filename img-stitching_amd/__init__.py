@@ -84,7 +84,7 @@ MAX_FRAME_SLOTS = 4  # PANO_MAX_FRAME_SLOTS
 
 EXPORTS = [
     "pano_create", "pano_destroy", "pano_last_error", "pano_version", "pano_set_camera",
-    "pano_set_cameras_from_list", "pano_load_camera_file", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
+    "pano_set_cameras_from_list", "pano_load_camera_file", "pano_get_camera", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
     "pano_build_masks_voronoi", "pano_build_masks_graphcut", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
     "pano_compose_host", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_stream_input", "pano_stream_output",
@@ -141,6 +141,12 @@ class Context:
 
     def load_camera_file(self, path):
         self._ck(self.lib.pano_load_camera_file(self.h, os.fsencode(path)))
+
+    def get_camera(self, i):
+        """(K[9], R[9], warped_image_scale) as float32 values"""
+        K = (C.c_float * 9)(); R = (C.c_float * 9)(); sc = C.c_float()
+        self._ck(self.lib.pano_get_camera(self.h, i, K, R, C.byref(sc)))
+        return list(K), list(R), sc.value
 
     def save_camera_file(self, path):
         self._ck(self.lib.pano_save_camera_file(self.h, os.fsencode(path)))

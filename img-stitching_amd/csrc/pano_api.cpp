@@ -2044,6 +2044,14 @@ pano_status pano_set_cameras_from_list(pano_ctx* c, const char* list) {
 pano_status pano_load_camera_file(pano_ctx* c, const char* path) {
     return guarded(c, [&]() { return load_camera_file_impl(c, path); });
 }
+pano_status pano_get_camera(const pano_ctx* c, int i, float K[9], float R[9], float* scale) {
+    if (!c || i < 0 || i >= c->cfg.num_images) return PANO_EINVAL;
+    if (!c->have_cam[i]) return PANO_ESTATE;
+    if (K) std::memcpy(K, c->K[i], 9 * sizeof(float));
+    if (R) std::memcpy(R, c->R[i], 9 * sizeof(float));
+    if (scale) *scale = c->scale;
+    return PANO_OK;
+}
 
 pano_status pano_save_camera_file(pano_ctx* c, const char* path) {
     return guarded(c, [&]() { return save_camera_file_impl(c, path); });

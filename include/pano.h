@@ -79,6 +79,10 @@ pano_status pano_set_cameras_from_list(pano_ctx* ctx, const char* comma_separate
  * old 7-line shared-K format of 2222/cameraparaout_*.txt also accepted) */
 pano_status pano_load_camera_file(pano_ctx* ctx, const char* path);
 
+/* read back camK[i] / cameraR[i] / warped_image_scale - public members of ocvStitcher (ocvstitcher.hpp:1275-1299) that
+ * callers and the loaders' tests look at; any of K, R, scale may be NULL */
+pano_status pano_get_camera(const pano_ctx* ctx, int i, float K[9], float R[9], float* warped_image_scale);
+
 /* append the current K / R / scale as a new record to a cameraparaout_<id>.txt log, in the format
  * saveCameraParams writes (ocvstitcher.hpp:522-562): "YYYY-MM-DD-HH-MM-SS:" / N lines of 18 values with trailing
  * commas / scale; values in ostream default formatting (6 significant digits) */
