@@ -87,7 +87,7 @@ EXPORTS = [
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_get_camera", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
     "pano_build_masks_voronoi", "pano_build_masks_graphcut", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
-    "pano_compose_host", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_stream_input", "pano_stream_output",
+    "pano_compose_host", "pano_host_alloc", "pano_host_free", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_stream_input", "pano_stream_output",
     "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
     "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_get_live_rect", "pano_get_live_gap", "pano_get_warp_table_stats", "pano_debug_get_level", "pano_debug_get_weights",
     "pano_debug_get_canvas_weights", "pano_debug_get_canvas",
@@ -96,6 +96,29 @@ EXPORTS = [
 
 def _vp(x):
     return C.c_void_p(int(x))
+
+
+class HostBuffer:
+    """page-locked host memory (pano_host_alloc) viewed as a numpy array; pano_compose_host DMAs such buffers directly"""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self.lib = load_library()
+        self.lib.pano_host_alloc.restype = C.c_void_p
+        self.lib.pano_host_alloc.argtypes = [C.c_size_t]
+        self.lib.pano_host_free.argtypes = [C.c_void_p]
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = self.lib.pano_host_alloc(n)
+        if not self.ptr:
+            raise PanoError(-3, "pano_host_alloc failed")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * n).from_address(self.ptr)).view(dtype).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.lib.pano_host_free(self.ptr)
+            self.ptr = None
+
+    __del__ = close
 
 
 class Context:
@@ -236,14 +259,20 @@ class Context:
         return g
 
     # -- per-frame, host buffers (cv::Mat in / cv::Mat out)
-    def compose_host(self, frames):
-        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+    def compose_host(self, frames, out=None):
+        """process(imgs, ret): host frames (rows may be strided views) in, host panorama out.  `out`: a (h, w, 3) uint8 array
+        to write into (rows may be strided) instead of a fresh one"""
+        frames = [f if (f.dtype == np.uint8 and f.ndim == 3 and f.strides[1:] == (3, 1)) else np.ascontiguousarray(f, np.uint8)
+                  for f in frames]
         assert len(frames) == self.n
         for f in frames:
             if f.shape != (self.frame_h, self.frame_w, 3):
                 raise PanoError(-2, "frame shape")
         w, h = self.output_size()
-        out = np.empty((h, w, 3), np.uint8)
+        if out is None:
+            out = np.empty((h, w, 3), np.uint8)
+        elif out.shape != (h, w, 3) or out.dtype != np.uint8 or out.strides[1:] != (3, 1):
+            raise PanoError(-2, "output shape")
         ptrs = (C.c_void_p * self.n)(*[f.ctypes.data for f in frames])
         strides = (C.c_size_t * self.n)(*[f.strides[0] for f in frames])
         self._ck(self.lib.pano_compose_host(self.h, ptrs, strides, _vp(out.ctypes.data), C.c_size_t(out.strides[0])))

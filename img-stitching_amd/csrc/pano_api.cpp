@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "pano_graphcut.hpp"
+#include "pano_hostcopy.hpp"
 #include "pano_kernels.hpp"
 #include "pano_plan.hpp"
 
@@ -108,6 +109,12 @@ struct pano_ctx {
     uint8_t* stage_out = nullptr;
     size_t stage_out_pitch = 0, stage_out_bytes = 0;
     hipStream_t own_stream = nullptr;
+    // ... and its page-locked host side (pageable caller memory is copied through these by the pool's threads)
+    uint8_t* pin_in[kMaxCams] = {};
+    size_t pin_in_pitch = 0;
+    uint8_t* pin_out = nullptr;
+    hipStream_t host_h2d[2] = {};
+    hipEvent_t host_in_ready[2] = {};
     // streaming slots (pano_stream_*): pinned host buffers, per-slot device buffers, copy streams and events
     struct StreamSlot {
         uint8_t* h_in[kMaxCams] = {};
@@ -243,6 +250,21 @@ void free_device(pano_ctx* c) {
     c->slots_ready = false;
     dfree(c->pyr_base);
     dfree(c->stage_out);
+    c->stage_out_bytes = 0;
+    for (int i = 0; i < kMaxCams; i++) {
+        if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
+        c->pin_in[i] = nullptr;
+    }
+    if (c->pin_out) (void)hipHostFree(c->pin_out);
+    c->pin_out = nullptr;
+    for (auto& hs : c->host_h2d) {
+        if (hs) (void)hipStreamDestroy(hs);
+        hs = nullptr;
+    }
+    for (auto& he : c->host_in_ready) {
+        if (he) (void)hipEventDestroy(he);
+        he = nullptr;
+    }
     if (c->ev_valid)
         for (auto& sl : c->ring)
             for (auto& e : sl.e) (void)hipEventDestroy(e);
@@ -1180,14 +1202,24 @@ static pano_status set_frame_slots_impl(pano_ctx* c, int n) {
     }
     const int have = std::min(c->nslots, n);
     c->nslots = have;
-    for (int k = have; k < n; k++) {  // grow
-        HIP_TRY(c, hipMalloc((void**)&c->slot_pyr[k], c->slot_bytes * c->plan.n + 256));
-        c->nslots = k + 1;  // free_device releases what exists if a later allocation fails
-        HIP_TRY(c, hipMemset(c->slot_pyr[k], 0, c->slot_bytes * c->plan.n));
-        for (int l = 1; l < c->levels; l++)
-            HIP_TRY(c, hipMalloc((void**)&c->slot_canvas[k][l], (size_t)c->cv.cplane[l] * 3 * sizeof(int16_t) + 256));
-    }
     drop_graphs(c);
+    for (int k = have; k < n; k++) {  // grow: a slot counts only once every one of its buffers exists
+        char* pyr = nullptr;
+        int16_t* cvs[kMaxLevels] = {};
+        bool ok = hipMalloc((void**)&pyr, c->slot_bytes * c->plan.n + 256) == hipSuccess &&
+                  hipMemset(pyr, 0, c->slot_bytes * c->plan.n) == hipSuccess;
+        for (int l = 1; ok && l < c->levels; l++)
+            ok = hipMalloc((void**)&cvs[l], (size_t)c->cv.cplane[l] * 3 * sizeof(int16_t) + 256) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            dfree(pyr);
+            for (int l = 1; l < c->levels; l++) dfree(cvs[l]);
+            return fail(c, PANO_EHIP, "hipMalloc (frame slot): the slots allocated so far stay usable");
+        }
+        c->slot_pyr[k] = pyr;
+        for (int l = 1; l < c->levels; l++) c->slot_canvas[k][l] = cvs[l];
+        c->nslots = k + 1;
+    }
     return PANO_OK;
 }
 
@@ -1706,13 +1738,21 @@ pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b, const uint8_t* const* fa
     return PANO_OK;
 }
 
+// process(vector<Mat>&, Mat&) (ocvstitcher.hpp:1141): host frames in, host panorama out, synchronous.  Page-locked caller
+// memory is DMA'd directly; pageable memory goes through the ctx's page-locked staging, copied by the pool's threads while the
+// previous camera's DMA runs (pano_hostcopy.hpp).  Works in frame slot 0 (pano.h) whatever slot the caller has selected.
 static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides, uint8_t* h_out,
                               size_t out_stride) {
     pano_status st = check_compute(c);
     if (st != PANO_OK) return st;
     if (!h_frames || !strides || !h_out) return PANO_EINVAL;
     const Plan& P = c->plan;
-    const size_t in_pitch = align_up((size_t)c->frame_w * 3, 256), out_pitch = align_up((size_t)P.cut.w * 3, 256);
+    const size_t row_in = (size_t)c->frame_w * 3, row_out = (size_t)P.cut.w * 3;
+    // tight pitches (K1 wants strides % 16 == 0): a caller stride of width*3 makes every copy one linear transfer
+    const size_t in_pitch = align_up(row_in, 16), out_pitch = align_up(row_out, 16);
+    for (int i = 0; i < P.n; i++)
+        if (!h_frames[i] || strides[i] < row_in) return PANO_EINVAL;
+    if (out_stride < row_out) return PANO_EINVAL;
     if (!c->stage_in[0] || c->stage_in_pitch != in_pitch) {
         for (int i = 0; i < P.n; i++) {
             dfree(c->stage_in[i]);
@@ -1724,25 +1764,87 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
     if (!c->stage_out || out_pitch * (size_t)P.cut.h > c->stage_out_bytes) {
         HIP_TRY(c, hipDeviceSynchronize());
         dfree(c->stage_out);
+        if (c->pin_out) (void)hipHostFree(c->pin_out);
+        c->pin_out = nullptr;
         c->stage_out_bytes = out_pitch * (size_t)P.cut.h;
         HIP_TRY(c, hipMalloc((void**)&c->stage_out, c->stage_out_bytes));
     }
     c->stage_out_pitch = out_pitch;
+    if (!c->host_h2d[0]) {
+        for (auto& hs : c->host_h2d) HIP_TRY(c, hipStreamCreateWithFlags(&hs, hipStreamNonBlocking));
+        for (auto& he : c->host_in_ready) HIP_TRY(c, hipEventCreateWithFlags(&he, hipEventDisableTiming));
+    }
+    const int prev_slot = c->cur_slot;
+    if (c->nslots > 1 && prev_slot != 0) bind_slot(c, 0);
     hipStream_t s = c->own_stream;
+    CopyPool& pool = CopyPool::instance();
     const uint8_t* frames[kMaxCams];
     size_t pitches[kMaxCams];
     for (int i = 0; i < P.n; i++) {
-        if (!h_frames[i] || strides[i] < (size_t)c->frame_w * 3) return PANO_EINVAL;
-        HIP_TRY(c, hipMemcpy2DAsync(c->stage_in[i], in_pitch, h_frames[i], strides[i], (size_t)c->frame_w * 3, c->frame_h,
-                                    hipMemcpyHostToDevice, s));
+        hipStream_t cs = c->host_h2d[i & 1];  // two copy queues: consecutive cameras can use two DMA engines
+        const uint8_t* src = h_frames[i];
+        size_t spitch = strides[i];
+        if (!is_pinned_host(src, spitch * (size_t)(c->frame_h - 1) + row_in)) {
+            if (!c->pin_in[i] || c->pin_in_pitch != in_pitch) {
+                HIP_TRY(c, hipStreamSynchronize(cs));
+                if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
+                c->pin_in[i] = nullptr;
+                HIP_TRY(c, hipHostMalloc((void**)&c->pin_in[i], in_pitch * c->frame_h, hipHostMallocDefault));
+            }
+            pool.copy2d(c->pin_in[i], in_pitch, src, spitch, row_in, c->frame_h);
+            src = c->pin_in[i];
+            spitch = in_pitch;
+        }
+        if (spitch == in_pitch)
+            HIP_TRY(c, hipMemcpyAsync(c->stage_in[i], src, in_pitch * (size_t)(c->frame_h - 1) + row_in, hipMemcpyHostToDevice, cs));
+        else
+            HIP_TRY(c, hipMemcpy2DAsync(c->stage_in[i], in_pitch, src, spitch, row_in, c->frame_h, hipMemcpyHostToDevice, cs));
         frames[i] = c->stage_in[i];
         pitches[i] = in_pitch;
     }
-    if ((st = pano_compose(c, frames, pitches, c->stage_out, out_pitch, s)) != PANO_OK) return st;
-    HIP_TRY(c, hipMemcpy2DAsync(h_out, out_stride, c->stage_out, out_pitch, (size_t)P.cut.w * 3, P.cut.h,
-                                hipMemcpyDeviceToHost, s));
+    c->pin_in_pitch = in_pitch;
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(c, hipEventRecord(c->host_in_ready[k], c->host_h2d[k]));
+        HIP_TRY(c, hipStreamWaitEvent(s, c->host_in_ready[k], 0));
+    }
+    st = pano_compose(c, frames, pitches, c->stage_out, out_pitch, s);
+    if (c->nslots > 1 && prev_slot != 0) bind_slot(c, prev_slot);
+    if (st != PANO_OK) return st;
+    const size_t out_bytes = out_pitch * (size_t)(P.cut.h - 1) + row_out;
+    if (is_pinned_host(h_out, out_stride * (size_t)(P.cut.h - 1) + row_out)) {
+        if (out_stride == out_pitch)
+            HIP_TRY(c, hipMemcpyAsync(h_out, c->stage_out, out_bytes, hipMemcpyDeviceToHost, s));
+        else
+            HIP_TRY(c, hipMemcpy2DAsync(h_out, out_stride, c->stage_out, out_pitch, row_out, P.cut.h, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        return PANO_OK;
+    }
+    if (!c->pin_out) HIP_TRY(c, hipHostMalloc((void**)&c->pin_out, c->stage_out_bytes, hipHostMallocDefault));
+    // the panorama comes back in two halves so that the host copy of the first overlaps the DMA of the second
+    const int h0 = P.cut.h / 2;
+    const size_t b0 = out_pitch * (size_t)h0;
+    if (h0 > 0) HIP_TRY(c, hipMemcpyAsync(c->pin_out, c->stage_out, b0, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(c->host_in_ready[0], s));
+    HIP_TRY(c, hipMemcpyAsync(c->pin_out + b0, c->stage_out + b0, out_bytes - b0, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventSynchronize(c->host_in_ready[0]));
+    pool.copy2d(h_out, out_stride, c->pin_out, out_pitch, row_out, h0);
     HIP_TRY(c, hipStreamSynchronize(s));
+    pool.copy2d(h_out + (size_t)h0 * out_stride, out_stride, c->pin_out + b0, out_pitch, row_out, P.cut.h - h0);
     return PANO_OK;
+}
+
+/* page-locked host memory for frames and panoramas (what cv::cuda::HostMem(PAGE_LOCKED) is to a CUDA OpenCV build):
+ * pano_compose_host DMAs such buffers directly */
+void* pano_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void pano_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 pano_status pano_stack_master(pano_ctx* c, const uint8_t* d_up, int up_w, int up_h, size_t up_stride, const uint8_t* d_down,
@@ -1838,7 +1940,11 @@ pano_status pano_stream_submit(pano_ctx* c, int slot) {
     }
     HIP_TRY(c, hipEventRecord(sl.in_ready, sl.h2d));
     HIP_TRY(c, hipStreamWaitEvent(c->own_stream, sl.in_ready, 0));
-    if ((st = pano_compose(c, frames, pitches, sl.d_out, c->slot_out_pitch, c->own_stream)) != PANO_OK) return st;
+    const int prev_slot = c->cur_slot;   // the streaming form works in frame slot 0 (pano.h)
+    if (c->nslots > 1 && prev_slot != 0) bind_slot(c, 0);
+    st = pano_compose(c, frames, pitches, sl.d_out, c->slot_out_pitch, c->own_stream);
+    if (c->nslots > 1 && prev_slot != 0) bind_slot(c, prev_slot);
+    if (st != PANO_OK) return st;
     HIP_TRY(c, hipEventRecord(sl.composed, c->own_stream));
     HIP_TRY(c, hipStreamWaitEvent(sl.d2h, sl.composed, 0));
     HIP_TRY(c, hipMemcpyAsync(sl.h_out, sl.d_out, c->slot_out_pitch * P.cut.h, hipMemcpyDeviceToHost, sl.d2h));
@@ -2058,7 +2164,15 @@ pano_status pano_save_camera_file(pano_ctx* c, const char* path) {
 }
 
 pano_status pano_prepare(pano_ctx* c) {
-    return guarded(c, [&]() { return prepare_impl(c); });
+    // a failure half way (an allocation, an upload) must not leave a ctx that claims to be prepared with null buffers
+    pano_status st = guarded(c, [&]() { return prepare_impl(c); });
+    if (st != PANO_OK && c && c->prepared) {
+        std::string why = c->err;
+        if (c->device >= 0) free_device(c);
+        c->prepared = false;
+        c->err = why;
+    }
+    return st;
 }
 
 pano_status pano_set_frame_slots(pano_ctx* c, int n) {

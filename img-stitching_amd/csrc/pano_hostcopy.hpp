@@ -1,0 +1,135 @@
+// pano_hostcopy.hpp - host side of the cv::Mat-shaped entry (pano_compose_host = ocvStitcher::process(vector<Mat>&, Mat&),
+// reference include/ocvstitcher.hpp:1141): getting pageable caller memory to and from the GPU at PCIe rate.
+//
+// A hipMemcpy from pageable memory is staged by the runtime through a small bounce buffer on ONE thread: 4.5 GB/s measured
+// on the MI355X box (62 panoramas/s for 8 x 1080p in, 2 x 3893 x 991 out).  Here the staging is explicit: a few copy threads
+// move the caller's rows into page-locked buffers the ctx owns (host memcpy scales with threads until the memory
+// controllers saturate), and each camera's DMA is queued the moment its rows are in place, so the copy of camera i+1
+// overlaps the DMA of camera i.  Caller memory that is already page-locked (hipHostMalloc / hipHostRegister /
+// pano_host_alloc) skips the staging and is DMA'd directly.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <unistd.h>
+
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace pano {
+
+// is [p, p + bytes) page-locked memory known to HIP?  (plain malloc memory: an error or "unregistered", by ROCm version)
+inline bool is_pinned_host(const void* p, size_t bytes) {
+    if (!p || !bytes) return false;
+    auto one = [](const void* q) {
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+            (void)hipGetLastError();  // the failed query must not surface as a later launch error
+            return false;
+        }
+        return a.type == hipMemoryTypeHost;
+    };
+    return one(p) && one(static_cast<const char*>(p) + bytes - 1);
+}
+
+class CopyPool {
+  public:
+    // process-wide, created on first use and never destroyed (worker threads must not outlive a static's destructor)
+    static CopyPool& instance() {
+        static CopyPool* pool = new CopyPool();
+        return *pool;
+    }
+    int threads() const { return nthreads_; }
+
+    // copy `rows` rows of `width` bytes; the rows are split over the pool and the calling thread; returns when done
+    void copy2d(uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t width, int rows) {
+        if (rows <= 0 || width == 0) return;
+        const size_t total = width * (size_t)rows;
+        int parts = (int)std::min<size_t>((size_t)nthreads_, std::max<size_t>(1, total / kMinChunk));
+        parts = std::min(parts, rows);
+        if (parts <= 1) {
+            rows_copy(dst, dpitch, src, spitch, width, rows);
+            return;
+        }
+        Latch latch;
+        latch.left = parts - 1;
+        const int per = (rows + parts - 1) / parts;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            ensure_workers();
+            for (int k = 1; k < parts; k++) {
+                const int r0 = k * per, r1 = std::min(rows, r0 + per);
+                q_.push_back(Task{dst + (size_t)r0 * dpitch, dpitch, src + (size_t)r0 * spitch, spitch, width, std::max(0, r1 - r0), &latch});
+            }
+        }
+        cv_.notify_all();
+        rows_copy(dst, dpitch, src, spitch, width, std::min(rows, per));
+        std::unique_lock<std::mutex> lk(latch.m);
+        latch.cv.wait(lk, [&] { return latch.left == 0; });
+    }
+
+  private:
+    static constexpr size_t kMinChunk = 256 << 10;  // below this a task costs more than it copies
+    struct Latch {  // lives on the caller's stack: `left` only changes under `m`, so the last worker is done with it
+        int left = 0;   // before the caller can see 0 and return
+        std::mutex m;
+        std::condition_variable cv;
+    };
+    struct Task {
+        uint8_t* dst; size_t dpitch; const uint8_t* src; size_t spitch; size_t width; int rows; Latch* latch;
+    };
+    CopyPool() {
+        int n = 8;  // PANO_HOST_THREADS: copy threads per process (1 = copy on the calling thread)
+        if (const char* e = getenv("PANO_HOST_THREADS")) n = atoi(e);
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0) n = std::min(n, hw);
+        nthreads_ = std::max(1, std::min(n, 64));
+    }
+    static void rows_copy(uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t width, int rows) {
+        if (dpitch == width && spitch == width) {
+            std::memcpy(dst, src, width * (size_t)rows);
+            return;
+        }
+        for (int y = 0; y < rows; y++) std::memcpy(dst + (size_t)y * dpitch, src + (size_t)y * spitch, width);
+    }
+    void ensure_workers() {  // m_ held
+        if (pid_ != getpid()) {  // after a fork the child has this object but none of its threads
+            workers_.clear();    // (detached: nothing to join)
+            q_.clear();
+            pid_ = getpid();
+        }
+        while ((int)workers_.size() < nthreads_ - 1) {
+            workers_.emplace_back([this] { work(); });
+            workers_.back().detach();
+        }
+    }
+    void work() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return !q_.empty(); });
+                t = q_.front();
+                q_.pop_front();
+            }
+            rows_copy(t.dst, t.dpitch, t.src, t.spitch, t.width, t.rows);
+            {
+                std::lock_guard<std::mutex> g(t.latch->m);
+                if (--t.latch->left == 0) t.latch->cv.notify_one();
+            }
+        }
+    }
+    int nthreads_ = 1;
+    pid_t pid_ = 0;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Task> q_;
+    std::vector<std::thread> workers_;
+};
+
+}  // namespace pano

@@ -177,6 +177,12 @@ pano_status pano_compose(pano_ctx* ctx, const uint8_t* const* d_frames, const si
 pano_status pano_compose_host(pano_ctx* ctx, const uint8_t* const* h_frames, const size_t* strides,
                               uint8_t* h_out, size_t out_stride);
 
+/* Page-locked host memory for frames and panoramas - what cv::cuda::HostMem(PAGE_LOCKED) is to a CUDA build of OpenCV.
+ * pano_compose_host recognises page-locked buffers (these, hipHostMalloc, hipHostRegister) and DMAs them directly; any
+ * other memory is staged through page-locked buffers of the ctx by a few copy threads (PANO_HOST_THREADS, default 8). */
+void* pano_host_alloc(size_t bytes);
+void pano_host_free(void* p);
+
 /* The reference runs its two stitchers (upper / lower camera group) on two threads per frame
  * (src/master.cpp:314-318).  pano_compose_pair composes both in ONE launch sequence: a single warp launch over
  * all cameras of both contexts, one launch per pyramid / blend level for both canvases.  Results are identical to

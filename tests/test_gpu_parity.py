@@ -1022,3 +1022,68 @@ def test_rig_r_on_its_real_frames(pano, po, torch, rig_r_real):
     stacked = out.cpu().numpy()
     assert np.array_equal(stacked, po.stack_master(halves[0], halves[1]))
     assert sha(stacked) == g["stack_master_sha256"] and np.array_equal(stacked, load_png_bgr(os.path.join(GOLDEN, "r_stacked.png")))
+
+
+def test_host_entry_pageable_pinned_and_strided(pano, po, torch, c1):
+    """pano_compose_host = process(vector<Mat>&, Mat&): pageable caller memory (staged through page-locked buffers by the copy
+    threads), page-locked caller memory (pano_host_alloc: DMA'd directly), padded row strides on both sides, two stitchers
+    called from two threads at once like master.cpp:314-318, and a selected frame slot > 0 left alone - all the oracle's bytes"""
+    import threading
+    masks = oracle_masks(po, c1)
+    sets = [c1["frames"], [np.ascontiguousarray(f[::-1]) for f in c1["frames"]]]
+    wants = [po.compose(f, c1["K"], c1["R"], c1["scale"], masks, 3)[0] for f in sets]
+    ctxs = []
+    for k in range(2):
+        ctx = make_ctx(pano, c1, 0, num_bands=3)
+        for i in range(4):
+            ctx.set_mask(i, masks[i])
+        ctxs.append(ctx)
+    ctx = ctxs[0]
+    ow, oh = ctx.output_size()
+    # pageable, tight
+    assert np.array_equal(ctx.compose_host(sets[0]), wants[0])
+    # pageable, padded rows in and out (views into wider arrays)
+    wide = [np.zeros((270, 480 + 7, 3), np.uint8) for _ in range(4)]
+    for w_, f in zip(wide, sets[1]):
+        w_[:, :480] = f
+    out_w = np.full((oh, ow + 5, 3), 77, np.uint8)
+    got = ctx.compose_host([w_[:, :480] for w_ in wide], out=out_w[:, :ow])
+    assert np.array_equal(got, wants[1]) and (out_w[:, ow:] == 77).all()
+    # page-locked frames and output: no staging
+    pin = [pano.HostBuffer((270, 480, 3)) for _ in range(4)]
+    pout = pano.HostBuffer((oh, ow, 3))
+    for rep in range(2):
+        for b, f in zip(pin, sets[rep]):
+            b.array[:] = f
+        pout.array[:] = 0
+        assert np.array_equal(ctx.compose_host([b.array for b in pin], out=pout.array), wants[rep])
+    # mixed: two cameras page-locked, two pageable, pageable output
+    assert np.array_equal(ctx.compose_host([pin[0].array, sets[1][1], pin[2].array, sets[1][3]]), wants[1])
+    # a frame slot > 0 selected by the caller stays selected and untouched (the host entry works in slot 0)
+    ctx.set_frame_slots(2)
+    ctx.select_frame_slot(1)
+    fd = [torch.from_numpy(f).cuda() for f in sets[0]]
+    o1 = torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda")
+    st1 = torch.cuda.Stream()
+    ctx.compose([t.data_ptr() for t in fd], [480 * 3] * 4, o1.data_ptr(), ow * 3, st1.cuda_stream)
+    assert np.array_equal(ctx.compose_host(sets[1]), wants[1])
+    ctx.compose([t.data_ptr() for t in fd], [480 * 3] * 4, o1.data_ptr(), ow * 3, st1.cuda_stream)   # still slot 1
+    torch.cuda.synchronize()
+    assert np.array_equal(o1.cpu().numpy(), wants[0])
+    # two stitchers from two threads, many frames
+    res = [[None] * 6 for _ in range(2)]
+
+    def run(k):
+        for j in range(6):
+            res[k][j] = ctxs[k].compose_host(sets[(j + k) % 2])
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        for j in range(6):
+            assert np.array_equal(res[k][j], wants[(j + k) % 2]), (k, j)
+    for b in pin + [pout]:
+        b.close()
