@@ -106,12 +106,14 @@ int main(int argc, char** argv) {
         double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         printf("frame %d: stitching takes %.3f ms\n", f, ms);
     }
-    // vconcat with a black divider (master.cpp:321-326), widths cropped to the narrower half
-    int w = std::min(out[0].cols, out[1].cols);
-    pano::Mat fin(out[0].rows + out[1].rows, w);
-    for (int y = 0; y < out[0].rows; y++) memcpy(fin.data + (size_t)y * fin.step, out[0].data + (size_t)y * out[0].step, (size_t)w * 3);
-    for (int y = 0; y < out[1].rows; y++) memcpy(fin.data + (size_t)(y + out[0].rows) * fin.step, out[1].data + (size_t)y * out[1].step, (size_t)w * 3);
-    for (int y = out[0].rows - 1; y <= out[0].rows + 1 && y < fin.rows; y++) memset(fin.data + (size_t)y * fin.step, 0, (size_t)w * 3);
+    if (out[0].empty() || out[1].empty()) { fprintf(stderr, "process failed: %s / %s\n", st[0].lastError(), st[1].lastError()); return 1; }
+    // master.cpp:321-326: cv::resize(up -> down.size()), vconcat, black 10-row bar - the library's bit-exact twin of it
+    pano::Mat fin(2 * out[1].rows, out[1].cols);
+    if (pano_stack_master_host(st[1].handle(), out[0].data, out[0].cols, out[0].rows, out[0].step, out[1].data, out[1].cols,
+                               out[1].rows, out[1].step, fin.data, fin.step) != PANO_OK) {
+        fprintf(stderr, "pano_stack_master_host: %s\n", st[1].lastError());
+        return 1;
+    }
     write_ppm("final.ppm", fin);
     printf("wrote final.ppm %dx%d\n", fin.cols, fin.rows);
     return 0;

@@ -87,7 +87,7 @@ EXPORTS = [
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_get_camera", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
     "pano_build_masks_voronoi", "pano_build_masks_graphcut", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
-    "pano_compose_host", "pano_host_alloc", "pano_host_free", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_stream_input", "pano_stream_output",
+    "pano_compose_host", "pano_host_alloc", "pano_host_free", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_stack_master_host", "pano_stack_finalcut_host", "pano_stream_input", "pano_stream_output",
     "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
     "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_get_live_rect", "pano_get_live_gap", "pano_get_warp_table_stats", "pano_debug_get_level", "pano_debug_get_weights",
     "pano_debug_get_canvas_weights", "pano_debug_get_canvas",
@@ -341,6 +341,25 @@ class Context:
         self._ck(self.lib.pano_stack_finalcut(self.h, _vp(d_up), up_w, up_h, C.c_size_t(up_stride), _vp(d_down), dw, dh,
                                               C.c_size_t(d_stride), int(finalcut), _vp(d_out), C.c_size_t(out_stride),
                                               _vp(stream)))
+
+    def stack_master_host(self, up, down):
+        """master.cpp:321-326 on host arrays"""
+        up = np.ascontiguousarray(up, np.uint8); down = np.ascontiguousarray(down, np.uint8)
+        out = np.empty((2 * down.shape[0], down.shape[1], 3), np.uint8)
+        self._ck(self.lib.pano_stack_master_host(self.h, _vp(up.ctypes.data), up.shape[1], up.shape[0], C.c_size_t(up.strides[0]),
+                                                 _vp(down.ctypes.data), down.shape[1], down.shape[0], C.c_size_t(down.strides[0]),
+                                                 _vp(out.ctypes.data), C.c_size_t(out.strides[0])))
+        return out
+
+    def stack_finalcut_host(self, up, down, finalcut):
+        """panocamimpl.cpp:354-360 on host arrays"""
+        up = np.ascontiguousarray(up, np.uint8); down = np.ascontiguousarray(down, np.uint8)
+        w, h = min(up.shape[1], down.shape[1]), min(up.shape[0], down.shape[0]) - 2 * finalcut
+        out = np.empty((2 * h, w, 3), np.uint8)
+        self._ck(self.lib.pano_stack_finalcut_host(self.h, _vp(up.ctypes.data), up.shape[1], up.shape[0], C.c_size_t(up.strides[0]),
+                                                   _vp(down.ctypes.data), down.shape[1], down.shape[0], C.c_size_t(down.strides[0]),
+                                                   int(finalcut), _vp(out.ctypes.data), C.c_size_t(out.strides[0])))
+        return out
 
     # -- measurement
     def set_profiling(self, on):

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -14,6 +15,7 @@
 #include <cstring>
 #include <ctime>
 #include <fstream>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <sstream>
@@ -115,6 +117,10 @@ struct pano_ctx {
     uint8_t* pin_out = nullptr;
     hipStream_t host_h2d[2] = {};
     hipEvent_t host_in_ready[2] = {};
+    uint8_t* stack_buf = nullptr;   // pano_stack_*_host: both halves + the stacked image on the device
+    size_t stack_bytes = 0;
+    double host_trace[5] = {};   // PANO_HOST_TRACE: stage in + queue H2D | queue kernels | H2D + kernels done | copy back | unstage
+    long host_trace_n = 0;
     // streaming slots (pano_stream_*): pinned host buffers, per-slot device buffers, copy streams and events
     struct StreamSlot {
         uint8_t* h_in[kMaxCams] = {};
@@ -251,6 +257,8 @@ void free_device(pano_ctx* c) {
     dfree(c->pyr_base);
     dfree(c->stage_out);
     c->stage_out_bytes = 0;
+    dfree(c->stack_buf);
+    c->stack_bytes = 0;
     for (int i = 0; i < kMaxCams; i++) {
         if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
         c->pin_in[i] = nullptr;
@@ -838,6 +846,10 @@ static pano_status create_impl(const pano_config* cfg, pano_ctx** out) {
 
 void pano_destroy(pano_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->host_trace_n)
+        fprintf(stderr, "pano_compose_host x %ld: stage in + queue H2D %.3f ms, queue kernels %.3f, wait H2D + kernels %.3f, copy back %.3f, unstage %.3f\n",
+                ctx->host_trace_n, ctx->host_trace[0] / ctx->host_trace_n, ctx->host_trace[1] / ctx->host_trace_n,
+                ctx->host_trace[2] / ctx->host_trace_n, ctx->host_trace[3] / ctx->host_trace_n, ctx->host_trace[4] / ctx->host_trace_n);
     if (ctx->device >= 0 && ctx->prepared) {
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();
@@ -1778,27 +1790,51 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
     if (c->nslots > 1 && prev_slot != 0) bind_slot(c, 0);
     hipStream_t s = c->own_stream;
     CopyPool& pool = CopyPool::instance();
+    // PANO_HOST_TRACE=1: mean host-clock ms of the phases, printed by pano_destroy (diagnostic)
+    static const bool trace = getenv("PANO_HOST_TRACE") && atoi(getenv("PANO_HOST_TRACE"));
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tp[6] = {};
+    if (trace) tp[0] = now();
     const uint8_t* frames[kMaxCams];
     size_t pitches[kMaxCams];
+    // The reference calls process() of its two stitchers from two threads at the same moment (src/master.cpp:314-318).  Left
+    // alone both would stage and upload in lockstep, halving each other's rate, and then download in lockstep.  One stitcher at
+    // a time through the upload section staggers them: the second one's upload runs against the first one's kernels and
+    // download (the link is full duplex)
+    static std::mutex upload_turn;
+    std::unique_lock<std::mutex> turn(upload_turn);
+    // every pageable camera's rows go to the copy threads at once; each camera's DMA is queued the moment its rows are staged
+    CopyPool::Latch staged[kMaxCams];
+    struct WaitAll {  // an early return must not leave copy threads writing to latches of a dead stack frame
+        CopyPool& pool;
+        CopyPool::Latch* l;
+        ~WaitAll() {
+            for (int i = 0; i < kMaxCams; i++) pool.wait(l[i]);
+        }
+    } wait_all{pool, staged};
+    const uint8_t* dma_src[kMaxCams];
+    bool any_staged = false;
     for (int i = 0; i < P.n; i++) {
-        hipStream_t cs = c->host_h2d[i & 1];  // two copy queues: consecutive cameras can use two DMA engines
-        const uint8_t* src = h_frames[i];
-        size_t spitch = strides[i];
-        if (!is_pinned_host(src, spitch * (size_t)(c->frame_h - 1) + row_in)) {
+        dma_src[i] = h_frames[i];
+        // direct DMA only when it is ONE linear transfer: rectangular copies with odd row lengths run at a fraction of the
+        // link rate (1.3 GB/s measured for 11679-byte rows), slower than staging them
+        if (strides[i] != in_pitch || !is_pinned_host(h_frames[i], strides[i] * (size_t)(c->frame_h - 1) + row_in)) {
             if (!c->pin_in[i] || c->pin_in_pitch != in_pitch) {
-                HIP_TRY(c, hipStreamSynchronize(cs));
+                HIP_TRY(c, hipStreamSynchronize(c->host_h2d[i & 1]));
                 if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
                 c->pin_in[i] = nullptr;
                 HIP_TRY(c, hipHostMalloc((void**)&c->pin_in[i], in_pitch * c->frame_h, hipHostMallocDefault));
             }
-            pool.copy2d(c->pin_in[i], in_pitch, src, spitch, row_in, c->frame_h);
-            src = c->pin_in[i];
-            spitch = in_pitch;
+            pool.submit(staged[i], c->pin_in[i], in_pitch, h_frames[i], strides[i], row_in, c->frame_h);
+            dma_src[i] = c->pin_in[i];
+            any_staged = true;
         }
-        if (spitch == in_pitch)
-            HIP_TRY(c, hipMemcpyAsync(c->stage_in[i], src, in_pitch * (size_t)(c->frame_h - 1) + row_in, hipMemcpyHostToDevice, cs));
-        else
-            HIP_TRY(c, hipMemcpy2DAsync(c->stage_in[i], in_pitch, src, spitch, row_in, c->frame_h, hipMemcpyHostToDevice, cs));
+    }
+    for (int i = 0; i < P.n; i++) {
+        pool.wait(staged[i]);
+        // two copy queues: consecutive cameras can use two DMA engines
+        HIP_TRY(c, hipMemcpyAsync(c->stage_in[i], dma_src[i], in_pitch * (size_t)(c->frame_h - 1) + row_in, hipMemcpyHostToDevice,
+                                  c->host_h2d[i & 1]));
         frames[i] = c->stage_in[i];
         pitches[i] = in_pitch;
     }
@@ -1807,16 +1843,35 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
         HIP_TRY(c, hipEventRecord(c->host_in_ready[k], c->host_h2d[k]));
         HIP_TRY(c, hipStreamWaitEvent(s, c->host_in_ready[k], 0));
     }
-    st = pano_compose(c, frames, pitches, c->stage_out, out_pitch, s);
+    if (!any_staged)  // nothing was staged, so queueing took no time: the turn lasts until the frames have crossed the link
+        for (int k = 0; k < 2; k++) HIP_TRY(c, hipEventSynchronize(c->host_in_ready[k]));
+    turn.unlock();
+    if (trace) tp[1] = now();
+    // a page-locked panorama buffer whose rows fit the staging buffer: the blend writes rows at the CALLER's stride (it takes
+    // any), and the way back is one linear DMA
+    const bool direct_out = out_stride * (size_t)(P.cut.h - 1) + row_out <= c->stage_out_bytes &&
+                            is_pinned_host(h_out, out_stride * (size_t)(P.cut.h - 1) + row_out);
+    const size_t dev_pitch = direct_out ? out_stride : out_pitch;
+    st = pano_compose(c, frames, pitches, c->stage_out, dev_pitch, s);
     if (c->nslots > 1 && prev_slot != 0) bind_slot(c, prev_slot);
     if (st != PANO_OK) return st;
-    const size_t out_bytes = out_pitch * (size_t)(P.cut.h - 1) + row_out;
-    if (is_pinned_host(h_out, out_stride * (size_t)(P.cut.h - 1) + row_out)) {
-        if (out_stride == out_pitch)
-            HIP_TRY(c, hipMemcpyAsync(h_out, c->stage_out, out_bytes, hipMemcpyDeviceToHost, s));
-        else
-            HIP_TRY(c, hipMemcpy2DAsync(h_out, out_stride, c->stage_out, out_pitch, row_out, P.cut.h, hipMemcpyDeviceToHost, s));
+    if (trace) {
+        tp[2] = now();
+        HIP_TRY(c, hipStreamSynchronize(s));   // tracing only: separates the kernels from the copy back
+        tp[3] = now();
+    }
+    auto account = [&]() {
+        if (!trace) return;
+        tp[5] = now();
+        if (tp[4] == 0) tp[4] = tp[5];
+        for (int k = 0; k < 5; k++) c->host_trace[k] += tp[k + 1] - tp[k];
+        c->host_trace_n++;
+    };
+    const size_t out_bytes = dev_pitch * (size_t)(P.cut.h - 1) + row_out;
+    if (direct_out) {
+        HIP_TRY(c, hipMemcpyAsync(h_out, c->stage_out, out_bytes, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
+        account();
         return PANO_OK;
     }
     if (!c->pin_out) HIP_TRY(c, hipHostMalloc((void**)&c->pin_out, c->stage_out_bytes, hipHostMallocDefault));
@@ -1829,7 +1884,9 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
     HIP_TRY(c, hipEventSynchronize(c->host_in_ready[0]));
     pool.copy2d(h_out, out_stride, c->pin_out, out_pitch, row_out, h0);
     HIP_TRY(c, hipStreamSynchronize(s));
+    if (trace) tp[4] = now();
     pool.copy2d(h_out + (size_t)h0 * out_stride, out_stride, c->pin_out + b0, out_pitch, row_out, P.cut.h - h0);
+    account();
     return PANO_OK;
 }
 
@@ -1877,6 +1934,48 @@ pano_status pano_stack_finalcut(pano_ctx* c, const uint8_t* d_up, int up_w, int 
                  (int)out_stride, height - 2, 4, (hipStream_t)stream);
     HIP_TRY(c, hipGetLastError());
     return PANO_OK;
+}
+
+// master.cpp:321-326 on host cv::Mat-style buffers: the two half panoramas go up, pano_stack_master runs, the stacked image
+// comes back (synchronous).  finalcut < 0: master.cpp's resize + vconcat + 10-row bar; >= 0: panocamimpl.cpp:354-360's crop
+static pano_status stack_host_impl(pano_ctx* c, const uint8_t* h_up, int up_w, int up_h, size_t up_stride, const uint8_t* h_down,
+                                   int down_w, int down_h, size_t down_stride, int finalcut, uint8_t* h_out, size_t out_stride) {
+    if (!c) return PANO_EINVAL;
+    if (c->device < 0) return fail(c, PANO_ENODEVICE, "plan-only context");
+    if (!h_up || !h_down || !h_out || up_w < 1 || up_h < 1 || down_w < 1 || down_h < 1 || up_stride < (size_t)up_w * 3 ||
+        down_stride < (size_t)down_w * 3)
+        return PANO_EINVAL;
+    const int ow = finalcut < 0 ? down_w : std::min(up_w, down_w);
+    const int oh = finalcut < 0 ? 2 * down_h : 2 * (std::min(up_h, down_h) - 2 * finalcut);
+    if (ow < 1 || oh < 2 || out_stride < (size_t)ow * 3) return PANO_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t pu = align_up((size_t)up_w * 3, 16), pd = align_up((size_t)down_w * 3, 16), po = align_up((size_t)ow * 3, 16);
+    const size_t bu = align_up(pu * up_h, 256), bd = align_up(pd * down_h, 256), bo = po * oh;
+    if (bu + bd + bo > c->stack_bytes) {
+        dfree(c->stack_buf);
+        c->stack_bytes = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->stack_buf, bu + bd + bo));
+        c->stack_bytes = bu + bd + bo;
+    }
+    uint8_t *d_up = c->stack_buf, *d_down = d_up + bu, *d_out = d_down + bd;
+    hipStream_t s = c->own_stream;
+    HIP_TRY(c, hipMemcpy2DAsync(d_up, pu, h_up, up_stride, (size_t)up_w * 3, up_h, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpy2DAsync(d_down, pd, h_down, down_stride, (size_t)down_w * 3, down_h, hipMemcpyHostToDevice, s));
+    pano_status st = finalcut < 0 ? pano_stack_master(c, d_up, up_w, up_h, pu, d_down, down_w, down_h, pd, d_out, po, s)
+                                  : pano_stack_finalcut(c, d_up, up_w, up_h, pu, d_down, down_w, down_h, pd, finalcut, d_out, po, s);
+    if (st != PANO_OK) return st;
+    HIP_TRY(c, hipMemcpy2DAsync(h_out, out_stride, d_out, po, (size_t)ow * 3, oh, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return PANO_OK;
+}
+pano_status pano_stack_master_host(pano_ctx* c, const uint8_t* h_up, int up_w, int up_h, size_t up_stride, const uint8_t* h_down,
+                                   int down_w, int down_h, size_t down_stride, uint8_t* h_out, size_t out_stride) {
+    return stack_host_impl(c, h_up, up_w, up_h, up_stride, h_down, down_w, down_h, down_stride, -1, h_out, out_stride);
+}
+pano_status pano_stack_finalcut_host(pano_ctx* c, const uint8_t* h_up, int up_w, int up_h, size_t up_stride, const uint8_t* h_down,
+                                     int down_w, int down_h, size_t down_stride, int finalcut, uint8_t* h_out, size_t out_stride) {
+    if (finalcut < 0) return PANO_EINVAL;
+    return stack_host_impl(c, h_up, up_w, up_h, up_stride, h_down, down_w, down_h, down_stride, finalcut, h_out, out_stride);
 }
 
 namespace {

@@ -46,40 +46,73 @@ class CopyPool {
     }
     int threads() const { return nthreads_; }
 
-    // copy `rows` rows of `width` bytes; the rows are split over the pool and the calling thread; returns when done
-    void copy2d(uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t width, int rows) {
+    // A batch of row copies with completion per job: submit() queues a job's rows in chunks for the pool, wait(job) returns
+    // when that job's rows are in place - and copies queued chunks itself while it waits, so the calling thread is one of the
+    // workers and the pool's threads are woken once per batch, not once per job.
+    struct Latch {  // `left` only changes under `m`: the last worker is done with the latch before a waiter can see 0
+        int left = 0;
+        std::mutex m;
+        std::condition_variable cv;
+    };
+    void submit(Latch& latch, uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t width, int rows) {
         if (rows <= 0 || width == 0) return;
         const size_t total = width * (size_t)rows;
         int parts = (int)std::min<size_t>((size_t)nthreads_, std::max<size_t>(1, total / kMinChunk));
-        parts = std::min(parts, rows);
-        if (parts <= 1) {
-            rows_copy(dst, dpitch, src, spitch, width, rows);
-            return;
-        }
-        Latch latch;
-        latch.left = parts - 1;
+        parts = std::max(1, std::min(parts, rows));
         const int per = (rows + parts - 1) / parts;
+        {
+            std::lock_guard<std::mutex> gl(latch.m);
+            latch.left += parts;
+        }
         {
             std::lock_guard<std::mutex> g(m_);
             ensure_workers();
-            for (int k = 1; k < parts; k++) {
+            for (int k = 0; k < parts; k++) {
                 const int r0 = k * per, r1 = std::min(rows, r0 + per);
                 q_.push_back(Task{dst + (size_t)r0 * dpitch, dpitch, src + (size_t)r0 * spitch, spitch, width, std::max(0, r1 - r0), &latch});
             }
         }
         cv_.notify_all();
-        rows_copy(dst, dpitch, src, spitch, width, std::min(rows, per));
-        std::unique_lock<std::mutex> lk(latch.m);
-        latch.cv.wait(lk, [&] { return latch.left == 0; });
+    }
+    void wait(Latch& latch) {
+        for (;;) {
+            {
+                std::lock_guard<std::mutex> gl(latch.m);
+                if (latch.left == 0) return;
+            }
+            Task t;
+            bool have = false;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (!q_.empty()) {
+                    t = q_.front();
+                    q_.pop_front();
+                    have = true;
+                }
+            }
+            if (have) {
+                run(t);
+                continue;
+            }
+            std::unique_lock<std::mutex> lk(latch.m);   // nothing left to help with: the last chunks are in other hands
+            latch.cv.wait(lk, [&] { return latch.left == 0; });
+            return;
+        }
+    }
+    // copy `rows` rows of `width` bytes, split over the pool and the calling thread; returns when done
+    void copy2d(uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t width, int rows) {
+        if (rows <= 0 || width == 0) return;
+        if (nthreads_ <= 1 || width * (size_t)rows < 2 * kMinChunk) {
+            rows_copy(dst, dpitch, src, spitch, width, rows);
+            return;
+        }
+        Latch latch;
+        submit(latch, dst, dpitch, src, spitch, width, rows);
+        wait(latch);
     }
 
   private:
     static constexpr size_t kMinChunk = 256 << 10;  // below this a task costs more than it copies
-    struct Latch {  // lives on the caller's stack: `left` only changes under `m`, so the last worker is done with it
-        int left = 0;   // before the caller can see 0 and return
-        std::mutex m;
-        std::condition_variable cv;
-    };
     struct Task {
         uint8_t* dst; size_t dpitch; const uint8_t* src; size_t spitch; size_t width; int rows; Latch* latch;
     };
@@ -117,12 +150,13 @@ class CopyPool {
                 t = q_.front();
                 q_.pop_front();
             }
-            rows_copy(t.dst, t.dpitch, t.src, t.spitch, t.width, t.rows);
-            {
-                std::lock_guard<std::mutex> g(t.latch->m);
-                if (--t.latch->left == 0) t.latch->cv.notify_one();
-            }
+            run(t);
         }
+    }
+    static void run(const Task& t) {
+        rows_copy(t.dst, t.dpitch, t.src, t.spitch, t.width, t.rows);
+        std::lock_guard<std::mutex> g(t.latch->m);
+        if (--t.latch->left == 0) t.latch->cv.notify_all();
     }
     int nthreads_ = 1;
     pid_t pid_ = 0;

@@ -11,9 +11,11 @@
 //     std::thread t1(&pano::Stitcher::process, &up, std::ref(upImgs), std::ref(out[0]));   // (:1141)
 //
 // Differences that are deliberate: K/R are never re-estimated (init modes 2 and 3 only - the north star fixes
-// the cameras), the seam finder is Voronoi (stitching_detailed.cpp:728-729) instead of graph cut, and there
+// the cameras); the seam finder is the reference's GraphCutSeamFinder(COST_COLOR) by default (ocvstitcher.hpp:1033),
+// with the geometry-only Voronoi finder of the one-shot twin (stitching_detailed.cpp:728-729) selectable; there
 // is no function-static frame counter shared between instances (reference :1150 is racy): each instance
-// refreshes its masks every `maskRefreshPeriod` frames on its own.
+// refreshes its masks every `maskRefreshPeriod` frames on its own; and process() reports what went wrong
+// (lastStatus() / lastError()) instead of leaving `ret` undefined.
 #pragma once
 
 #include <cstdio>
@@ -42,12 +44,17 @@ struct Mat {
     Mat() {}
     Mat(int r, int c) { create(r, c); }
     Mat(int r, int c, uint8_t* ext, size_t st) : rows(r), cols(c), step(st), data(ext) {}  // borrowed
+    // storage is page-locked (pano_host_alloc) when the library can provide it - pano_compose_host then DMAs it directly
+    // instead of staging it - and plain heap memory otherwise (plan-only use without a GPU)
     void create(int r, int c) {
         if (r == rows && c == cols && owner) return;
         rows = r; cols = c; step = (size_t)c * 3;
-        owner.reset(new uint8_t[step * (size_t)r], std::default_delete<uint8_t[]>());
+        const size_t bytes = step * (size_t)r;
+        if (void* p = pano_host_alloc(bytes)) owner.reset((uint8_t*)p, [](uint8_t* q) { pano_host_free(q); });
+        else owner.reset(new uint8_t[bytes], std::default_delete<uint8_t[]>());
         data = owner.get();
     }
+    void release() { rows = cols = 0; step = 0; data = nullptr; owner.reset(); }
     bool empty() const { return data == nullptr; }
     Mat roi(int x, int y, int w, int h) const {  // cv::Mat::operator()(Rect): a view, no copy
         Mat m = *this;
@@ -244,27 +251,27 @@ class Stitcher {
         return RET_OK;
     }
 
-    // process(imgs, ret) (ocvstitcher.hpp:1141-1216)
+    // process(imgs, ret) (ocvstitcher.hpp:1141-1216).  The reference's returns nothing and cannot fail visibly; here a frame
+    // that could not be composed leaves `ret` EMPTY and the reason in lastStatus() / lastError()
     void process(std::vector<Mat>& imgs, Mat& ret) {
-        if (!ctx_ || (int)imgs.size() < cfg_.num_images) return;
-        if (maskRefreshPeriod > 0 && ++frame_ > maskRefreshPeriod) {  // updateMask cadence (:1152-1159)
-            buildMasks(imgs);
-            frame_ = 0;
-        }
-        int w = 0, h = 0;
-        if (pano_get_output_size(ctx_, &w, &h) != PANO_OK) return;
-        ret.create(h, w);
         const uint8_t* frames[PANO_MAX_CAMS];
         size_t strides[PANO_MAX_CAMS];
-        for (int i = 0; i < cfg_.num_images; i++) {
-            frames[i] = imgs[i].data;
-            strides[i] = imgs[i].step;
+        status_ = PANO_OK;
+        if (!ctx_) { status_ = PANO_ESTATE; ret.release(); return; }
+        if (!borrow(imgs, frames, strides)) { status_ = PANO_EINVAL; ret.release(); return; }  // count, size, null data
+        if (maskRefreshPeriod > 0 && ++frame_ > maskRefreshPeriod) {  // updateMask cadence (:1152-1159)
+            frame_ = 0;
+            if (buildMasks(imgs) != RET_OK) { status_ = PANO_ERR; ret.release(); return; }
         }
-        pano_compose_host(ctx_, frames, strides, ret.data, ret.step);
+        int w = 0, h = 0;
+        if ((status_ = pano_get_output_size(ctx_, &w, &h)) != PANO_OK) { ret.release(); return; }
+        ret.create(h, w);
+        if ((status_ = pano_compose_host(ctx_, frames, strides, ret.data, ret.step)) != PANO_OK) ret.release();
     }
 
     pano_ctx* handle() { return ctx_; }
     const StitcherCfg& config() const { return cfg_; }
+    pano_status lastStatus() const { return status_; }   // of the last process()
     const char* lastError() const { return pano_last_error(ctx_); }
 
   private:
@@ -291,6 +298,7 @@ class Stitcher {
     std::string defaultCamParams_;
     std::vector<int> cut_;
     int frame_ = 0;
+    pano_status status_ = PANO_OK;
 };
 
 }  // namespace pano

@@ -244,6 +244,15 @@ pano_status pano_stack_finalcut(pano_ctx* ctx, const uint8_t* d_up, int up_w, in
                                 const uint8_t* d_down, int down_w, int down_h, size_t down_stride, int finalcut,
                                 uint8_t* d_out, size_t out_stride, void* hip_stream);
 
+/* the same two on host cv::Mat-style buffers (what master.cpp / panocamimpl.cpp hold after process() returned): upload,
+ * stack, download, synchronous.  h_out: down_w x 2*down_h, resp. min_w x 2*(min_h - 2*finalcut) */
+pano_status pano_stack_master_host(pano_ctx* ctx, const uint8_t* h_up, int up_w, int up_h, size_t up_stride,
+                                   const uint8_t* h_down, int down_w, int down_h, size_t down_stride,
+                                   uint8_t* h_out, size_t out_stride);
+pano_status pano_stack_finalcut_host(pano_ctx* ctx, const uint8_t* h_up, int up_w, int up_h, size_t up_stride,
+                                     const uint8_t* h_down, int down_w, int down_h, size_t down_stride, int finalcut,
+                                     uint8_t* h_out, size_t out_stride);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 enum { PANO_STAGE_WARP = 0, PANO_STAGE_PYRAMID = 1, PANO_STAGE_BLEND = 2, PANO_NUM_STAGES = 3 };
 /* when enabled, hipEvents bracket each stage on the launch stream */

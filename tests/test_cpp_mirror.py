@@ -53,13 +53,31 @@ def test_replay_frames_on_gpu(replay_bin, rig_r, tmp_path):
     cfg = write_cfgs(tmp_path, rig_r)
     r = subprocess.run([replay_bin, str(cfg), "--frames", "2"], capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 0, r.stderr + r.stdout
-    assert "wrote final.ppm 1430x500" in r.stdout
-    assert os.path.getsize(tmp_path / "final.ppm") > 1430 * 500 * 3
+    assert "wrote final.ppm 1470x500" in r.stdout
+    assert os.path.getsize(tmp_path / "final.ppm") > 1470 * 500 * 3
+    # the REAL rig-R frames (2222/4cam/0..3.png as committed fixtures) through the whole C++ flow - init(yaml) x2, calibration
+    # (graph-cut masks), two process() threads, pano_stack_master_host - must give the oracle's stacked image byte for byte
+    import numpy as np
+    from conftest import GOLDEN, load_png_bgr
+    ppms = []
+    for i in range(4):
+        a = load_png_bgr(os.path.join(GOLDEN, f"r_cam{i}.png"))[:, :, ::-1]
+        p = tmp_path / f"r{i}.ppm"
+        with open(p, "wb") as f:
+            f.write(b"P6\n960 540\n255\n" + np.ascontiguousarray(a).tobytes())
+        ppms.append(str(p))
+    r = subprocess.run([replay_bin, str(cfg), "--frames", "2"] + ppms, capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr + r.stdout
+    raw = open(tmp_path / "final.ppm", "rb").read()
+    head = b"P6\n1470 500\n255\n"
+    assert raw.startswith(head)
+    got = np.frombuffer(raw[len(head):], np.uint8).reshape(500, 1470, 3)[:, :, ::-1]
+    assert np.array_equal(got, load_png_bgr(os.path.join(GOLDEN, "r_stacked.png")))
     # exposure compensation on: calibration() estimates the block gains (seam-scale tiles of rig R are about 340 x 218
     # -> 11 x 7 blocks of 32), process() applies them
     r = subprocess.run([replay_bin, str(cfg), "--exposure", "--frames", "1"], capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 0, r.stderr + r.stdout
-    assert "stitcher 0: exposure gain maps 11x7 blocks" in r.stdout and "wrote final.ppm 1430x500" in r.stdout
+    assert "stitcher 0: exposure gain maps 11x7 blocks" in r.stdout and "wrote final.ppm 1470x500" in r.stdout
     # the geometry-only Voronoi seam finder instead of the reference's graph cut
     r = subprocess.run([replay_bin, str(cfg), "--voronoi", "--frames", "1"], capture_output=True, text=True, cwd=tmp_path)
-    assert r.returncode == 0 and "wrote final.ppm 1430x500" in r.stdout, r.stderr + r.stdout
+    assert r.returncode == 0 and "wrote final.ppm 1470x500" in r.stdout, r.stderr + r.stdout

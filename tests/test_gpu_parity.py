@@ -444,6 +444,9 @@ def test_caller_side_assembly(pano, po, torch, c1):
         ctx.stack_finalcut(tu.data_ptr(), uw, uh, uw * 3, td.data_ptr(), dw, dh, dw * 3, 4, out2.data_ptr(), w * 3, s)
         torch.cuda.synchronize()
         assert np.array_equal(out2.cpu().numpy(), po.stack_finalcut(up, down, 4))
+        # the same on host buffers (what master.cpp holds after process())
+        assert np.array_equal(ctx.stack_master_host(up, down), po.stack_master(up, down))
+        assert np.array_equal(ctx.stack_finalcut_host(up, down, 4), po.stack_finalcut(up, down, 4))
 
 
 def test_streaming_slots(pano, po, c1):
