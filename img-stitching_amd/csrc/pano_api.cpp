@@ -88,6 +88,7 @@ struct pano_ctx {
     long long k1_blocks[kMaxCams] = {}, k1_flagged[kMaxCams] = {};
     bool use_lut = true;
     uint16_t* owner[kMaxLevels] = {};
+    uint8_t* small_live = nullptr;   // CanvasParams::small_live
     float* wsum[kMaxLevels] = {};
     int16_t* canvas[kMaxLevels] = {};
 
@@ -231,6 +232,7 @@ void free_device(pano_ctx* c) {
         dfree(c->stage_in[i]);
         for (int l = 0; l < kMaxLevels; l++) dfree(c->wgt[i][l]);
     }
+    dfree(c->small_live);
     for (int l = 0; l < kMaxLevels; l++) {
         dfree(c->owner[l]);
         dfree(c->wsum[l]);
@@ -529,6 +531,7 @@ pano_status ensure_weights(pano_ctx* c, hipStream_t s) {
     // owner maps of the vector levels
     for (int l = 0; l <= P.bands; l++)
         if (c->cv.fast[l]) launch_build_owner(c->pyr, c->cv, l, c->owner[l], s);
+    if (c->cv.small_fused) launch_small_live(c->pyr, c->cv, c->small_live, s);
     HIP_TRY(c, hipGetLastError());
     // one-time: later frames may run on other streams (frame slots) and must find the weights complete
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -1170,6 +1173,16 @@ static pano_status prepare_impl(pano_ctx* c) {
         while (k <= P.bands && c->cv.fast[k]) k++;
         if (k >= 1 && P.bands - k + 1 >= 2) c->cv.small_base = k;
     }
+    // ... or as ONE launch that builds the camera levels above small_base itself (small_fused_kernel), when there are at
+    // most four of them.  Opt-in (PANO_SMALL_FUSED=1): bit-exact, 8 launches per frame instead of 11, but as measured on
+    // config 2 its halo recomputation costs 28 us where the four launches it replaces take 24
+    c->cv.small_fused = c->cv.small_base > 0 && P.bands - c->cv.small_base + 1 <= kSmallFusedMaxLevels &&
+                        getenv("PANO_SMALL_FUSED") && atoi(getenv("PANO_SMALL_FUSED")) == 1;
+    if (c->cv.small_fused) {
+        c->cv.w0 = P.canvas.w; c->cv.h0 = P.canvas.h;  // (set again below with the rest)
+        HIP_TRY(c, hipMalloc((void**)&c->small_live, small_live_bytes(c->cv)));
+        c->cv.small_live = c->small_live;
+    }
     c->full_tiles = getenv("PANO_FULL_TILES") && atoi(getenv("PANO_FULL_TILES"));
     live_rects(c, {});  // no masks yet: every pixel of every level is live
     c->cv.cam_lo = 0;
@@ -1544,6 +1557,10 @@ pano_status pano_warp_mask(pano_ctx* c, int i, uint8_t* d_dst, size_t dst_stride
     return PANO_OK;
 }
 
+// pyrDown launches per frame: every level, or - when the small levels run fused - only up to small_base (the fused kernel
+// builds the levels above it in LDS)
+static int pyr_levels(const pano_ctx* c) { return c->cv.small_fused ? c->cv.small_base : c->plan.bands; }
+
 pano_status pano_feed_cameras(pano_ctx* c, unsigned cam_bits, const uint8_t* const* d_frames, const size_t* strides,
                               void* stream) {
     pano_status st = check_compute(c);
@@ -1578,7 +1595,7 @@ pano_status pano_feed_cameras(pano_ctx* c, unsigned cam_bits, const uint8_t* con
     } else {
         launch_warp_tiles(wp, k, mw, mh, s);
     }
-    for (int l = 0; l < P.bands; l++) launch_pyr_down(c->pyr, cam_bits, l, s);
+    for (int l = 0; l < pyr_levels(c); l++) launch_pyr_down(c->pyr, cam_bits, l, s);
     if (c->profiling && (st = record(c, 2, s)) != PANO_OK) return st;
     HIP_TRY(c, hipGetLastError());
     return PANO_OK;
@@ -1717,9 +1734,9 @@ pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b, const uint8_t* const* fa
     // diagnostic (wrong pictures, timing only): what would fewer pyramid launches be worth?  PANO_PYR_LEVELS=n launches only
     // the first n levels
     static const int kpyr = getenv("PANO_PYR_LEVELS") ? atoi(getenv("PANO_PYR_LEVELS")) : 99;
-    for (int l = 0; l < A.bands && l < kpyr; l++) launch_pyr_down(pp, all, l, s);
+    for (int l = 0; l < pyr_levels(a) && l < kpyr; l++) launch_pyr_down(pp, all, l, s);
 #else
-    for (int l = 0; l < A.bands; l++) launch_pyr_down(pp, all, l, s);
+    for (int l = 0; l < pyr_levels(a); l++) launch_pyr_down(pp, all, l, s);
 #endif
     if (prof && (st = record(a, 2, s)) != PANO_OK) return st;
     // K3: both canvases per launch
@@ -2180,6 +2197,9 @@ pano_status pano_debug_get_level(pano_ctx* c, int i, int level, int16_t* h_dst, 
     *w = c->plan.tile[i].rect.w >> level;
     *h = c->plan.tile[i].rect.h >> level;
     if (!h_dst) return PANO_OK;
+    HIP_TRY(c, hipDeviceSynchronize());
+    // with the small levels fused, camera levels above small_base only ever exist in LDS: build them for the inspection
+    for (int l = pyr_levels(c); l < level; l++) launch_pyr_down(c->pyr, 1u << i, l, nullptr);
     HIP_TRY(c, hipDeviceSynchronize());
     std::vector<uint8_t> tmp((size_t)*w * *h);
     for (int pl = 0; pl < 3; pl++) {  // planar u8 on the device -> CV_16SC3 for the caller

@@ -1739,6 +1739,264 @@ __global__ __launch_bounds__(256) void collapse_small_kernel(CanvasSet CS) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The small levels in ONE launch (CanvasParams::small_fused): camera pyramid levels small_base+1 .. bands, the camera half
+// of the blend (norm_l) and the collapse chain, per 32 x 8 tile of canvas level small_base, all through LDS.
+// Replaces, per frame, the pyrDown launches above level small_base, norm_small_kernel and collapse_small_kernel - launches
+// of 3 - 9 us each with almost no work (a dependent launch costs ~4 us before it does anything).  The price is recomputation:
+// a tile needs G_{k0+1} over its pyrUp footprint, which needs G_{k0} over the pyrDown footprint of that, and so on
+// (53 x 29 pixels of G_{k0} for a 32 x 8 tile with three small levels) - a few thousand byte-sized taps per workgroup.
+// Same arithmetic as pyr_down_kernel / norm_small_kernel / collapse_small_kernel, bit for bit; camera levels above
+// small_base are not written to memory at all (pano_debug_get_level builds them on demand).
+//
+// LDS boxes per live camera: level j (= k0 + j) is held over the REAL pixel range need_j that anything consumes, padded by
+// 2 on every side in VIRTUAL coordinates: cell v holds G(reflect101(v)), so the pyrDown of the next level reads 5 x 5
+// windows with no border logic.  Box x origins are multiples of 4 and window origins even, so a 5-tap window is two LDS
+// dwords, one v_alignbyte and one v_dot4.
+constexpr int kFuseMaxJ = 3;            // at most four fused levels (k0 .. k0 + 3)
+constexpr int kFuseLdsBytes = 12 << 10; // >= the worst-case boxes of one plane for J = 3 (85 x 61 pixels of G_{k0} -> 92 x 65 bytes, 48 x 33, 28 x 17, 16 x 9)
+struct FuseBox {
+    int x0, y0, x1, y1;   // need: real pixel range, inclusive (x1 < x0: empty)
+    int bx0, by0, bw, bh; // LDS box: virtual origin, row pitch in bytes (multiple of 4), rows
+    int off;              // byte offset in LDS
+};
+// one byte per (tile, canvas): the cameras that carry weight anywhere on the tile's footprint at any fused level.  Static
+// (it follows the masks), so the fused kernel knows at once whose pixels to fetch - no weight round trip in front of the loads
+__global__ __launch_bounds__(256) void small_live_kernel(PyrParams P, CanvasParams C, uint8_t* table) {
+    const int k0 = C.small_base, J = C.bands - k0;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int tx = tid & 31, ty = tid >> 5;
+    const int cw = C.w0 >> k0, ch = C.h0 >> k0;
+    int x0 = blockIdx.x * kSmallTileW, y0 = blockIdx.y * kSmallTileH;
+    int x1 = min(x0 + kSmallTileW, cw) - 1, y1 = min(y0 + kSmallTileH, ch) - 1;
+    int bits = 0;
+    for (int j = 0; j <= J; j++) {
+        const int l = k0 + j;
+        if (tx <= x1 - x0 && ty <= y1 - y0)
+            for (int i = 0; i < C.cam_n; i++) {
+                const PyrCam& c = P.cam[C.cam_lo + i];
+                const int x = x0 + tx - (c.tx >> l), y = y0 + ty - (c.ty >> l);
+                if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l) && cam_weight(c, l, x, y) != 0.f) bits |= 1 << i;
+            }
+        const int nw = C.w0 >> (l + 1), nh = C.h0 >> (l + 1);
+        x0 = max((x0 >> 1) - 1, 0); y0 = max((y0 >> 1) - 1, 0);
+        x1 = min((x1 >> 1) + 1, max(nw - 1, 0)); y1 = min((y1 >> 1) + 1, max(nh - 1, 0));
+    }
+    // (__syncthreads_or answers "any lane non-zero", not the OR of the values)
+    __shared__ int all_bits;
+    if (tid == 0) all_bits = 0;
+    __syncthreads();
+    if (bits) atomicOr(&all_bits, bits);
+    __syncthreads();
+    if (tid == 0) table[blockIdx.y * gridDim.x + blockIdx.x] = (uint8_t)all_bits;
+}
+void launch_small_live(const PyrParams& p, const CanvasParams& c, uint8_t* table, hipStream_t s) {
+    const int cw = c.w0 >> c.small_base, ch = c.h0 >> c.small_base;
+    dim3 block(64, 4, 1), grid((cw + kSmallTileW - 1) / kSmallTileW, (ch + kSmallTileH - 1) / kSmallTileH, 1);
+    hipLaunchKernelGGL(small_live_kernel, grid, block, 0, s, p, c, table);
+}
+
+// grid.z = canvas * 3 + plane: a workgroup does ONE colour plane of its tile (three times the workgroups, a third of the
+// serial work in each: the kernel's duration is the length of one workgroup's chain of barrier-separated phases)
+__global__ __launch_bounds__(256) void small_fused_kernel(PyrParams P, CanvasSet CS) {
+    const CanvasParams& C = CS.c[blockIdx.z / 3];
+    const int pl = blockIdx.z % 3;
+    __shared__ __attribute__((aligned(16))) uint8_t box_lds[kFuseLdsBytes];
+    __shared__ int16_t lds[kSmallLdsElems];
+    const int k0 = C.small_base, nb = C.bands, J = nb - k0;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int tx = tid & 31, ty = tid >> 5;
+    const unsigned livebits = C.small_live[blockIdx.y * gridDim.x + blockIdx.x];
+    // canvas footprints of this workgroup's tile at every fused level (block-uniform: scalar registers)
+    int rx0[kFuseMaxJ + 1], ry0[kFuseMaxJ + 1], rw[kFuseMaxJ + 1], rh[kFuseMaxJ + 1], ro[kFuseMaxJ + 1];
+    {
+        const int cw = C.w0 >> k0, ch = C.h0 >> k0;
+        int x0 = blockIdx.x * kSmallTileW, y0 = blockIdx.y * kSmallTileH;
+        int x1 = min(x0 + kSmallTileW, cw) - 1, y1 = min(y0 + kSmallTileH, ch) - 1;
+        int o = 0;
+#pragma unroll
+        for (int j = 0; j <= kFuseMaxJ; j++) {
+            const int l = k0 + j;
+            rx0[j] = x0; ry0[j] = y0; rw[j] = x1 - x0 + 1; rh[j] = y1 - y0 + 1;
+            ro[j] = o;
+            if (j > 0) o += rw[j] * rh[j];
+            const int nw = C.w0 >> (l + 1), nh = C.h0 >> (l + 1);
+            x0 = max((x0 >> 1) - 1, 0); y0 = max((y0 >> 1) - 1, 0);
+            x1 = min((x1 >> 1) + 1, max(nw - 1, 0)); y1 = min((y1 >> 1) + 1, max(nh - 1, 0));
+        }
+    }
+    int acc[kFuseMaxJ + 1];
+    float W[kFuseMaxJ + 1];
+#pragma unroll
+    for (int j = 0; j <= kFuseMaxJ; j++) {
+        W[j] = 0.f;
+        acc[j] = 0;
+    }
+    bool first = true;
+#pragma unroll
+    for (int i = 0; i < kCams; i++) {  // feed order
+        if (!((livebits >> i) & 1u)) continue;  // block-uniform
+        const PyrCam& c = P.cam[C.cam_lo + i];
+        // this lane's weight at its pixel of every level (0 outside the camera's tile): in flight with the pixel loads below
+        float wv[kFuseMaxJ + 1];
+#pragma unroll
+        for (int j = 0; j <= kFuseMaxJ; j++) {
+            wv[j] = 0.f;
+            if (j <= J && tx < rw[j] && ty < rh[j]) {
+                const int l = k0 + j;
+                const int x = rx0[j] + tx - (c.tx >> l), y = ry0[j] + ty - (c.ty >> l);
+                if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l)) wv[j] = cam_weight(c, l, x, y);
+            }
+        }
+        if (!first) __syncthreads();  // the previous camera's boxes stay until every lane has read its taps
+        first = false;
+        // what is needed of every camera level, coarse to fine (block-uniform)
+        FuseBox B[kFuseMaxJ + 1];
+        {
+            int off = 0;
+#pragma unroll
+            for (int j = kFuseMaxJ; j >= 0; j--) {
+                if (j > J) continue;
+                const int l = k0 + j;
+                const int dw = c.w0 >> l, dh = c.h0 >> l;
+                FuseBox b;
+                b.x0 = max(rx0[j] - (c.tx >> l), 0); b.y0 = max(ry0[j] - (c.ty >> l), 0);
+                b.x1 = min(rx0[j] + rw[j] - 1 - (c.tx >> l), dw - 1); b.y1 = min(ry0[j] + rh[j] - 1 - (c.ty >> l), dh - 1);
+                if (b.x1 < b.x0 || b.y1 < b.y0) { b.x0 = b.y0 = 0; b.x1 = b.y1 = -1; }
+                constexpr int jn_max = kFuseMaxJ;
+                const int jn = j + 1 <= jn_max ? j + 1 : j;
+                if (j < J && B[jn].x1 >= B[jn].x0) {
+                    const FuseBox& n = B[jn];
+                    const int fx0 = max(2 * n.x0 - 2, 0), fy0 = max(2 * n.y0 - 2, 0);
+                    const int fx1 = min(2 * n.x1 + 2, dw - 1), fy1 = min(2 * n.y1 + 2, dh - 1);
+                    if (b.x1 < b.x0) { b.x0 = fx0; b.y0 = fy0; b.x1 = fx1; b.y1 = fy1; }
+                    else { b.x0 = min(b.x0, fx0); b.y0 = min(b.y0, fy0); b.x1 = max(b.x1, fx1); b.y1 = max(b.y1, fy1); }
+                }
+                b.bx0 = (b.x0 - 2) & ~3; b.by0 = b.y0 - 2;
+                b.bw = b.x1 >= b.x0 ? ((b.x1 + 2 - b.bx0 + 1 + 3) & ~3) : 0;
+                b.bh = b.x1 >= b.x0 ? b.y1 + 2 - b.by0 + 1 : 0;
+                b.off = off;
+                off += b.bw * b.bh;
+                B[j] = b;
+            }
+        }
+        // level k0: global -> LDS, four virtual columns per lane and step (lanes = 32 column groups x 8 rows: no divisions);
+        // the loads of a lane (at most 9 rows) are all issued before the first is stored
+        {
+            const FuseBox& b = B[0];
+            const int dw = c.w0 >> k0, dh = c.h0 >> k0;
+            const int gpr = b.bw >> 2;  // <= 23 column groups
+            constexpr int kRowSteps = 9;  // box rows <= 65
+            const uint8_t* plane = c.lvl[k0] + (size_t)pl * c.plane[k0];
+            if (tx < gpr) {
+                const int vx = b.bx0 + 4 * tx;
+                const bool inside = vx >= 0 && vx + 3 < dw;
+                unsigned d[kRowSteps];
+                if (inside) {
+#pragma unroll
+                    for (int k = 0; k < kRowSteps; k++) {
+                        const int cy = ty + 8 * k;
+                        const unsigned rowoff = (unsigned)reflect101_idx(b.by0 + min(cy, b.bh - 1), dh) * (unsigned)c.pitch[k0] + (unsigned)vx;
+                        d[k] = *reinterpret_cast<const unsigned*>(plane + rowoff);
+                    }
+                } else {
+                    int xr[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) xr[q] = reflect101_idx(vx + q, dw);
+#pragma unroll
+                    for (int k = 0; k < kRowSteps; k++) {
+                        const int cy = ty + 8 * k;
+                        const uint8_t* row = plane + (unsigned)reflect101_idx(b.by0 + min(cy, b.bh - 1), dh) * (unsigned)c.pitch[k0];
+                        d[k] = (unsigned)row[xr[0]] | ((unsigned)row[xr[1]] << 8) | ((unsigned)row[xr[2]] << 16) | ((unsigned)row[xr[3]] << 24);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kRowSteps; k++) {
+                    const int cy = ty + 8 * k;
+                    if (cy < b.bh) *reinterpret_cast<unsigned*>(box_lds + b.off + cy * b.bw + 4 * tx) = d[k];
+                }
+            }
+        }
+        __syncthreads();
+        // levels k0+1 .. nb: pyrDown LDS -> LDS, one cell (pads included) per lane and step (lanes = 64 columns x 4 rows)
+#pragma unroll
+        for (int j = 1; j <= kFuseMaxJ; j++) {
+            if (j > J) continue;
+            const FuseBox& b = B[j];
+            const FuseBox& a = B[j - 1];
+            const int l = k0 + j;
+            const int dw = c.w0 >> l, dh = c.h0 >> l;
+            const int cx = threadIdx.x;  // box rows are at most 48 bytes
+            if (cx < b.bw) {
+                const int qx = reflect101_idx(b.bx0 + cx, dw);
+                const bool xin = qx >= b.x0 && qx <= b.x1;
+                const int col = 2 * qx - 2 - a.bx0;  // even; the window is bytes col .. col + 4 of the row
+                const unsigned sh = (unsigned)col & 3u;
+                for (int cy = threadIdx.y; cy < b.bh; cy += 4) {
+                    const int qy = reflect101_idx(b.by0 + cy, dh);
+                    int out = 0;
+                    if (xin && qy >= b.y0 && qy <= b.y1) {
+                        const uint8_t* S = box_lds + a.off + (2 * qy - 2 - a.by0) * a.bw + (col & ~3);
+                        int v = 128;
+#pragma unroll
+                        for (int t = 0; t < 5; t++) {
+                            const unsigned d0 = *reinterpret_cast<const unsigned*>(S + t * a.bw);
+                            const unsigned d1 = *reinterpret_cast<const unsigned*>(S + t * a.bw + 4);
+                            const unsigned lo4 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                            const unsigned t5 = (d1 >> (8 * sh)) & 0xffu;
+                            const int h = (int)__builtin_amdgcn_udot4(lo4, 0x04060401u, t5, false);
+                            v += h * (t == 0 || t == 4 ? 1 : (t == 2 ? 6 : 4));
+                        }
+                        out = v >> 8;  // no saturate: the taps sum to 256
+                    }
+                    box_lds[b.off + cy * b.bw + cx] = (uint8_t)out;
+                }
+            }
+            __syncthreads();
+        }
+        // this camera's weighted Laplacian at the lane's pixel of every level
+#pragma unroll
+        for (int j = 0; j <= kFuseMaxJ; j++) {
+            if (j > J || wv[j] == 0.f) continue;
+            const int l = k0 + j;
+            const FuseBox& b = B[j];
+            const int x = rx0[j] + tx - (c.tx >> l), y = ry0[j] + ty - (c.ty >> l);
+            W[j] += wv[j];
+            int lap = box_lds[b.off + (y - b.by0) * b.bw + (x - b.bx0)];
+            if (j < J) {
+                const FuseBox& u = B[j + 1 <= kFuseMaxJ ? j + 1 : j];
+                const uint8_t* S = box_lds + u.off - u.by0 * u.bw - u.bx0;  // (0, 0) of the real plane
+                lap = sat16i(lap - pyr_up_px<uint8_t>(S, (c.w0 >> l) >> 1, (c.h0 >> l) >> 1, u.bw, x, y));
+            }
+            acc[j] = (int16_t)(acc[j] + (int16_t)(int)((float)lap * wv[j]));
+        }
+    }
+    __syncthreads();
+    // norm_l, then the collapse chain coarse -> fine through LDS (collapse_small_kernel's phase 2)
+#pragma unroll
+    for (int j = kFuseMaxJ; j >= 0; j--) {
+        if (j > J) continue;  // block-uniform
+        const int l = k0 + j;
+        const int cw = C.w0 >> l, ch = C.h0 >> l;
+        const int nx = cw >> 1, ny = ch >> 1;
+        if (tx < rw[j] && ty < rh[j]) {
+            const int X = rx0[j] + tx, Y = ry0[j] + ty;
+            int v;
+            if (W[j] == 1.0f) v = toward_zero_by_one(acc[j]);
+            else v = (int16_t)(int)((float)acc[j] / (W[j] + 1e-5f));
+            if (j < J) {
+                const int jc = j + 1 <= kFuseMaxJ ? j + 1 : j;
+                // out_{l+1} over its footprint, as a plane whose (0, 0) is canvas pixel (0, 0) of that level
+                const int16_t* S = lds + ro[jc] - ry0[jc] * rw[jc] - rx0[jc];
+                v = sat16i(v + pyr_up_px<int16_t>(S, nx, ny, rw[jc], X, Y));
+            }
+            if (j > 0) lds[ro[j] + ty * rw[j] + tx] = (int16_t)v;
+            else C.img[l][(size_t)pl * C.cplane[l] + (size_t)Y * C.cpitch[l] + X] = (int16_t)v;
+        }
+        __syncthreads();
+    }
+}
+
 void launch_blend_small(const PyrParams& p, const CanvasSet& cs, hipStream_t s) {
     const CanvasParams& c = cs.c[0];
     const int k0 = c.small_base;
@@ -1748,6 +2006,11 @@ void launch_blend_small(const PyrParams& p, const CanvasSet& cs, hipStream_t s) 
         ch = max(ch, cs.c[g].h0 >> k0);
     }
     dim3 block(64, 4, 1);
+    if (c.small_fused) {
+        dim3 gf((cw + kSmallTileW - 1) / kSmallTileW, (ch + kSmallTileH - 1) / kSmallTileH, cs.n * 3);
+        hipLaunchKernelGGL(small_fused_kernel, gf, block, 0, s, p, cs);
+        return;
+    }
     dim3 g1((cw + 63) / 64, (ch + 3) / 4, (c.bands - k0 + 1) * cs.n);
     hipLaunchKernelGGL(norm_small_kernel, g1, block, 0, s, p, cs);
     dim3 g2((cw + kSmallTileW - 1) / kSmallTileW, (ch + kSmallTileH - 1) / kSmallTileH, cs.n);

@@ -92,6 +92,9 @@ struct CanvasParams {
                                // 0xFF mixed; high byte = bit i set when camera i carries weight anywhere on the block
     int opitch[kLevels];       // owner entries per block row
     int small_base;            // >0: levels small_base..bands run as one normalise launch + one LDS collapse launch
+    int small_fused;           // 1: ... and as ONE launch (small_fused_kernel) that also builds the camera levels above
+                               // small_base itself: the per-frame pyrDown chain stops at level small_base
+    const uint8_t* small_live; // small_fused: per 32 x 8 tile of level small_base, the cameras with weight on its footprint
     int cam_lo, cam_n;         // this canvas blends cameras [cam_lo, cam_lo + cam_n) of the PyrParams it is launched with
     int w0, h0;                // padded canvas size
     int bands;
@@ -128,8 +131,14 @@ void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s
 // K3: one blend level for the whole canvas (Laplacian, weight, accumulate, normalise, collapse);
 // level 0 writes the cut 8U panorama
 void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStream_t s);
-// the small levels small_base..bands in two launches
+// the small levels small_base..bands in two launches (one when CanvasParams::small_fused)
+constexpr int kSmallFusedMaxLevels = 4;   // small_fused_kernel handles bands - small_base + 1 <= 4 levels
 void launch_blend_small(const PyrParams& p, const CanvasSet& cs, hipStream_t s);
+// the live-camera table of small_fused_kernel (run when masks change): one byte per 32 x 8 tile of level small_base
+void launch_small_live(const PyrParams& p, const CanvasParams& c, uint8_t* table, hipStream_t s);
+inline size_t small_live_bytes(const CanvasParams& c) {
+    return (size_t)(((c.w0 >> c.small_base) + 31) / 32) * (((c.h0 >> c.small_base) + 7) / 8);
+}
 // owner map of a vector level (run when masks change)
 void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint16_t* owner, hipStream_t s);
 // Blender::NO path
