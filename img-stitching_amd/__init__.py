@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("PANO_LIB") or os.path.join(_HERE, "libpano_hip.so")
 
 SPHERICAL, CYLINDRICAL = 0, 1
 BANDS_NO_BLEND, BANDS_FROM_STRENGTH = -1, -2
+NUM_STAGES = 4   # PANO_NUM_STAGES: warp, pyramid, blend, level-0 blend launch alone
 RET_OK, RET_ERR = 0, -1
 MAX_CAMS = 8
 
@@ -87,7 +88,7 @@ EXPORTS = [
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_get_camera", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
     "pano_build_masks_voronoi", "pano_build_masks_graphcut", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
-    "pano_compose_host", "pano_host_alloc", "pano_host_free", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_stack_master", "pano_stack_finalcut", "pano_stack_master_host", "pano_stack_finalcut_host", "pano_stream_input", "pano_stream_output",
+    "pano_compose_host", "pano_host_alloc", "pano_host_free", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_rccl_unique_id", "pano_rccl_comm_create", "pano_rccl_comm_destroy", "pano_gather_slots", "pano_stack_master", "pano_stack_finalcut", "pano_stack_master_host", "pano_stack_finalcut_host", "pano_stream_input", "pano_stream_output",
     "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
     "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_get_live_rect", "pano_get_live_gap", "pano_get_warp_table_stats", "pano_debug_get_level", "pano_debug_get_weights",
     "pano_debug_get_canvas_weights", "pano_debug_get_canvas",
@@ -342,6 +343,28 @@ class Context:
                                               C.c_size_t(d_stride), int(finalcut), _vp(d_out), C.c_size_t(out_stride),
                                               _vp(stream)))
 
+    # -- the sharded exchange over RCCL (one process per GPU)
+    @staticmethod
+    def rccl_unique_id():
+        """128 bytes from ncclGetUniqueId, to be handed to every rank (e.g. torch.distributed.broadcast_object_list)"""
+        buf = (C.c_char * 128)()
+        st = load_library().pano_rccl_unique_id(buf)
+        if st != 0:
+            raise PanoError(st, "pano_rccl_unique_id (is librccl.so there?)")
+        return bytes(buf)
+
+    def rccl_comm_create(self, unique_id, world, rank):
+        comm = C.c_void_p()
+        self._ck(self.lib.pano_rccl_comm_create(self.h, C.c_char_p(unique_id), int(world), int(rank), C.byref(comm)))
+        return comm
+
+    def rccl_comm_destroy(self, comm):
+        self.lib.pano_rccl_comm_destroy(comm)
+
+    def gather_slots(self, comm, rank, root, owner_rank, stream=0):
+        arr = (C.c_int * self.n)(*[int(r) for r in owner_rank])
+        self._ck(self.lib.pano_gather_slots(self.h, comm, int(rank), int(root), arr, _vp(stream)))
+
     def stack_master_host(self, up, down):
         """master.cpp:321-326 on host arrays"""
         up = np.ascontiguousarray(up, np.uint8); down = np.ascontiguousarray(down, np.uint8)
@@ -366,10 +389,10 @@ class Context:
         self._ck(self.lib.pano_set_profiling(self.h, int(bool(on))))
 
     def stage_ms(self):
-        ms = (C.c_float * 3)(); self._ck(self.lib.pano_get_stage_ms(self.h, ms)); return tuple(ms)
+        ms = (C.c_float * NUM_STAGES)(); self._ck(self.lib.pano_get_stage_ms(self.h, ms)); return tuple(ms)
 
     def stage_stats(self, reset=True):
-        ms = (C.c_double * 3)(); n = (C.c_uint64 * 3)()
+        ms = (C.c_double * NUM_STAGES)(); n = (C.c_uint64 * NUM_STAGES)()
         self._ck(self.lib.pano_get_stage_stats(self.h, ms, n, int(bool(reset)))); return tuple(ms), tuple(n)
 
     def warp_bytes(self):

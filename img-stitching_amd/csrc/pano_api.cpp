@@ -24,6 +24,7 @@
 
 #include "pano_graphcut.hpp"
 #include "pano_hostcopy.hpp"
+#include "pano_rccl.hpp"
 #include "pano_kernels.hpp"
 #include "pano_plan.hpp"
 
@@ -89,6 +90,9 @@ struct pano_ctx {
     bool use_lut = true;
     uint16_t* owner[kMaxLevels] = {};
     uint8_t* small_live = nullptr;   // CanvasParams::small_live
+    uint16_t* order0 = nullptr;      // CanvasParams::order0
+    size_t order_cap = 0;
+    bool order_dirty = false;
     float* wsum[kMaxLevels] = {};
     int16_t* canvas[kMaxLevels] = {};
 
@@ -139,7 +143,7 @@ struct pano_ctx {
     // profiling: a ring of event quads so that the timed loop never has to wait for the GPU
     static constexpr int kEvRing = 64;
     struct EvSlot {
-        hipEvent_t e[PANO_NUM_STAGES + 1];
+        hipEvent_t e[6];  // 0..3: K1 begin, K1 end, pyramid end, blend end; 4, 5: begin / end of the level-0 blend dispatch
         unsigned recorded;
     };
     bool profiling = false;
@@ -233,6 +237,8 @@ void free_device(pano_ctx* c) {
         for (int l = 0; l < kMaxLevels; l++) dfree(c->wgt[i][l]);
     }
     dfree(c->small_live);
+    dfree(c->order0);
+    c->order_cap = 0;
     for (int l = 0; l < kMaxLevels; l++) {
         dfree(c->owner[l]);
         dfree(c->wsum[l]);
@@ -509,8 +515,57 @@ pano_status upload_gain_tables(pano_ctx* c, int i, const float* h_gain) {
 }
 
 // weight pyramids + canvas weight sums; runs when masks changed
+// dispatch order of the level-0 blend tiles: inside every XCD band the tiles with a general-path wave first (static: it follows
+// the owner map and the cut).  PANO_L0_ORDER=0 keeps the plain band order
+pano_status build_tile_order(pano_ctx* c, hipStream_t s) {
+    c->order_dirty = false;
+    c->cv.order0 = nullptr;
+    c->cv.order_per = c->cv.order_gx = 0;
+    static const bool off = getenv("PANO_L0_ORDER") && atoi(getenv("PANO_L0_ORDER")) == 0;
+    if (off || c->plan.bands < 0 || !c->cv.fast[0]) return PANO_OK;
+    const CanvasParams& cv = c->cv;
+    const int w = cv.cut_x + cv.cut_w - (cv.cut_x & ~3), h = cv.cut_y + cv.cut_h - (cv.cut_y & ~1);
+    const int gx = (w + 127) / 128, gy = (h + 15) / 16;
+    const size_t T = (size_t)gx * gy;
+    if (T == 0 || T >= 0xffffu) return PANO_OK;
+    const size_t per = (T + 7) / 8;
+    uint8_t* d_flags = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_flags, T));
+    launch_tile_mixed(cv, gx, gy, d_flags, s);
+    std::vector<uint8_t> flags(T);
+    hipError_t fe = hipMemcpyAsync(flags.data(), d_flags, T, hipMemcpyDeviceToHost, s);
+    if (fe == hipSuccess) fe = hipStreamSynchronize(s);
+    (void)hipFree(d_flags);
+    HIP_TRY(c, fe);
+    std::vector<uint16_t> order(8 * per, 0xffffu);
+    for (size_t k = 0; k < 8; k++) {
+        const size_t lo = k * per, hi = std::min(T, lo + per);
+        size_t o = lo;
+        for (int pass = 1; pass >= 0; pass--)
+            for (size_t t = lo; t < hi; t++)
+                if (flags[t] == pass) order[o++] = (uint16_t)t;
+    }
+    if (c->order_cap < order.size()) {
+        dfree(c->order0);
+        c->order_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->order0, order.size() * sizeof(uint16_t)));
+        c->order_cap = order.size();
+    }
+    HIP_TRY(c, hipMemcpy(c->order0, order.data(), order.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    c->cv.order0 = c->order0;
+    c->cv.order_per = (int)per;
+    c->cv.order_gx = gx;
+    return PANO_OK;
+}
+
 pano_status ensure_weights(pano_ctx* c, hipStream_t s) {
-    if (!c->weights_dirty) return PANO_OK;
+    if (!c->weights_dirty) {
+        if (c->order_dirty) {  // the cut changed: frames in flight still walk the old table
+            HIP_TRY(c, hipDeviceSynchronize());
+            return build_tile_order(c, s);
+        }
+        return PANO_OK;
+    }
     const Plan& P = c->plan;
     for (int i = 0; i < P.n; i++)
         if (!c->mask_set[i]) return fail(c, PANO_ESTATE, "blend masks not set (pano_set_mask / pano_build_masks_voronoi)");
@@ -532,6 +587,10 @@ pano_status ensure_weights(pano_ctx* c, hipStream_t s) {
     for (int l = 0; l <= P.bands; l++)
         if (c->cv.fast[l]) launch_build_owner(c->pyr, c->cv, l, c->owner[l], s);
     if (c->cv.small_fused) launch_small_live(c->pyr, c->cv, c->small_live, s);
+    {
+        pano_status os = build_tile_order(c, s);
+        if (os != PANO_OK) return os;
+    }
     HIP_TRY(c, hipGetLastError());
     // one-time: later frames may run on other streams (frame slots) and must find the weights complete
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -552,19 +611,22 @@ pano_status harvest_oldest(pano_ctx* c) {
     if (c->ev_count == 0) return PANO_OK;
     int idx = (c->ev_head - c->ev_count + pano_ctx::kEvRing) % pano_ctx::kEvRing;
     pano_ctx::EvSlot& sl = c->ring[idx];
-    for (int k = PANO_NUM_STAGES; k >= 0; k--)
+    for (int k = 3; k >= 0; k--)
         if (sl.recorded & (1u << k)) {
             HIP_TRY(c, hipEventSynchronize(sl.e[k]));
             break;
         }
-    for (int k = 0; k < PANO_NUM_STAGES; k++)
-        if ((sl.recorded & (1u << k)) && (sl.recorded & (1u << (k + 1)))) {
+    if (sl.recorded & (1u << 5)) HIP_TRY(c, hipEventSynchronize(sl.e[5]));
+    for (int k = 0; k < PANO_NUM_STAGES; k++) {
+        const int a = k == PANO_STAGE_BLEND0 ? 4 : k, b = k == PANO_STAGE_BLEND0 ? 5 : k + 1;
+        if ((sl.recorded & (1u << a)) && (sl.recorded & (1u << b))) {
             float ms = 0.f;
-            HIP_TRY(c, hipEventElapsedTime(&ms, sl.e[k], sl.e[k + 1]));
+            HIP_TRY(c, hipEventElapsedTime(&ms, sl.e[a], sl.e[b]));
             c->acc_ms[k] += ms;
             c->acc_n[k]++;
             c->last_ms[k] = ms;
         }
+    }
     sl.recorded = 0;
     c->ev_count--;
     if (c->ev_cur == idx) c->ev_cur = -1;
@@ -1295,6 +1357,7 @@ pano_status pano_set_cut(pano_ctx* c, const int r[4]) {
     drop_graphs(c);
     c->plan.cut = cut;
     c->cv.cut_x = cut.x; c->cv.cut_y = cut.y; c->cv.cut_w = cut.w; c->cv.cut_h = cut.h;
+    c->order_dirty = true;  // the level-0 tile grid lies over the hull of the cut
     return PANO_OK;
 }
 
@@ -1622,7 +1685,16 @@ pano_status pano_blend(pano_ctx* c, uint8_t* d_out, size_t out_stride, void* str
             launch_blend_small(c->pyr, cs, s);
             top = cv.small_base - 1;
         }
-        for (int l = top; l >= 0; l--) launch_blend_level(c->pyr, cs, l, s);
+        if (c->profiling && c->ev_cur < 0 && (st = begin_slot(c)) != PANO_OK) return st;
+        for (int l = top; l >= 0; l--) {
+            if (l == 0 && c->profiling) {
+                pano_ctx::EvSlot& sl = c->ring[c->ev_cur];
+                launch_blend_level(c->pyr, cs, l, s, sl.e[4], sl.e[5]);
+                sl.recorded |= 3u << 4;
+            } else {
+                launch_blend_level(c->pyr, cs, l, s);
+            }
+        }
     }
     if (c->profiling) {
         if (c->ev_cur < 0 && (st = begin_slot(c)) != PANO_OK) return st;
@@ -1757,7 +1829,15 @@ pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b, const uint8_t* const* fa
             launch_blend_small(pp, cs, s);
             top = cs.c[0].small_base - 1;
         }
-        for (int l = top; l >= 0; l--) launch_blend_level(pp, cs, l, s);
+        for (int l = top; l >= 0; l--) {
+            if (l == 0 && prof) {
+                pano_ctx::EvSlot& sl = a->ring[a->ev_cur];
+                launch_blend_level(pp, cs, l, s, sl.e[4], sl.e[5]);
+                sl.recorded |= 3u << 4;
+            } else {
+                launch_blend_level(pp, cs, l, s);
+            }
+        }
     }
     if (prof) {
         if ((st = record(a, 3, s)) != PANO_OK) return st;
@@ -2086,6 +2166,79 @@ pano_status pano_get_pyramid_slots(pano_ctx* c, void** d_base, size_t* slot_byte
     if (!d_base || !slot_bytes) return PANO_EINVAL;
     *d_base = c->pyr_base;
     *slot_bytes = c->slot_bytes;
+    return PANO_OK;
+}
+
+/* ---- the camera-sharded exchange over RCCL (one process per GPU) ------------------------------------------- */
+#define RCCL_TRY(ctx, expr)                                                                      \
+    do {                                                                                         \
+        ncclResult_t r_ = (expr);                                                                \
+        if (r_ != ncclSuccess) {                                                                 \
+            if (ctx) (ctx)->err = std::string(#expr) + ": " + Rccl::get().GetErrorString(r_);   \
+            return PANO_EHIP;                                                                    \
+        }                                                                                        \
+    } while (0)
+
+pano_status pano_rccl_unique_id(char id[PANO_RCCL_ID_BYTES]) {
+    static_assert(PANO_RCCL_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!id) return PANO_EINVAL;
+    Rccl& R = Rccl::get();
+    if (!R.ok) return PANO_ENODEVICE;
+    ncclUniqueId u;
+    if (R.GetUniqueId(&u) != ncclSuccess) return PANO_EHIP;
+    std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return PANO_OK;
+}
+
+pano_status pano_rccl_comm_create(pano_ctx* c, const char id[PANO_RCCL_ID_BYTES], int world, int rank, void** comm) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (!id || !comm || world < 1 || rank < 0 || rank >= world) return PANO_EINVAL;
+    Rccl& R = Rccl::get();
+    if (!R.ok) return fail(c, PANO_ENODEVICE, R.error.c_str());
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t nc = nullptr;
+    RCCL_TRY(c, R.CommInitRank(&nc, world, u, rank));
+    *comm = nc;
+    return PANO_OK;
+}
+
+pano_status pano_rccl_comm_destroy(void* comm) {
+    if (!comm) return PANO_OK;
+    Rccl& R = Rccl::get();
+    if (!R.ok) return PANO_ENODEVICE;
+    return R.CommDestroy((ncclComm_t)comm) == ncclSuccess ? PANO_OK : PANO_EHIP;
+}
+
+pano_status pano_gather_slots(pano_ctx* c, void* comm, int rank, int root, const int* owner_rank, void* stream) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (!comm || !owner_rank || rank < 0 || root < 0) return PANO_EINVAL;
+    Rccl& R = Rccl::get();
+    if (!R.ok) return fail(c, PANO_ENODEVICE, R.error.c_str());
+    const int n = c->plan.n;
+    // consecutive slots with the same peer travel as one message: a rank's cameras are a contiguous byte range
+    RCCL_TRY(c, R.GroupStart());
+    for (int i = 0; i < n;) {
+        int j = i + 1;
+        while (j < n && owner_rank[j] == owner_rank[i]) j++;
+        const int owner = owner_rank[i];
+        char* base = c->pyr_base + (size_t)i * c->slot_bytes;
+        const size_t bytes = (size_t)(j - i) * c->slot_bytes;
+        ncclResult_t r = ncclSuccess;
+        if (owner != root) {
+            if (rank == root) r = R.Recv(base, bytes, ncclUint8, owner, (ncclComm_t)comm, (hipStream_t)stream);
+            else if (rank == owner) r = R.Send(base, bytes, ncclUint8, root, (ncclComm_t)comm, (hipStream_t)stream);
+        }
+        if (r != ncclSuccess) {
+            (void)R.GroupEnd();
+            c->err = std::string("ncclSend / ncclRecv: ") + R.GetErrorString(r);
+            return PANO_EHIP;
+        }
+        i = j;
+    }
+    RCCL_TRY(c, R.GroupEnd());
     return PANO_OK;
 }
 

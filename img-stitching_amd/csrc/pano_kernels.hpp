@@ -94,6 +94,8 @@ struct CanvasParams {
     int small_base;            // >0: levels small_base..bands run as one normalise launch + one LDS collapse launch
     int small_fused;           // 1: ... and as ONE launch (small_fused_kernel) that also builds the camera levels above
                                // small_base itself: the per-frame pyrDown chain stops at level small_base
+    const uint16_t* order0;    // level 0, or nullptr: per XCD band (order_per entries each, 0xffff = none) the 128 x 16-pixel
+    int order_per, order_gx;   // workgroup tiles in the order they are dispatched - seam tiles first; tile = by * order_gx + bx
     const uint8_t* small_live; // small_fused: per 32 x 8 tile of level small_base, the cameras with weight on its footprint
     int cam_lo, cam_n;         // this canvas blends cameras [cam_lo, cam_lo + cam_n) of the PyrParams it is launched with
     int w0, h0;                // padded canvas size
@@ -130,7 +132,9 @@ void launch_warp_mask(const WarpCam& c, uint8_t* dst, int dst_stride, hipStream_
 void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s);
 // K3: one blend level for the whole canvas (Laplacian, weight, accumulate, normalise, collapse);
 // level 0 writes the cut 8U panorama
-void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStream_t s);
+// ev_start / ev_stop (optional, level 0): the dispatch's own begin / end timestamps
+void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStream_t s, hipEvent_t ev_start = nullptr,
+                        hipEvent_t ev_stop = nullptr);
 // the small levels small_base..bands in two launches (one when CanvasParams::small_fused)
 constexpr int kSmallFusedMaxLevels = 4;   // small_fused_kernel handles bands - small_base + 1 <= 4 levels
 void launch_blend_small(const PyrParams& p, const CanvasSet& cs, hipStream_t s);
@@ -139,6 +143,8 @@ void launch_small_live(const PyrParams& p, const CanvasParams& c, uint8_t* table
 inline size_t small_live_bytes(const CanvasParams& c) {
     return (size_t)(((c.w0 >> c.small_base) + 31) / 32) * (((c.h0 >> c.small_base) + 7) / 8);
 }
+// per 128 x 16-pixel tile of level 0 (gx x gy of them over the hull of the cut): does it hold a wave with no single owner?
+void launch_tile_mixed(const CanvasParams& c, int gx, int gy, uint8_t* flags, hipStream_t s);
 // owner map of a vector level (run when masks change)
 void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint16_t* owner, hipStream_t s);
 // Blender::NO path

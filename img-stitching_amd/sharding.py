@@ -39,18 +39,33 @@ def group_plan(total_cams, cams_per_group, world, rank):
     return plans
 
 
+def owner_ranks(total_cams, cams_per_group, world, group):
+    """for every camera of `group`, the rank that feeds it - the `owner_rank` array of pano_gather_slots"""
+    shards = camera_shards(total_cams, world)
+    lo = group * cams_per_group
+    return [next(r for r in range(world) if (lo + c) in shards[r]) for c in range(cams_per_group)]
+
+
 def exchange_slots(dist, rank, slot_buffer, slot_bytes, moves, via_host=False):
     """slot_buffer: 1-D uint8 tensor over all slots of the group's context.  Senders push their range to rank 0,
-    rank 0 receives each range where it belongs.  via_host stages device tensors through host memory, for rehearsing
-    the path with the gloo backend (several ranks on one GPU); RCCL sends device memory directly."""
+    rank 0 receives each range where it belongs - all transfers of the group posted together (batch_isend_irecv: one
+    ncclGroupStart / End on RCCL), not one blocking launch after the other.  The torch.distributed twin of the C-ABI's
+    pano_gather_slots.  via_host stages device tensors through host memory, for rehearsing the path with the gloo backend
+    (several ranks on one GPU); RCCL sends device memory directly."""
+    ops, landings = [], []
     for peer, first, count in moves:
         view = slot_buffer[first * slot_bytes:(first + count) * slot_bytes]
         if rank == peer:
-            dist.send(view.cpu() if via_host else view, dst=0)
+            ops.append(dist.P2POp(dist.isend, view.cpu() if via_host else view, 0))
         elif rank == 0:
             if via_host:
                 host = view.cpu()
-                dist.recv(host, src=peer)
-                view.copy_(host)
+                ops.append(dist.P2POp(dist.irecv, host, peer))
+                landings.append((view, host))
             else:
-                dist.recv(view, src=peer)
+                ops.append(dist.P2POp(dist.irecv, view, peer))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for view, host in landings:
+        view.copy_(host)

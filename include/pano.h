@@ -232,6 +232,21 @@ pano_status pano_get_pyramid_slots(pano_ctx* ctx, void** d_base, size_t* slot_by
 /* Blender::blend + 8U + cut over whatever the pyramid slots hold */
 pano_status pano_blend(pano_ctx* ctx, uint8_t* d_out, size_t out_stride, void* hip_stream);
 
+/* The one exchange of the sharded path, over RCCL (one process per GPU): the pyramid slots of the cameras that OTHER ranks fed land
+ * in this ctx's slots on `root` - ncclGroupStart, one ncclRecv (root) / ncclSend (owner) per run of consecutive slots with the same
+ * owner, ncclGroupEnd, asynchronous on hip_stream.  This is the "single RCCL gather of the tiles onto rank 0" of the north star as
+ * grouped point-to-point calls: the ranks of ANOTHER stitcher's cameras take no part, and the slots arrive in place.  The reference's
+ * only inter-device transport is JPEG over UDP between two Jetsons (src/slave.cpp:88-145, src/panocamimpl.cpp:11-56).
+ *   owner_rank[i]   the rank that ran pano_feed_cameras for camera i of this ctx (the same array on every rank)
+ *   rccl_comm       an ncclComm_t that spans those ranks: the caller's own, or one made here -
+ * pano_rccl_unique_id on one rank, the 128 bytes handed to the others by whatever channel the caller has, pano_rccl_comm_create on
+ * every rank (collective).  librccl.so is loaded on first use; PANO_ENODEVICE when it is not there. */
+#define PANO_RCCL_ID_BYTES 128
+pano_status pano_rccl_unique_id(char id[PANO_RCCL_ID_BYTES]);
+pano_status pano_rccl_comm_create(pano_ctx* ctx, const char id[PANO_RCCL_ID_BYTES], int world, int rank, void** rccl_comm);
+pano_status pano_rccl_comm_destroy(void* rccl_comm);
+pano_status pano_gather_slots(pano_ctx* ctx, void* rccl_comm, int rank, int root, const int* owner_rank, void* hip_stream);
+
 /* ---- caller-side assembly of the two half panoramas (device buffers, BGR8) ------------------------------ */
 /* src/master.cpp:321-326: cv::resize(up, up, down.size()) [INTER_LINEAR], cv::vconcat(up, down), black 10-row
  * divider centred on the seam.  d_out is down_w x 2*down_h.  `ctx` (either stitcher) names the device. */
@@ -254,7 +269,9 @@ pano_status pano_stack_finalcut_host(pano_ctx* ctx, const uint8_t* h_up, int up_
                                      uint8_t* h_out, size_t out_stride);
 
 /* ---- measurement ------------------------------------------------------------------------- */
-enum { PANO_STAGE_WARP = 0, PANO_STAGE_PYRAMID = 1, PANO_STAGE_BLEND = 2, PANO_NUM_STAGES = 3 };
+/* PANO_STAGE_BLEND0: the level-0 blend launch alone (the largest kernel of the blend stage), from the dispatch's own begin / end
+ * timestamps like PANO_STAGE_WARP - the intervals rocprofv3 reports per kernel */
+enum { PANO_STAGE_WARP = 0, PANO_STAGE_PYRAMID = 1, PANO_STAGE_BLEND = 2, PANO_STAGE_BLEND0 = 3, PANO_NUM_STAGES = 4 };
 /* when enabled, hipEvents bracket each stage on the launch stream */
 pano_status pano_set_profiling(pano_ctx* ctx, int enabled);
 /* ms of each stage of the LAST compose (synchronises on its events) */
