@@ -413,6 +413,7 @@ void po_pyr_up_16s(const int16_t* src, int w, int h, int cn, int16_t* dst) {
 void po_copy_make_border_16s(const int16_t* src, int w, int h, int cn, int top, int bottom, int left, int right,
                              int border, int16_t* dst) {
     int dw = w + left + right, dh = h + top + bottom;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int y = 0; y < dh; y++) {
         int sy = border_interpolate(y - top, h, border);
         for (int x = 0; x < dw; x++) {
@@ -424,6 +425,7 @@ void po_copy_make_border_16s(const int16_t* src, int w, int h, int cn, int top, 
 }
 void po_copy_make_border_32f(const float* src, int w, int h, int top, int bottom, int left, int right, float* dst) {
     int dw = w + left + right, dh = h + top + bottom;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int y = 0; y < dh; y++)
         for (int x = 0; x < dw; x++) {
             int sx = x - left, sy = y - top;
@@ -684,15 +686,18 @@ void po_blender_feed(po_blender* b, const int16_t* img, const uint8_t* mask, int
     for (int i = 0; i < nb; i++) {
         int16_t* tmp = (int16_t*)malloc(sizeof(int16_t) * (size_t)pw[i] * ph[i] * 3);
         po_pyr_up_16s(pyr[i + 1], pw[i + 1], ph[i + 1], 3, tmp); /* sizes are exact doubles here */
-        size_t cnt = (size_t)pw[i] * ph[i] * 3;
-        for (size_t k = 0; k < cnt; k++) pyr[i][k] = sat16((int)pyr[i][k] - (int)tmp[k]);
+        long cnt = (long)pw[i] * ph[i] * 3;
+        int16_t* pi = pyr[i];
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (long k = 0; k < cnt; k++) pi[k] = sat16((int)pi[k] - (int)tmp[k]);
         free(tmp);
     }
     /* weight Gaussian pyramid: mask * (1/255.) as f32, CONSTANT border, pyrDown */
     {
         float* wm = (float*)malloc(sizeof(float) * (size_t)w * h);
         const float s = (float)(1. / 255.);
-        for (size_t k = 0; k < (size_t)w * h; k++) wm[k] = (float)mask[k] * s;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (long k = 0; k < (long)w * h; k++) wm[k] = (float)mask[k] * s;
         wp[0] = (float*)malloc(sizeof(float) * (size_t)width * height);
         po_copy_make_border_32f(wm, w, h, top, bottom, left, right, wp[0]);
         free(wm);
@@ -704,6 +709,7 @@ void po_blender_feed(po_blender* b, const int16_t* img, const uint8_t* mask, int
     int y_tl = tl_new_y - R[1], y_br = br_new_y - R[1], x_tl = tl_new_x - R[0], x_br = br_new_x - R[0];
     for (int i = 0; i <= nb; i++) {
         int rw = x_br - x_tl, rh = y_br - y_tl;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
         for (int y = 0; y < rh; y++) {
             const int16_t* srow = pyr[i] + (size_t)y * pw[i] * 3;
             const float* wrow = wp[i] + (size_t)y * pw[i];

@@ -1090,3 +1090,18 @@ def test_host_entry_pageable_pinned_and_strided(pano, po, torch, c1):
             assert np.array_equal(res[k][j], wants[(j + k) % 2]), (k, j)
     for b in pin + [pout]:
         b.close()
+
+
+def test_paced_60fps_stream(pano, po):
+    """BASELINE config 5 in small: 2 x 4 x 960x540 frames offered at 60 fps for one second through pano_stream_* (page-locked
+    slots, two panoramas in flight; tools/stream_60fps.py is the harness): no frame dropped, and the sampled panoramas are the
+    oracle's"""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("stream_60fps", os.path.join(ROOT, "tools", "stream_60fps.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run(fps=60.0, frames=60, width=960, height=540, bands=4, check=True)
+    assert r["dropped"] == 0 and r["frames_composed"] == 60, r
+    assert r["sampled_frames_equal_oracle"] is True, r
+    assert r["achieved_fps"] > 55.0, r

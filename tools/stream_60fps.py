@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 5 - the paced capture loop: 8 x 1080p frames arrive in host memory every 1/fps seconds (the reference's
+loop pops one cv::Mat per camera from the nvCam queues and calls process(), src/master.cpp:302-411) and go through the streaming
+entries pano_stream_* (page-locked slots, H2D || compose || D2H, two panoramas in flight).
+
+Per tick: the frame set of this tick (rotating host buffers, so nothing stays warm) is written into the slot's page-locked inputs -
+the write the capture thread does - the slot is submitted, and the PREVIOUS tick's panorama is waited for.  Reported: achieved fps,
+p50 / p99 / max latency from a frame's tick to its panorama in host memory, and dropped frames (a tick the loop reaches more than a
+period late is skipped and counted).  PANO_GRAPH=1 in the environment runs the same loop with hipGraph replay of the launch sequence.
+
+    python tools/stream_60fps.py [--fps 60] [--frames 600] [--width 1920 --height 1080] [--check]
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=False, device=0, pipeline=None):
+    """pipeline: True = wait for tick k's panorama after submitting tick k + 1 (two in flight, what throughput needs), False = wait
+    right after the submit (lowest latency); None = False when a period leaves room for it (fps <= 100)"""
+    if pipeline is None:
+        pipeline = fps > 100.0
+    from helpers import c2_group, synth_frame
+    pano = importlib.import_module("img-stitching_amd")
+    g = c2_group(w=width, h=height, f=1002.416 * width / 1920.0)
+    NG, NC = 2, 4
+    ctxs = []
+    for grp in range(NG):
+        ctx = pano.Context(NC, width, height, scale=g["scale"], num_bands=bands, device=device)
+        for i in range(NC):
+            ctx.set_camera(i, g["K"][i], g["R"][i])
+        ctx.prepare()
+        ctx.build_masks_voronoi()
+        ctxs.append(ctx)
+    # rotating frame sets in ordinary (pageable) host memory: what a capture queue hands over
+    sets = [[[synth_frame(width, height, 1000 + 100 * s + grp * NC + i) for i in range(NC)] for grp in range(NG)] for s in range(nsets)]
+    ins = [[[ctxs[grp].stream_input(s, i) for i in range(NC)] for grp in range(NG)] for s in range(2)]
+    period = 1.0 / fps
+    tick_t, done_t = {}, {}
+    sample = {}
+    dropped = 0
+    pending = None   # (frame index, slot)
+
+    def finish(p):
+        k, s = p
+        for grp in range(NG):
+            ctxs[grp].stream_wait(s)
+        done_t[k] = time.perf_counter()
+        if check and k in (0, frames // 2):
+            sample[k] = [ctxs[grp].stream_output(s).copy() for grp in range(NG)]
+
+    # two untimed frames: page-locked slots, device buffers and weights come into being here
+    for s in range(2):
+        for grp in range(NG):
+            for i in range(NC):
+                ins[s][grp][i][:] = sets[0][grp][i]
+            ctxs[grp].stream_submit(s)
+        for grp in range(NG):
+            ctxs[grp].stream_wait(s)
+    t0 = time.perf_counter() + 0.01
+    slot = 0
+    for k in range(frames):
+        target = t0 + k * period
+        now = time.perf_counter()
+        if now > target + period:      # this tick is over before we got here: the frame is lost
+            dropped += 1
+            continue
+        while now < target:
+            if target - now > 0.002:
+                time.sleep(target - now - 0.001)
+            now = time.perf_counter()
+        tick_t[k] = target
+        fs = sets[k % nsets]
+        for grp in range(NG):
+            for i in range(NC):
+                ins[slot][grp][i][:] = fs[grp][i]          # the capture thread's write into the slot
+        for grp in range(NG):
+            ctxs[grp].stream_submit(slot)
+        if pipeline:
+            if pending is not None:
+                finish(pending)
+            pending = (k, slot)
+        else:
+            finish((k, slot))
+        slot ^= 1
+    if pending is not None:
+        finish(pending)
+    t_end = time.perf_counter()
+    lat = np.array([done_t[k] - tick_t[k] for k in sorted(done_t)]) * 1e3
+    out = {"config": "C5: %d x %dx%d -> 2 panoramas, %d bands, paced at %.1f fps, %d frames, pano_stream_* (2 slots)%s" %
+                     (NG * NC, width, height, bands, fps, frames, ", hipGraph replay" if os.environ.get("PANO_GRAPH") == "1" else ""),
+           "target_fps": fps, "frames_offered": frames, "frames_composed": int(len(lat)), "dropped": int(dropped),
+           "achieved_fps": round(len(lat) / (t_end - t0), 2),
+           "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 3), "p99": round(float(np.percentile(lat, 99)), 3),
+                          "max": round(float(lat.max()), 3)},
+           "pipelined": bool(pipeline),
+           "latency_definition": "frame tick (frames in host memory) -> panorama in host memory, including the write of the 8 frames "
+                                 "into the page-locked slot" + (" and one tick of pipelining (the wait happens after the next submit)" if pipeline else "")}
+    if check:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pano_oracle as po
+        po.set_threads(min(16, os.cpu_count() or 1))
+        masks = [ctxs[0].get_mask(i) for i in range(NC)]
+        ok = True
+        for k, got in sample.items():
+            for grp in range(NG):
+                want, _ = po.compose(sets[k % nsets][grp], g["K"], g["R"], g["scale"], masks, bands)
+                ok &= bool(np.array_equal(got[grp], want))
+        po.set_threads(1)
+        out["sampled_frames_equal_oracle"] = ok
+        out["sampled_frames"] = sorted(sample)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fps", type=float, default=60.0)
+    ap.add_argument("--frames", type=int, default=600)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bands", type=int, default=5)
+    ap.add_argument("--check", action="store_true", help="compare two sampled panoramas with the CPU oracle")
+    ap.add_argument("--pipeline", type=int, default=-1, help="1: two panoramas in flight, 0: wait after every submit, -1: by fps")
+    a = ap.parse_args()
+    print(json.dumps(run(a.fps, a.frames, a.width, a.height, a.bands, check=a.check,
+                         pipeline=None if a.pipeline < 0 else bool(a.pipeline))), flush=True)
+
+
+if __name__ == "__main__":
+    main()
