@@ -88,7 +88,7 @@ EXPORTS = [
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_get_camera", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
     "pano_build_masks_voronoi", "pano_build_masks_graphcut", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
-    "pano_compose_host", "pano_host_alloc", "pano_host_free", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_rccl_unique_id", "pano_rccl_comm_create", "pano_rccl_comm_destroy", "pano_gather_slots", "pano_stack_master", "pano_stack_finalcut", "pano_stack_master_host", "pano_stack_finalcut_host", "pano_stream_input", "pano_stream_output",
+    "pano_compose_host", "pano_host_alloc", "pano_host_free", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_feed_cameras_host", "pano_blend_host", "pano_rccl_unique_id", "pano_rccl_comm_create", "pano_rccl_comm_destroy", "pano_gather_slots", "pano_stack_master", "pano_stack_finalcut", "pano_stack_master_host", "pano_stack_finalcut_host", "pano_stream_input", "pano_stream_output",
     "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
     "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_get_live_rect", "pano_get_live_gap", "pano_get_warp_table_stats", "pano_debug_get_level", "pano_debug_get_weights",
     "pano_debug_get_canvas_weights", "pano_debug_get_canvas",
@@ -342,6 +342,19 @@ class Context:
         self._ck(self.lib.pano_stack_finalcut(self.h, _vp(d_up), up_w, up_h, C.c_size_t(up_stride), _vp(d_down), dw, dh,
                                               C.c_size_t(d_stride), int(finalcut), _vp(d_out), C.c_size_t(out_stride),
                                               _vp(stream)))
+
+    def feed_cameras_host(self, cam_bits, frames):
+        """pano_feed_cameras with host frames (list indexed by camera; entries of unselected cameras may be None)"""
+        keep = [np.ascontiguousarray(f, np.uint8) if f is not None else None for f in frames]
+        ptrs = (C.c_void_p * self.n)(*[(f.ctypes.data if f is not None else 0) for f in keep])
+        st = (C.c_size_t * self.n)(*[(f.strides[0] if f is not None else 0) for f in keep])
+        self._ck(self.lib.pano_feed_cameras_host(self.h, int(cam_bits), ptrs, st))
+
+    def blend_host(self):
+        w, h = self.output_size()
+        out = np.empty((h, w, 3), np.uint8)
+        self._ck(self.lib.pano_blend_host(self.h, _vp(out.ctypes.data), C.c_size_t(out.strides[0])))
+        return out
 
     # -- the sharded exchange over RCCL (one process per GPU)
     @staticmethod

@@ -2179,6 +2179,58 @@ pano_status pano_get_pyramid_slots(pano_ctx* c, void** d_base, size_t* slot_byte
         }                                                                                        \
     } while (0)
 
+// the sharded path for callers whose frames are in host memory (a capture card per GPU host process): upload + feed, and
+// blend + download, on the ctx's own stream
+static pano_status feed_cameras_host_impl(pano_ctx* c, unsigned cam_bits, const uint8_t* const* h_frames, const size_t* strides) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (!h_frames || !strides) return PANO_EINVAL;
+    const Plan& P = c->plan;
+    cam_bits &= (1u << P.n) - 1u;
+    const size_t row_in = (size_t)c->frame_w * 3, in_pitch = align_up(row_in, 16);
+    if (!c->stage_in[0] || c->stage_in_pitch != in_pitch) {
+        HIP_TRY(c, hipDeviceSynchronize());
+        for (int i = 0; i < P.n; i++) {
+            dfree(c->stage_in[i]);
+            HIP_TRY(c, hipMalloc((void**)&c->stage_in[i], in_pitch * c->frame_h + 64));
+        }
+        c->stage_in_pitch = in_pitch;
+    }
+    const uint8_t* frames[kMaxCams] = {};
+    size_t pitches[kMaxCams] = {};
+    for (int i = 0; i < P.n; i++) {
+        if (!((cam_bits >> i) & 1u)) continue;
+        if (!h_frames[i] || strides[i] < row_in) return PANO_EINVAL;
+        HIP_TRY(c, hipMemcpy2DAsync(c->stage_in[i], in_pitch, h_frames[i], strides[i], row_in, c->frame_h, hipMemcpyHostToDevice,
+                                    c->own_stream));
+        frames[i] = c->stage_in[i];
+        pitches[i] = in_pitch;
+    }
+    return pano_feed_cameras(c, cam_bits, frames, pitches, c->own_stream);
+}
+pano_status pano_feed_cameras_host(pano_ctx* c, unsigned cam_bits, const uint8_t* const* h_frames, const size_t* strides) {
+    return guarded(c, [&]() { return feed_cameras_host_impl(c, cam_bits, h_frames, strides); });
+}
+pano_status pano_blend_host(pano_ctx* c, uint8_t* h_out, size_t out_stride) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    const Plan& P = c->plan;
+    const size_t row_out = (size_t)P.cut.w * 3, out_pitch = align_up(row_out, 16);
+    if (!h_out || out_stride < row_out) return PANO_EINVAL;
+    if (!c->stage_out || out_pitch * (size_t)P.cut.h > c->stage_out_bytes) {
+        HIP_TRY(c, hipDeviceSynchronize());
+        dfree(c->stage_out);
+        if (c->pin_out) (void)hipHostFree(c->pin_out);
+        c->pin_out = nullptr;
+        c->stage_out_bytes = out_pitch * (size_t)P.cut.h;
+        HIP_TRY(c, hipMalloc((void**)&c->stage_out, c->stage_out_bytes));
+    }
+    if ((st = pano_blend(c, c->stage_out, out_pitch, c->own_stream)) != PANO_OK) return st;
+    HIP_TRY(c, hipMemcpy2DAsync(h_out, out_stride, c->stage_out, out_pitch, row_out, P.cut.h, hipMemcpyDeviceToHost, c->own_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->own_stream));
+    return PANO_OK;
+}
+
 pano_status pano_rccl_unique_id(char id[PANO_RCCL_ID_BYTES]) {
     static_assert(PANO_RCCL_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
     if (!id) return PANO_EINVAL;
@@ -2218,6 +2270,7 @@ pano_status pano_gather_slots(pano_ctx* c, void* comm, int rank, int root, const
     Rccl& R = Rccl::get();
     if (!R.ok) return fail(c, PANO_ENODEVICE, R.error.c_str());
     const int n = c->plan.n;
+    if (!stream) stream = c->own_stream;  // callers without HIP types: the stream pano_feed_cameras_host / pano_blend_host use
     // consecutive slots with the same peer travel as one message: a rank's cameras are a contiguous byte range
     RCCL_TRY(c, R.GroupStart());
     for (int i = 0; i < n;) {

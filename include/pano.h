@@ -232,6 +232,11 @@ pano_status pano_get_pyramid_slots(pano_ctx* ctx, void** d_base, size_t* slot_by
 /* Blender::blend + 8U + cut over whatever the pyramid slots hold */
 pano_status pano_blend(pano_ctx* ctx, uint8_t* d_out, size_t out_stride, void* hip_stream);
 
+/* the same two with host buffers (a capture card per GPU host process): upload + feed, blend + download (synchronous), on the ctx's
+ * own stream - the stream pano_gather_slots uses when it is given hip_stream == NULL */
+pano_status pano_feed_cameras_host(pano_ctx* ctx, unsigned cam_bits, const uint8_t* const* h_frames, const size_t* strides);
+pano_status pano_blend_host(pano_ctx* ctx, uint8_t* h_out, size_t out_stride);
+
 /* The one exchange of the sharded path, over RCCL (one process per GPU): the pyramid slots of the cameras that OTHER ranks fed land
  * in this ctx's slots on `root` - ncclGroupStart, one ncclRecv (root) / ncclSend (owner) per run of consecutive slots with the same
  * owner, ncclGroupEnd, asynchronous on hip_stream.  This is the "single RCCL gather of the tiles onto rank 0" of the north star as

@@ -81,3 +81,50 @@ def test_replay_frames_on_gpu(replay_bin, rig_r, tmp_path):
     # the geometry-only Voronoi seam finder instead of the reference's graph cut
     r = subprocess.run([replay_bin, str(cfg), "--voronoi", "--frames", "1"], capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 0 and "wrote final.ppm 1470x500" in r.stdout, r.stderr + r.stdout
+
+
+@pytest.fixture(scope="module")
+def sharded_bin(tmp_path_factory, pano):
+    """examples/sharded_replay.cpp: the camera-sharded flow (feed -> pano_gather_slots over RCCL -> blend) for a C++ caller,
+    plain g++ against the C-ABI - the RCCL call path of the library is compiled and linked here, on the CPU box too"""
+    pano.build()
+    out = tmp_path_factory.mktemp("bin") / "sharded_replay"
+    lib_dir = os.path.join(ROOT, "img-stitching_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", os.path.join(ROOT, "examples", "sharded_replay.cpp"), "-o", str(out),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + lib_dir, "-lpano_hip", "-Wl,-rpath," + lib_dir, "-lpthread"])
+    return str(out)
+
+
+def test_sharded_replay_builds_and_rccl_loads(sharded_bin, pano):
+    r = subprocess.run([sharded_bin], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage: sharded_replay <rank> <world> <id-file>" in r.stderr
+    # librccl.so is found and ncclGetUniqueId answers without a GPU: the exchange is there to be called
+    uid = pano.Context.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+
+
+@pytest.mark.gpu
+def test_sharded_replay_single_rank_on_gpu(sharded_bin, pano, tmp_path):
+    """world = 1 walks feed -> (no exchange) -> blend on the box's one GPU; the checksum of the panorama must be the one the
+    ordinary host entry gives for the same frames"""
+    import zlib
+    import numpy as np
+    from helpers import c2_group
+    r = subprocess.run([sharded_bin, "--single", "2"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr + r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.startswith("frame ")]
+    assert len(lines) == 2 and "3893x991 panorama" in lines[0]
+    g = c2_group()
+    ctx = pano.Context(4, 1920, 1080, scale=np.float32(1002.416), num_bands=5, device=0)
+    for i in range(4):
+        ctx.set_camera(i, g["K"][i], g["R"][i])
+    ctx.prepare(); ctx.build_masks_voronoi()
+    k = np.arange(1920 * 1080 * 3, dtype=np.uint64)
+    frames = [(((k * 7 + np.uint64(c * 31)) >> np.uint64(3)) & np.uint64(0xff)).astype(np.uint8).reshape(1080, 1920, 3) for c in range(4)]
+    got = ctx.compose_host(frames)
+    ctx.feed_cameras_host(0b1111, frames)
+    assert np.array_equal(got, ctx.blend_host())          # feed + blend with host buffers == the ordinary host entry
+    b = got.reshape(-1).astype(np.uint64)
+    w = (np.arange(b.size, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(1)) & np.uint64(0xffffffff)
+    want = int(((b * w) & np.uint64(0xffffffff)).sum() & np.uint64(0xffffffff))
+    assert "checksum %08x" % want in lines[0], (lines[0], "%08x" % want)
