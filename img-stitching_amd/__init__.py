@@ -16,7 +16,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PANO_LIB selects another build of the same C-ABI (the diagnostic library used by tools/); default = product
+# PANO_LIB selects another build of the same C-ABI (an experimental build next to the product one); default = product
 LIB_PATH = os.environ.get("PANO_LIB") or os.path.join(_HERE, "libpano_hip.so")
 
 SPHERICAL, CYLINDRICAL = 0, 1

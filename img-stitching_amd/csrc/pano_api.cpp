@@ -93,6 +93,7 @@ struct pano_ctx {
     uint16_t* order0 = nullptr;      // CanvasParams::order0
     size_t order_cap = 0;
     bool order_dirty = false;
+    bool l0_order = true;            // PANO_L0_ORDER=0: plain band order
     float* wsum[kMaxLevels] = {};
     int16_t* canvas[kMaxLevels] = {};
 
@@ -521,8 +522,7 @@ pano_status build_tile_order(pano_ctx* c, hipStream_t s) {
     c->order_dirty = false;
     c->cv.order0 = nullptr;
     c->cv.order_per = c->cv.order_gx = 0;
-    static const bool off = getenv("PANO_L0_ORDER") && atoi(getenv("PANO_L0_ORDER")) == 0;
-    if (off || c->plan.bands < 0 || !c->cv.fast[0]) return PANO_OK;
+    if (!c->l0_order || c->plan.bands < 0 || !c->cv.fast[0]) return PANO_OK;
     const CanvasParams& cv = c->cv;
     const int w = cv.cut_x + cv.cut_w - (cv.cut_x & ~3), h = cv.cut_y + cv.cut_h - (cv.cut_y & ~1);
     const int gx = (w + 127) / 128, gy = (h + 15) / 16;
@@ -1246,6 +1246,11 @@ static pano_status prepare_impl(pano_ctx* c) {
         c->cv.small_live = c->small_live;
     }
     c->full_tiles = getenv("PANO_FULL_TILES") && atoi(getenv("PANO_FULL_TILES"));
+    // launch-shape knobs of the blend (A/B levers of DESIGN.md section 6/8; none changes a result)
+    c->l0_order = !(getenv("PANO_L0_ORDER") && atoi(getenv("PANO_L0_ORDER")) == 0);
+    c->cv.k3_shape = getenv("PANO_K3_SHAPE") ? atoi(getenv("PANO_K3_SHAPE")) & 3 : 3;
+    c->cv.blend_split = !(getenv("PANO_BLEND_PLANES") && atoi(getenv("PANO_BLEND_PLANES")) == 0);
+    c->cv.l0_strips = getenv("PANO_L0_STRIPS") ? atoi(getenv("PANO_L0_STRIPS")) : 0;
     live_rects(c, {});  // no masks yet: every pixel of every level is live
     c->cv.cam_lo = 0;
     c->cv.cam_n = n;
@@ -1802,14 +1807,7 @@ pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b, const uint8_t* const* fa
     for (int i = 0; i < B.n; i++) pp.cam[A.n + i] = b->pyr.cam[i];
     pp.ncam = A.n + B.n;
     const unsigned all = (1u << pp.ncam) - 1u;
-#ifdef PANO_DIAG
-    // diagnostic (wrong pictures, timing only): what would fewer pyramid launches be worth?  PANO_PYR_LEVELS=n launches only
-    // the first n levels
-    static const int kpyr = getenv("PANO_PYR_LEVELS") ? atoi(getenv("PANO_PYR_LEVELS")) : 99;
-    for (int l = 0; l < pyr_levels(a) && l < kpyr; l++) launch_pyr_down(pp, all, l, s);
-#else
     for (int l = 0; l < pyr_levels(a); l++) launch_pyr_down(pp, all, l, s);
-#endif
     if (prof && (st = record(a, 2, s)) != PANO_OK) return st;
     // K3: both canvases per launch
     CanvasSet cs{};

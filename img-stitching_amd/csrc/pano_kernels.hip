@@ -109,7 +109,6 @@ __device__ __forceinline__ void map_source(const WarpCam& c, const float* __rest
 
 // remapBilinear<FixedPtCast<int,uchar,15>>: sum(p*w)+16384 >> 15 with w = (32-a|a)(32-b|b)*32
 // == ((32-b)*(p00*(32-a)+p01*a) + b*(p10*(32-a)+p11*a) + 512) >> 10, exact in integers.
-template <int ABL = 0>
 __device__ __forceinline__ void sample_bilinear_reflect(const uint8_t* __restrict__ src, int sw, int sh, int stride,
                                                         float fx, float fy, int out[3]) {
     int isx = cv_round_dev(fx * 32.f), isy = cv_round_dev(fy * 32.f);
@@ -238,7 +237,6 @@ __device__ __forceinline__ void bilinear_packed(uint2 t, uint2 u, int a, int b, 
 // tap loads in flight together, packed bilinear.  Anything else (reflected taps, z <= 0, extreme
 // exponents) takes the per-pixel generic path.
 // ------------------------------------------------------------------------------------------------
-template <int ABL>
 __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
     const WarpCam& c = P.cam[blockIdx.z];
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
@@ -274,49 +272,24 @@ __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
         fast &= Z[j] >= 0x1p-40f && Z[j] <= 0x1p40f;
     }
     int ix[4], iy[4], fa[4], fb[4];
-    if (ABL != 3) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float qx, qy;
-            div2_shared(X[j], Y[j], Z[j], qx, qy);
-            const int isx = cv_round_dev(qx * 32.f), isy = cv_round_dev(qy * 32.f);
-            fa[j] = isx & 31; fb[j] = isy & 31;
-            ix[j] = isx >> 5; iy[j] = isy >> 5;  // |value| < 2^26: the saturate_cast<short> is decided by the range test below
-            // the 12-byte aligned fetch of row iy+1 must end inside the frame: ix <= sw-4
-            fast &= ix[j] >= 0 && ix[j] <= sw - 4 && iy[j] >= 0 && iy[j] <= sh - 2;
-        }
-    } else {  // diagnostic: no projection arithmetic
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            ix[j] = min((x0 + j) * 9 / 10, sw - 4); iy[j] = min(y * 9 / 10, sh - 2);
-            fa[j] = (x0 + j) & 31; fb[j] = y & 31;
-        }
-        fast = true;
-    }
-    if (ABL == 2) {  // diagnostic: every pixel takes the interior path
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            ix[j] = min(max(ix[j], 0), sw - 4);
-            iy[j] = min(max(iy[j], 0), sh - 2);
-        }
-        fast = true;
+    for (int j = 0; j < 4; j++) {
+        float qx, qy;
+        div2_shared(X[j], Y[j], Z[j], qx, qy);
+        const int isx = cv_round_dev(qx * 32.f), isy = cv_round_dev(qy * 32.f);
+        fa[j] = isx & 31; fb[j] = isy & 31;
+        ix[j] = isx >> 5; iy[j] = isy >> 5;  // |value| < 2^26: the saturate_cast<short> is decided by the range test below
+        // the 12-byte aligned fetch of row iy+1 must end inside the frame: ix <= sw-4
+        fast &= ix[j] >= 0 && ix[j] <= sw - 4 && iy[j] >= 0 && iy[j] <= sh - 2;
     }
     int v[4][3];
     if (fast) {
         uint2 t[4], u[4];
-        if (ABL != 1) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const unsigned o = (unsigned)(iy[j] * stride + 3 * ix[j]);
-                t[j] = load_taps6(c.src, src_lo, o);
-                u[j] = load_taps6(c.src, src_lo, o + stride);
-            }
-        } else {  // diagnostic: no tap loads
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                t[j] = make_uint2(ix[j] * 0x01010101u, iy[j]);
-                u[j] = make_uint2(iy[j] * 0x01010101u, ix[j]);
-            }
+        for (int j = 0; j < 4; j++) {
+            const unsigned o = (unsigned)(iy[j] * stride + 3 * ix[j]);
+            t[j] = load_taps6(c.src, src_lo, o);
+            u[j] = load_taps6(c.src, src_lo, o + stride);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) bilinear_packed(t[j], u[j], fa[j], fb[j], v[j]);
@@ -325,7 +298,7 @@ __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
         for (int j = 0; j < 4; j++) {
             float fx, fy;
             map_source(c, m, A[j], B, fx, fy);
-            sample_bilinear_reflect<0>(c.src, sw, sh, stride, fx, fy, v[j]);
+            sample_bilinear_reflect(c.src, sw, sh, stride, fx, fy, v[j]);
         }
     }
     if (c.gain) {
@@ -336,7 +309,6 @@ __global__ __launch_bounds__(256) void warp_tiles_kernel(WarpParams P) {
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         unsigned pk = (unsigned)v[0][ch] | ((unsigned)v[1][ch] << 8) | ((unsigned)v[2][ch] << 16) | ((unsigned)v[3][ch] << 24);
-        if (ABL == 4 && pk != 0x12345678u) continue;  // diagnostic: no stores
         *reinterpret_cast<unsigned*>(d + (size_t)ch * c.dst_plane) = pk;  // rows are padded to 16 bytes
     }
 }
@@ -504,7 +476,6 @@ __device__ __forceinline__ void bilinear_b2(uint2 t, uint2 u, unsigned a, unsign
 }
 
 // The per-lane body of the general kernel: frames or strides of any alignment, dense table, global taps.
-template <int ABL>
 __device__ __forceinline__ void warp_lane_checked(const WarpCam& c, int x0, int y, uint4 mm, int ox, int oy, int v[4][3]) {
     const int stride = c.src_stride, sh1 = c.src_h - 1;
     const unsigned src_lo = (unsigned)(size_t)c.src & 3u;
@@ -527,7 +498,6 @@ __device__ __forceinline__ void warp_lane_checked(const WarpCam& c, int x0, int 
 }
 
 // K1, table form, the general kernel: any frame alignment, exposure gains, dense table, global taps.
-template <int ABL>
 __global__ __launch_bounds__(256) void warp_tiles_lut_checked_kernel(WarpParams P) {
     const WarpCam& c = P.cam[blockIdx.x];
     const unsigned lg = (unsigned)c.live_by0_gap;
@@ -541,7 +511,7 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_checked_kernel(WarpParams 
     const uint4 mm = *reinterpret_cast<const uint4*>(c.lut + (size_t)y * c.lut_pitch + x0);
     const int4 bb = c.box[by * ((c.tw + 63) >> 6) + bx];
     int v[4][3];
-    warp_lane_checked<ABL>(c, x0, y, mm, bb.x, bb.y, v);
+    warp_lane_checked(c, x0, y, mm, bb.x, bb.y, v);
     if (c.gain) {
 #pragma unroll
         for (int j = 0; j < 4; j++) apply_gain(c, min(x0 + j, c.tw - 1), y, v[j]);
@@ -572,7 +542,7 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_checked_kernel(WarpParams 
 // (checked by the launcher; anything else runs warp_tiles_lut_checked_kernel).
 // GAIN: an instantiation of its own that also applies the exposure gain maps (BlocksGainCompensator::apply) of the
 // cameras that carry one; the plain instantiation stays at 37 VGPRs.
-template <int ABL, bool GAIN = false>
+template <bool GAIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void warp_tiles_lut_kernel(WarpParams P) {
     __shared__ uint4 sbox[kBoxBytes / 16];
     // grid = (ncam, ceil(tw/64), ceil(th/16)): the camera is the FASTEST workgroup coordinate.  Linear workgroup ids
@@ -637,16 +607,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     const bool active = x0 < tw && y < th;
     // plain (cached) loads and stores: non-temporal ones for the streamed table and tile measured 15 % slower
     u32x2 e = u32x2{0u, 0u};
-    if (active && ABL != 20)  // 32-bit byte offset: scalar base + vector offset addressing, no 64-bit multiply
+    if (active)  // 32-bit byte offset: scalar base + vector offset addressing, no 64-bit multiply
         e = *reinterpret_cast<const u32x2 PANO_GLOBAL*>((const uint8_t PANO_GLOBAL*)lutc + (((unsigned)y * lutc_pitch + (unsigned)(x0 >> 2)) << 3));
-    if (ABL == 6 || ABL == 17) e = u32x2{(unsigned)((x0 * 7 / 8) * 32 + 5) | ((unsigned)((y * 7 / 8) * 32 + 9) << 16), 32u};
-    uint4 dense = make_uint4(0u, 0u, 0u, 0u);
-    if (ABL == 20 && active)  // diagnostic: the dense table (one code per pixel, no decode) instead of the packed one
-        dense = *reinterpret_cast<const uint4*>(cg->lut + ((unsigned)y * (4u * lutc_pitch) + (unsigned)x0));
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bb), "+s"(live) : : "memory");  // bb, live are only valid past this point
     if (bx > live.x || by > live.y) return;  // beyond this camera's live blocks (workgroup-uniform)
     const int src_w = live.z, src_h = live.w;
-    if (ABL == 12 || ABL == 6 || ABL == 17) bb.z = 0;  // diagnostic: global taps everywhere
     const int bh = bb.z >> 8, cpr = bb.z & 255;
     const unsigned lpitch = (unsigned)cpr * 16u;  // rows packed: chunk k = r * cpr + ci lands at LDS byte 16 * k
     // byte phase of the box origin inside its first 16-byte chunk; the same for every row because stride % 16 == 0
@@ -677,10 +642,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
     if (!active) return;
     uint8_t PANO_GLOBAL* d = dst + ((unsigned)y * dst_pitch + (unsigned)x0);  // 32-bit offsets: a tile is far below 4 GB
-    if (ABL == 18) {  // diagnostic: dispatch + prologue + table + box load only
-        if (e.x == 0x7ffffff0u) *reinterpret_cast<unsigned PANO_GLOBAL*>(d) = e.y;
-        return;
-    }
     unsigned X[4], Y[4];
     {
         const int Db = sbits(e.y, 0, 8), Eb = sbits(e.y, 8, 6);
@@ -693,14 +654,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
     // an escaped group (a BORDER_REFLECT fold inside it) reads its four codes from the dense table: one more dependent
     // load for the waves that hold one (about one in eight)
-    if (ABL == 20) {
-        const unsigned code[4] = {dense.x, dense.y, dense.z, dense.w};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            X[j] = code[j] & 0xffffu;
-            Y[j] = code[j] >> 16;
-        }
-    } else if (e.x == 0xffffffffu) {
+    if (e.x == 0xffffffffu) {
         const uint4 mm = *reinterpret_cast<const uint4*>(cg->lut + ((unsigned)y * (4u * lutc_pitch) + (unsigned)x0));
         const unsigned code[4] = {mm.x, mm.y, mm.z, mm.w};
 #pragma unroll
@@ -720,12 +674,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             const unsigned k = off & 3u;
             const unsigned* wt = sb + (off >> 2);
             const unsigned* wu = wt + (lpitch >> 2);  // row ys + 1; for ys == sh - 1 (weight 0) the spare row
-            if (ABL == 1) {  // diagnostic: no tap reads
-                t[j] = make_uint2(off, k); u[j] = make_uint2(k, off);
-            } else {
-                t[j] = make_uint2(__builtin_amdgcn_alignbyte(wt[1], wt[0], k), __builtin_amdgcn_alignbyte(wt[2], wt[1], k));
-                u[j] = make_uint2(__builtin_amdgcn_alignbyte(wu[1], wu[0], k), __builtin_amdgcn_alignbyte(wu[2], wu[1], k));
-            }
+            t[j] = make_uint2(__builtin_amdgcn_alignbyte(wt[1], wt[0], k), __builtin_amdgcn_alignbyte(wt[2], wt[1], k));
+            u[j] = make_uint2(__builtin_amdgcn_alignbyte(wu[1], wu[0], k), __builtin_amdgcn_alignbyte(wu[2], wu[1], k));
         }
     } else {
         // Global taps (the box of this patch does not fit LDS or touches the end of the frame).  `o_last` is the last
@@ -739,9 +689,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             const unsigned ys = (Y[j] >> 5) + (unsigned)bb.y;
             const unsigned ot = __umul24(ys, stride) + __umul24((X[j] >> 5) + (unsigned)bb.x, 3u);
             const unsigned k = ot & 3u, oa = ot & ~3u;
-            if (ABL == 1 || ABL == 17) {  // diagnostic: no tap loads
-                t[j] = make_uint2(oa, k); u[j] = make_uint2(k, oa);
-            } else if (o_last != 0u && oa + stride <= o_last) {
+            if (o_last != 0u && oa + stride <= o_last) {
                 const u32x3 dt = *reinterpret_cast<const u32x3 PANO_GLOBAL*>(src + oa);
                 const u32x3 du = *reinterpret_cast<const u32x3 PANO_GLOBAL*>(src + oa + stride);
                 t[j] = make_uint2(__builtin_amdgcn_alignbyte(dt.y, dt.x, k), __builtin_amdgcn_alignbyte(dt.z, dt.y, k));
@@ -784,7 +732,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
-        if ((ABL == 4 || ABL == 17) && pk[ch] != 0x12345678u) continue;  // diagnostic: no stores
         *reinterpret_cast<unsigned PANO_GLOBAL*>(d + (unsigned)ch * dst_plane) = pk[ch];  // rows are padded to 16 bytes
     }
 }
@@ -825,36 +772,12 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
                     p.cam[i].box != nullptr;
         bool gains = false;
         for (int i = 0; i < ncam; i++) gains |= p.cam[i].gain != nullptr;
-#ifdef PANO_DIAG
-        static const int labl = getenv("PANO_LUT_ABL") ? atoi(getenv("PANO_LUT_ABL")) : 0;
-        if (fast) switch (labl) {
-            case 1: PANO_LAUNCH_K1(warp_tiles_lut_kernel<1>, grid_lut); return;
-            case 4: PANO_LAUNCH_K1(warp_tiles_lut_kernel<4>, grid_lut); return;
-            case 6: PANO_LAUNCH_K1(warp_tiles_lut_kernel<6>, grid_lut); return;
-            case 12: PANO_LAUNCH_K1(warp_tiles_lut_kernel<12>, grid_lut); return;
-            case 17: PANO_LAUNCH_K1(warp_tiles_lut_kernel<17>, grid_lut); return;
-            case 18: PANO_LAUNCH_K1(warp_tiles_lut_kernel<18>, grid_lut); return;
-            case 20: PANO_LAUNCH_K1(warp_tiles_lut_kernel<20>, grid_lut); return;
-            case 13: fast = false; break;  // the general kernel
-            default: break;
-        }
-#endif
-        if (fast && gains) PANO_LAUNCH_K1((warp_tiles_lut_kernel<0, true>), grid_lut);
-        else if (fast) PANO_LAUNCH_K1(warp_tiles_lut_kernel<0>, grid_lut);
-        else PANO_LAUNCH_K1(warp_tiles_lut_checked_kernel<0>, grid_lut);
+        if (fast && gains) PANO_LAUNCH_K1(warp_tiles_lut_kernel<true>, grid_lut);
+        else if (fast) PANO_LAUNCH_K1(warp_tiles_lut_kernel<false>, grid_lut);
+        else PANO_LAUNCH_K1(warp_tiles_lut_checked_kernel, grid_lut);
     }
     else {
-#ifdef PANO_DIAG
-        static const int abl = getenv("PANO_WARP_ABL") ? atoi(getenv("PANO_WARP_ABL")) : 0;
-        switch (abl) {
-            case 1: PANO_LAUNCH_K1(warp_tiles_kernel<1>, grid); return;
-            case 2: PANO_LAUNCH_K1(warp_tiles_kernel<2>, grid); return;
-            case 3: PANO_LAUNCH_K1(warp_tiles_kernel<3>, grid); return;
-            case 4: PANO_LAUNCH_K1(warp_tiles_kernel<4>, grid); return;
-            default: break;
-        }
-#endif
-        PANO_LAUNCH_K1(warp_tiles_kernel<0>, grid);
+        PANO_LAUNCH_K1(warp_tiles_kernel, grid);
     }
 #undef PANO_LAUNCH_K1
 }
@@ -2280,10 +2203,10 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
             }
         }
         // workgroup shape (see the kernel): 3 = 2 x 2 waves in XCD bands (default), 2 = 2 x 2 waves, 0 = side by side, 1 = stacked
-        static const int shape_env = getenv("PANO_K3_SHAPE") ? atoi(getenv("PANO_K3_SHAPE")) & 3 : 3;
+        const int shape_env = c.k3_shape & 3;
         // one plane per lane on the canvas levels >= 1 (measured: levels 1 + 2 29 -> 23 us, in flight no worse);
         // PANO_BLEND_PLANES=0 keeps three planes per lane
-        static const bool split = !(getenv("PANO_BLEND_PLANES") && atoi(getenv("PANO_BLEND_PLANES")) == 0);
+        const bool split = c.blend_split != 0;
         int shape = shape_env;
         if (shape == 3 && ((w + 127) / 128 > 1023 || (h + 15) / 16 > 1023)) shape = 2;  // the band form packs the extents in 10 bits each
         dim3 block(64, 4, 1), grid((w + 127) / 128, (h + 15) / 16, cs.n);
@@ -2299,7 +2222,7 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
         // level 0 in strips of S blocks per lane (blend_level0_strip_kernel): opt-in, PANO_L0_STRIPS=2 / 4 / 8 pick S.  Measured on
         // config 2: half the vector instructions per pixel, yet 36.7 / 49.4 / 72.5 us against 31.4 us
         // for one block per lane alone and the same panoramas/s with frames in flight
-        static const int strips = getenv("PANO_L0_STRIPS") ? atoi(getenv("PANO_L0_STRIPS")) : 0;
+        const int strips = c.l0_strips;
         if (l == 0 && c.bands >= 1 && (strips == 2 || strips == 4 || strips == 8)) {
             const unsigned sgx = (w + 127) / 128, sgy = (h + 16 * strips - 1) / (16 * strips);
             if (sgx <= 1023 && sgy <= 1023) {

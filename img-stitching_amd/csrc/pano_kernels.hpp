@@ -91,6 +91,10 @@ struct CanvasParams {
     const uint16_t* owner[kLevels]; // vector levels, per 4x2 block: low byte = the single unit-weight camera (0..7), 0xFE none,
                                // 0xFF mixed; high byte = bit i set when camera i carries weight anywhere on the block
     int opitch[kLevels];       // owner entries per block row
+    // launch shape knobs, read from the environment ONCE per context (pano_prepare), never inside a launcher:
+    int k3_shape;              // PANO_K3_SHAPE: 3 = 2 x 2 waves in XCD bands (default), 2 = 2 x 2, 0 = side by side, 1 = stacked
+    int blend_split;           // PANO_BLEND_PLANES != 0: one colour plane per lane on the canvas levels >= 1 (default)
+    int l0_strips;             // PANO_L0_STRIPS = 2 / 4 / 8: level 0 by blend_level0_strip_kernel<S>; 0 (default): one block per lane
     int small_base;            // >0: levels small_base..bands run as one normalise launch + one LDS collapse launch
     int small_fused;           // 1: ... and as ONE launch (small_fused_kernel) that also builds the camera levels above
                                // small_base itself: the per-frame pyrDown chain stops at level small_base
