@@ -1235,11 +1235,20 @@ static pano_status prepare_impl(pano_ctx* c) {
         while (k <= P.bands && c->cv.fast[k]) k++;
         if (k >= 1 && P.bands - k + 1 >= 2) c->cv.small_base = k;
     }
-    // ... or as ONE launch that builds the camera levels above small_base itself (small_fused_kernel), when there are at
-    // most four of them.  Opt-in (PANO_SMALL_FUSED=1): bit-exact, 8 launches per frame instead of 11, but as measured on
-    // config 2 its halo recomputation costs 28 us where the four launches it replaces take 24
-    c->cv.small_fused = c->cv.small_base > 0 && P.bands - c->cv.small_base + 1 <= kSmallFusedMaxLevels &&
-                        getenv("PANO_SMALL_FUSED") && atoi(getenv("PANO_SMALL_FUSED")) == 1;
+    // ... or as ONE launch that builds the camera levels above small_base itself (small_fused_kernel), at most four levels.
+    // PANO_SMALL_FUSED: 0 = the separate pyrDown / normalise / collapse launches; 1 = fused from the level above the last
+    // vector level; 2 = fused from level max(1, bands - 3), which on the 1080p rig also takes blend level 2 in (six launches
+    // per frame instead of eleven)
+    {
+        const int mode = getenv("PANO_SMALL_FUSED") ? atoi(getenv("PANO_SMALL_FUSED")) : 0;
+        c->cv.small_fused = 0;
+        if (mode == 2 && P.bands >= 2) {
+            c->cv.small_base = std::max(1, P.bands - (kSmallFusedMaxLevels - 1));
+            c->cv.small_fused = 1;
+        } else if (mode == 1 && c->cv.small_base > 0 && P.bands - c->cv.small_base + 1 <= kSmallFusedMaxLevels) {
+            c->cv.small_fused = 1;
+        }
+    }
     if (c->cv.small_fused) {
         c->cv.w0 = P.canvas.w; c->cv.h0 = P.canvas.h;  // (set again below with the rest)
         HIP_TRY(c, hipMalloc((void**)&c->small_live, small_live_bytes(c->cv)));

@@ -1907,46 +1907,77 @@ __global__ __launch_bounds__(256) void collapse_small_kernel(CanvasSet CS) {
 
 // ------------------------------------------------------------------------------------------------
 // The small levels in ONE launch (CanvasParams::small_fused): camera pyramid levels small_base+1 .. bands, the camera half
-// of the blend (norm_l) and the collapse chain, per 32 x 8 tile of canvas level small_base, all through LDS.
-// Replaces, per frame, the pyrDown launches above level small_base, norm_small_kernel and collapse_small_kernel - launches
-// of 3 - 9 us each with almost no work (a dependent launch costs ~4 us before it does anything).  The price is recomputation:
-// a tile needs G_{k0+1} over its pyrUp footprint, which needs G_{k0} over the pyrDown footprint of that, and so on
-// (53 x 29 pixels of G_{k0} for a 32 x 8 tile with three small levels) - a few thousand byte-sized taps per workgroup.
+// of the blend (norm_l) and the collapse chain, per 64 x 16 tile and colour plane of canvas level small_base, all through LDS.
+// Replaces, per frame, the pyrDown launches above level small_base, norm_small_kernel, collapse_small_kernel - and, because
+// small_base may then sit one level lower, a vector blend level: launches of 3 - 10 us each with almost no work (a dependent
+// launch costs ~4 us before it does anything).  The price is recomputation: a tile needs G_{k0+1} over its pyrUp footprint,
+// which needs G_{k0} over the pyrDown footprint of that, and so on (117 x 69 pixels of G_{k0} for a 64 x 16 tile with four
+// fused levels); the pyrDown of the recomputed levels runs four outputs per lane on LDS dwords (the v_dot4 rows of pyr_down_kernel).
 // Same arithmetic as pyr_down_kernel / norm_small_kernel / collapse_small_kernel, bit for bit; camera levels above
 // small_base are not written to memory at all (pano_debug_get_level builds them on demand).
 //
 // LDS boxes per live camera: level j (= k0 + j) is held over the REAL pixel range need_j that anything consumes, padded by
 // 2 on every side in VIRTUAL coordinates: cell v holds G(reflect101(v)), so the pyrDown of the next level reads 5 x 5
-// windows with no border logic.  Box x origins are multiples of 4 and window origins even, so a 5-tap window is two LDS
-// dwords, one v_alignbyte and one v_dot4.
-constexpr int kFuseMaxJ = 3;            // at most four fused levels (k0 .. k0 + 3)
-constexpr int kFuseLdsBytes = 12 << 10; // >= the worst-case boxes of one plane for J = 3 (85 x 61 pixels of G_{k0} -> 92 x 65 bytes, 48 x 33, 28 x 17, 16 x 9)
+// windows with no border logic.  Box x origins are multiples of 4, so a group of four outputs reads the 16 bytes around it
+// as four LDS dwords.
+constexpr int kFuseMaxJ = 3;             // at most four fused levels (k0 .. k0 + 3)
+constexpr int kFuseTileW = 64, kFuseTileH = 16;
+constexpr int kFuseLdsBytes = 13 << 10;  // >= the worst-case boxes of one plane: 124 x 73 + 64 x 37 + 36 x 19 + 20 x 10 bytes + slack
+constexpr int kFuseCollapseElems = 640;  // int16: the footprints 34 x 10 + 19 x 7 + 12 x 6 of the coarser canvas levels
+// pixels a lane owns per level: level j's footprint (<= 64 x 16, 34 x 10, 19 x 7, 12 x 6) is walked by 64 x 4 lanes in
+// kFuseQ[j] passes of 4 rows (levels 0, 1) or by 32 x 8 lanes in one pass (levels 2, 3)
+__device__ __forceinline__ constexpr int fuse_q(int j) { return j == 0 ? 4 : (j == 1 ? 3 : 1); }
 struct FuseBox {
     int x0, y0, x1, y1;   // need: real pixel range, inclusive (x1 < x0: empty)
     int bx0, by0, bw, bh; // LDS box: virtual origin, row pitch in bytes (multiple of 4), rows
     int off;              // byte offset in LDS
 };
+// lane -> pixel q of level j's footprint (rw x rh): false when the lane has no such pixel
+__device__ __forceinline__ bool fuse_pixel(int j, int q, int tid, int rw, int rh, int& px, int& py) {
+    if (j <= 1) { px = tid & 63; py = (tid >> 6) + 4 * q; }
+    else { px = tid & 31; py = tid >> 5; }
+    return px < rw && py < rh;
+}
+__device__ __forceinline__ void fuse_footprints(const CanvasParams& C, int bx, int by, int rx0[], int ry0[], int rw[], int rh[], int ro[]) {
+    const int k0 = C.small_base;
+    const int cw = C.w0 >> k0, ch = C.h0 >> k0;
+    int x0 = bx * kFuseTileW, y0 = by * kFuseTileH;
+    int x1 = min(x0 + kFuseTileW, cw) - 1, y1 = min(y0 + kFuseTileH, ch) - 1;
+    int o = 0;
+#pragma unroll
+    for (int j = 0; j <= kFuseMaxJ; j++) {
+        const int l = k0 + j;
+        rx0[j] = x0; ry0[j] = y0; rw[j] = x1 - x0 + 1; rh[j] = y1 - y0 + 1;
+        ro[j] = o;
+        if (j > 0) o += rw[j] * rh[j];
+        const int nw = C.w0 >> (l + 1), nh = C.h0 >> (l + 1);
+        x0 = max((x0 >> 1) - 1, 0); y0 = max((y0 >> 1) - 1, 0);
+        x1 = min((x1 >> 1) + 1, max(nw - 1, 0)); y1 = min((y1 >> 1) + 1, max(nh - 1, 0));
+    }
+}
+
 // one byte per (tile, canvas): the cameras that carry weight anywhere on the tile's footprint at any fused level.  Static
 // (it follows the masks), so the fused kernel knows at once whose pixels to fetch - no weight round trip in front of the loads
 __global__ __launch_bounds__(256) void small_live_kernel(PyrParams P, CanvasParams C, uint8_t* table) {
     const int k0 = C.small_base, J = C.bands - k0;
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int tx = tid & 31, ty = tid >> 5;
-    const int cw = C.w0 >> k0, ch = C.h0 >> k0;
-    int x0 = blockIdx.x * kSmallTileW, y0 = blockIdx.y * kSmallTileH;
-    int x1 = min(x0 + kSmallTileW, cw) - 1, y1 = min(y0 + kSmallTileH, ch) - 1;
+    int rx0[kFuseMaxJ + 1], ry0[kFuseMaxJ + 1], rw[kFuseMaxJ + 1], rh[kFuseMaxJ + 1], ro[kFuseMaxJ + 1];
+    fuse_footprints(C, blockIdx.x, blockIdx.y, rx0, ry0, rw, rh, ro);
     int bits = 0;
-    for (int j = 0; j <= J; j++) {
+#pragma unroll
+    for (int j = 0; j <= kFuseMaxJ; j++) {
+        if (j > J) continue;
         const int l = k0 + j;
-        if (tx <= x1 - x0 && ty <= y1 - y0)
+#pragma unroll
+        for (int q = 0; q < fuse_q(j); q++) {
+            int px, py;
+            if (!fuse_pixel(j, q, tid, rw[j], rh[j], px, py)) continue;
             for (int i = 0; i < C.cam_n; i++) {
                 const PyrCam& c = P.cam[C.cam_lo + i];
-                const int x = x0 + tx - (c.tx >> l), y = y0 + ty - (c.ty >> l);
+                const int x = rx0[j] + px - (c.tx >> l), y = ry0[j] + py - (c.ty >> l);
                 if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l) && cam_weight(c, l, x, y) != 0.f) bits |= 1 << i;
             }
-        const int nw = C.w0 >> (l + 1), nh = C.h0 >> (l + 1);
-        x0 = max((x0 >> 1) - 1, 0); y0 = max((y0 >> 1) - 1, 0);
-        x1 = min((x1 >> 1) + 1, max(nw - 1, 0)); y1 = min((y1 >> 1) + 1, max(nh - 1, 0));
+        }
     }
     // (__syncthreads_or answers "any lane non-zero", not the OR of the values)
     __shared__ int all_bits;
@@ -1958,7 +1989,7 @@ __global__ __launch_bounds__(256) void small_live_kernel(PyrParams P, CanvasPara
 }
 void launch_small_live(const PyrParams& p, const CanvasParams& c, uint8_t* table, hipStream_t s) {
     const int cw = c.w0 >> c.small_base, ch = c.h0 >> c.small_base;
-    dim3 block(64, 4, 1), grid((cw + kSmallTileW - 1) / kSmallTileW, (ch + kSmallTileH - 1) / kSmallTileH, 1);
+    dim3 block(64, 4, 1), grid((cw + kFuseTileW - 1) / kFuseTileW, (ch + kFuseTileH - 1) / kFuseTileH, 1);
     hipLaunchKernelGGL(small_live_kernel, grid, block, 0, s, p, c, table);
 }
 
@@ -1968,52 +1999,57 @@ __global__ __launch_bounds__(256) void small_fused_kernel(PyrParams P, CanvasSet
     const CanvasParams& C = CS.c[blockIdx.z / 3];
     const int pl = blockIdx.z % 3;
     __shared__ __attribute__((aligned(16))) uint8_t box_lds[kFuseLdsBytes];
-    __shared__ int16_t lds[kSmallLdsElems];
+    __shared__ int16_t lds[kFuseCollapseElems];
     const int k0 = C.small_base, nb = C.bands, J = nb - k0;
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int tx = tid & 31, ty = tid >> 5;
     const unsigned livebits = C.small_live[blockIdx.y * gridDim.x + blockIdx.x];
     // canvas footprints of this workgroup's tile at every fused level (block-uniform: scalar registers)
     int rx0[kFuseMaxJ + 1], ry0[kFuseMaxJ + 1], rw[kFuseMaxJ + 1], rh[kFuseMaxJ + 1], ro[kFuseMaxJ + 1];
-    {
-        const int cw = C.w0 >> k0, ch = C.h0 >> k0;
-        int x0 = blockIdx.x * kSmallTileW, y0 = blockIdx.y * kSmallTileH;
-        int x1 = min(x0 + kSmallTileW, cw) - 1, y1 = min(y0 + kSmallTileH, ch) - 1;
-        int o = 0;
+    fuse_footprints(C, blockIdx.x, blockIdx.y, rx0, ry0, rw, rh, ro);
+    int acc[kFuseMaxJ + 1][4];
+    float W[kFuseMaxJ + 1][4];
 #pragma unroll
-        for (int j = 0; j <= kFuseMaxJ; j++) {
-            const int l = k0 + j;
-            rx0[j] = x0; ry0[j] = y0; rw[j] = x1 - x0 + 1; rh[j] = y1 - y0 + 1;
-            ro[j] = o;
-            if (j > 0) o += rw[j] * rh[j];
-            const int nw = C.w0 >> (l + 1), nh = C.h0 >> (l + 1);
-            x0 = max((x0 >> 1) - 1, 0); y0 = max((y0 >> 1) - 1, 0);
-            x1 = min((x1 >> 1) + 1, max(nw - 1, 0)); y1 = min((y1 >> 1) + 1, max(nh - 1, 0));
+    for (int j = 0; j <= kFuseMaxJ; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            W[j][q] = 0.f;
+            acc[j][q] = 0;
         }
-    }
-    int acc[kFuseMaxJ + 1];
-    float W[kFuseMaxJ + 1];
-#pragma unroll
-    for (int j = 0; j <= kFuseMaxJ; j++) {
-        W[j] = 0.f;
-        acc[j] = 0;
-    }
     bool first = true;
-#pragma unroll
-    for (int i = 0; i < kCams; i++) {  // feed order
+    // A real loop over the cameras, ONE copy of the body: unrolled eight times the kernel is 60 KB of code and workgroups on
+    // different cameras evict each other from the instruction cache.  The camera block is read through the kernarg segment
+    // (PyrParams is the first kernel argument) - indexing the by-value argument with a runtime index would copy it to scratch
+    static_assert(offsetof(PyrParams, cam) == 0, "PyrParams::cam first");
+#pragma unroll 1
+    for (int i = 0; i < C.cam_n; i++) {  // feed order
         if (!((livebits >> i) & 1u)) continue;  // block-uniform
-        const PyrCam& c = P.cam[C.cam_lo + i];
-        // this lane's weight at its pixel of every level (0 outside the camera's tile): in flight with the pixel loads below
-        float wv[kFuseMaxJ + 1];
+        typedef const PyrCam __attribute__((address_space(4))) KCam;
+        KCam* kc = (KCam*)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + (size_t)(C.cam_lo + i) * sizeof(PyrCam));
+        struct {  // what this kernel needs of the camera, in scalar registers
+            const uint8_t* g0; int pitch0, plane0, tx, ty, w0, h0;
+            const float* wgt[kFuseMaxJ + 1]; int wpitch[kFuseMaxJ + 1];
+        } c;
+        c.g0 = kc->lvl[k0]; c.pitch0 = kc->pitch[k0]; c.plane0 = kc->plane[k0];
+        c.tx = kc->tx; c.ty = kc->ty; c.w0 = kc->w0; c.h0 = kc->h0;
 #pragma unroll
         for (int j = 0; j <= kFuseMaxJ; j++) {
-            wv[j] = 0.f;
-            if (j <= J && tx < rw[j] && ty < rh[j]) {
-                const int l = k0 + j;
-                const int x = rx0[j] + tx - (c.tx >> l), y = ry0[j] + ty - (c.ty >> l);
-                if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l)) wv[j] = cam_weight(c, l, x, y);
-            }
+            c.wgt[j] = kc->wgt[min(k0 + j, kLevels - 1)];
+            c.wpitch[j] = kc->wpitch[min(k0 + j, kLevels - 1)];
         }
+        // this lane's weights at its pixels of every level (0 outside the camera's tile): in flight with the pixel loads below
+        float wv[kFuseMaxJ + 1][4];
+#pragma unroll
+        for (int j = 0; j <= kFuseMaxJ; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                wv[j][q] = 0.f;
+                int px, py;
+                if (j <= J && q < fuse_q(j) && fuse_pixel(j, q, tid, rw[j], rh[j], px, py)) {
+                    const int l = k0 + j;
+                    const int x = rx0[j] + px - (c.tx >> l), y = ry0[j] + py - (c.ty >> l);
+                    if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l)) wv[j][q] = c.wgt[j][(size_t)y * c.wpitch[j] + x];  // k0 >= 1: f32 levels
+                }
+            }
         if (!first) __syncthreads();  // the previous camera's boxes stay until every lane has read its taps
         first = false;
         // what is needed of every camera level, coarse to fine (block-uniform)
@@ -2029,8 +2065,7 @@ __global__ __launch_bounds__(256) void small_fused_kernel(PyrParams P, CanvasSet
                 b.x0 = max(rx0[j] - (c.tx >> l), 0); b.y0 = max(ry0[j] - (c.ty >> l), 0);
                 b.x1 = min(rx0[j] + rw[j] - 1 - (c.tx >> l), dw - 1); b.y1 = min(ry0[j] + rh[j] - 1 - (c.ty >> l), dh - 1);
                 if (b.x1 < b.x0 || b.y1 < b.y0) { b.x0 = b.y0 = 0; b.x1 = b.y1 = -1; }
-                constexpr int jn_max = kFuseMaxJ;
-                const int jn = j + 1 <= jn_max ? j + 1 : j;
+                const int jn = j + 1 <= kFuseMaxJ ? j + 1 : j;
                 if (j < J && B[jn].x1 >= B[jn].x0) {
                     const FuseBox& n = B[jn];
                     const int fx0 = max(2 * n.x0 - 2, 0), fy0 = max(2 * n.y0 - 2, 0);
@@ -2047,22 +2082,23 @@ __global__ __launch_bounds__(256) void small_fused_kernel(PyrParams P, CanvasSet
             }
         }
         // level k0: global -> LDS, four virtual columns per lane and step (lanes = 32 column groups x 8 rows: no divisions);
-        // the loads of a lane (at most 9 rows) are all issued before the first is stored
+        // the loads of a lane (at most 10 rows) are all issued before the first is stored
         {
             const FuseBox& b = B[0];
             const int dw = c.w0 >> k0, dh = c.h0 >> k0;
-            const int gpr = b.bw >> 2;  // <= 23 column groups
-            constexpr int kRowSteps = 9;  // box rows <= 65
-            const uint8_t* plane = c.lvl[k0] + (size_t)pl * c.plane[k0];
-            if (tx < gpr) {
-                const int vx = b.bx0 + 4 * tx;
+            const int gpr = b.bw >> 2;    // <= 31 column groups
+            constexpr int kRowSteps = 10; // box rows <= 73
+            const int gx = tid & 31, gy = tid >> 5;
+            const uint8_t* plane = c.g0 + (size_t)pl * c.plane0;
+            if (gx < gpr) {
+                const int vx = b.bx0 + 4 * gx;
                 const bool inside = vx >= 0 && vx + 3 < dw;
                 unsigned d[kRowSteps];
                 if (inside) {
 #pragma unroll
                     for (int k = 0; k < kRowSteps; k++) {
-                        const int cy = ty + 8 * k;
-                        const unsigned rowoff = (unsigned)reflect101_idx(b.by0 + min(cy, b.bh - 1), dh) * (unsigned)c.pitch[k0] + (unsigned)vx;
+                        const int cy = gy + 8 * k;
+                        const unsigned rowoff = (unsigned)reflect101_idx(b.by0 + min(cy, b.bh - 1), dh) * (unsigned)c.pitch0 + (unsigned)vx;
                         d[k] = *reinterpret_cast<const unsigned*>(plane + rowoff);
                     }
                 } else {
@@ -2071,70 +2107,102 @@ __global__ __launch_bounds__(256) void small_fused_kernel(PyrParams P, CanvasSet
                     for (int q = 0; q < 4; q++) xr[q] = reflect101_idx(vx + q, dw);
 #pragma unroll
                     for (int k = 0; k < kRowSteps; k++) {
-                        const int cy = ty + 8 * k;
-                        const uint8_t* row = plane + (unsigned)reflect101_idx(b.by0 + min(cy, b.bh - 1), dh) * (unsigned)c.pitch[k0];
+                        const int cy = gy + 8 * k;
+                        const uint8_t* row = plane + (unsigned)reflect101_idx(b.by0 + min(cy, b.bh - 1), dh) * (unsigned)c.pitch0;
                         d[k] = (unsigned)row[xr[0]] | ((unsigned)row[xr[1]] << 8) | ((unsigned)row[xr[2]] << 16) | ((unsigned)row[xr[3]] << 24);
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < kRowSteps; k++) {
-                    const int cy = ty + 8 * k;
-                    if (cy < b.bh) *reinterpret_cast<unsigned*>(box_lds + b.off + cy * b.bw + 4 * tx) = d[k];
+                    const int cy = gy + 8 * k;
+                    if (cy < b.bh) *reinterpret_cast<unsigned*>(box_lds + b.off + cy * b.bw + 4 * gx) = d[k];
                 }
             }
         }
         __syncthreads();
-        // levels k0+1 .. nb: pyrDown LDS -> LDS, one cell (pads included) per lane and step (lanes = 64 columns x 4 rows)
+        // levels k0+1 .. nb: pyrDown LDS -> LDS, a group of four cells (pads included) per lane and step (lanes = 16 groups x
+        // 16 rows).  Interior groups read 16 bytes per source row as four dwords and take pyr_down_hrow's two-dot4 windows;
+        // groups that touch a border or leave the needed range go cell by cell through the reflected coordinates
 #pragma unroll
         for (int j = 1; j <= kFuseMaxJ; j++) {
             if (j > J) continue;
             const FuseBox& b = B[j];
             const FuseBox& a = B[j - 1];
             const int l = k0 + j;
-            const int dw = c.w0 >> l, dh = c.h0 >> l;
-            const int cx = threadIdx.x;  // box rows are at most 48 bytes
-            if (cx < b.bw) {
-                const int qx = reflect101_idx(b.bx0 + cx, dw);
-                const bool xin = qx >= b.x0 && qx <= b.x1;
-                const int col = 2 * qx - 2 - a.bx0;  // even; the window is bytes col .. col + 4 of the row
-                const unsigned sh = (unsigned)col & 3u;
-                for (int cy = threadIdx.y; cy < b.bh; cy += 4) {
-                    const int qy = reflect101_idx(b.by0 + cy, dh);
-                    int out = 0;
-                    if (xin && qy >= b.y0 && qy <= b.y1) {
-                        const uint8_t* S = box_lds + a.off + (2 * qy - 2 - a.by0) * a.bw + (col & ~3);
-                        int v = 128;
+            const int dw = c.w0 >> l, dh = c.h0 >> l;            // this level
+            const int aw = c.w0 >> (l - 1), ah = c.h0 >> (l - 1);  // the finer level it is made from
+            const int gx = tid & 15;  // box rows are at most 64 bytes = 16 groups
+            const uint8_t* A0 = box_lds + a.off;
+            if (4 * gx < b.bw) {
+                const int vx = b.bx0 + 4 * gx;
+                const bool xfast = vx >= b.x0 && vx + 3 <= b.x1 && 2 * vx - 2 >= 0 && 2 * (vx + 3) + 2 <= aw - 1;
+                for (int cy = tid >> 4; cy < b.bh; cy += 16) {
+                    const int vy = b.by0 + cy;
+                    unsigned packed = 0;
+                    if (xfast && vy >= b.y0 && vy <= b.y1 && 2 * vy - 2 >= 0 && 2 * vy + 2 <= ah - 1) {
+                        const uint8_t* S = A0 + (2 * vy - 2 - a.by0) * a.bw + (2 * vx - 4 - a.bx0);  // dword aligned
+                        int v[4] = {128, 128, 128, 128};
 #pragma unroll
                         for (int t = 0; t < 5; t++) {
-                            const unsigned d0 = *reinterpret_cast<const unsigned*>(S + t * a.bw);
-                            const unsigned d1 = *reinterpret_cast<const unsigned*>(S + t * a.bw + 4);
-                            const unsigned lo4 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-                            const unsigned t5 = (d1 >> (8 * sh)) & 0xffu;
-                            const int h = (int)__builtin_amdgcn_udot4(lo4, 0x04060401u, t5, false);
-                            v += h * (t == 0 || t == 4 ? 1 : (t == 2 ? 6 : 4));
+                            const unsigned* r32 = reinterpret_cast<const unsigned*>(S + t * a.bw);
+                            int h[4];
+                            pyr_down_hrow(make_uint4(r32[0], r32[1], r32[2], r32[3]), h);
+                            const int wt = t == 0 || t == 4 ? 1 : (t == 2 ? 6 : 4);
+#pragma unroll
+                            for (int k = 0; k < 4; k++) v[k] += h[k] * wt;
                         }
-                        out = v >> 8;  // no saturate: the taps sum to 256
+#pragma unroll
+                        for (int k = 0; k < 4; k++) packed |= (unsigned)(v[k] >> 8) << (8 * k);  // no saturate: the taps sum to 256
+                    } else {
+                        const int qy = reflect101_idx(vy, dh);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int qx = reflect101_idx(vx + k, dw);
+                            int out = 0;
+                            if (qx >= b.x0 && qx <= b.x1 && qy >= b.y0 && qy <= b.y1) {
+                                const int col = 2 * qx - 2 - a.bx0;  // even; the window is bytes col .. col + 4 of the row
+                                const unsigned sh = (unsigned)col & 3u;
+                                const uint8_t* S = A0 + (2 * qy - 2 - a.by0) * a.bw + (col & ~3);
+                                int v = 128;
+#pragma unroll
+                                for (int t = 0; t < 5; t++) {
+                                    const unsigned d0 = *reinterpret_cast<const unsigned*>(S + t * a.bw);
+                                    const unsigned d1 = *reinterpret_cast<const unsigned*>(S + t * a.bw + 4);
+                                    const unsigned lo4 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                                    const unsigned t5 = (d1 >> (8 * sh)) & 0xffu;
+                                    v += (int)__builtin_amdgcn_udot4(lo4, 0x04060401u, t5, false) * (t == 0 || t == 4 ? 1 : (t == 2 ? 6 : 4));
+                                }
+                                out = v >> 8;
+                            }
+                            packed |= (unsigned)out << (8 * k);
+                        }
                     }
-                    box_lds[b.off + cy * b.bw + cx] = (uint8_t)out;
+                    *reinterpret_cast<unsigned*>(box_lds + b.off + cy * b.bw + 4 * gx) = packed;
                 }
             }
             __syncthreads();
         }
-        // this camera's weighted Laplacian at the lane's pixel of every level
+        // this camera's weighted Laplacian at the lane's pixels of every level
 #pragma unroll
         for (int j = 0; j <= kFuseMaxJ; j++) {
-            if (j > J || wv[j] == 0.f) continue;
+            if (j > J) continue;
             const int l = k0 + j;
             const FuseBox& b = B[j];
-            const int x = rx0[j] + tx - (c.tx >> l), y = ry0[j] + ty - (c.ty >> l);
-            W[j] += wv[j];
-            int lap = box_lds[b.off + (y - b.by0) * b.bw + (x - b.bx0)];
-            if (j < J) {
-                const FuseBox& u = B[j + 1 <= kFuseMaxJ ? j + 1 : j];
-                const uint8_t* S = box_lds + u.off - u.by0 * u.bw - u.bx0;  // (0, 0) of the real plane
-                lap = sat16i(lap - pyr_up_px<uint8_t>(S, (c.w0 >> l) >> 1, (c.h0 >> l) >> 1, u.bw, x, y));
+            const FuseBox& u = B[j + 1 <= kFuseMaxJ ? j + 1 : j];
+#pragma unroll
+            for (int q = 0; q < fuse_q(j); q++) {
+                if (wv[j][q] == 0.f) continue;
+                int px, py;
+                fuse_pixel(j, q, tid, rw[j], rh[j], px, py);
+                const int x = rx0[j] + px - (c.tx >> l), y = ry0[j] + py - (c.ty >> l);
+                W[j][q] += wv[j][q];
+                int lap = box_lds[b.off + (y - b.by0) * b.bw + (x - b.bx0)];
+                if (j < J) {
+                    const uint8_t* S = box_lds + u.off - u.by0 * u.bw - u.bx0;  // (0, 0) of the real plane
+                    lap = sat16i(lap - pyr_up_px<uint8_t>(S, (c.w0 >> l) >> 1, (c.h0 >> l) >> 1, u.bw, x, y));
+                }
+                acc[j][q] = (int16_t)(acc[j][q] + (int16_t)(int)((float)lap * wv[j][q]));
             }
-            acc[j] = (int16_t)(acc[j] + (int16_t)(int)((float)lap * wv[j]));
         }
     }
     __syncthreads();
@@ -2144,19 +2212,21 @@ __global__ __launch_bounds__(256) void small_fused_kernel(PyrParams P, CanvasSet
         if (j > J) continue;  // block-uniform
         const int l = k0 + j;
         const int cw = C.w0 >> l, ch = C.h0 >> l;
-        const int nx = cw >> 1, ny = ch >> 1;
-        if (tx < rw[j] && ty < rh[j]) {
-            const int X = rx0[j] + tx, Y = ry0[j] + ty;
+        const int jc = j + 1 <= kFuseMaxJ ? j + 1 : j;
+#pragma unroll
+        for (int q = 0; q < fuse_q(j); q++) {
+            int px, py;
+            if (!fuse_pixel(j, q, tid, rw[j], rh[j], px, py)) continue;
+            const int X = rx0[j] + px, Y = ry0[j] + py;
             int v;
-            if (W[j] == 1.0f) v = toward_zero_by_one(acc[j]);
-            else v = (int16_t)(int)((float)acc[j] / (W[j] + 1e-5f));
+            if (W[j][q] == 1.0f) v = toward_zero_by_one(acc[j][q]);
+            else v = (int16_t)(int)((float)acc[j][q] / (W[j][q] + 1e-5f));
             if (j < J) {
-                const int jc = j + 1 <= kFuseMaxJ ? j + 1 : j;
                 // out_{l+1} over its footprint, as a plane whose (0, 0) is canvas pixel (0, 0) of that level
                 const int16_t* S = lds + ro[jc] - ry0[jc] * rw[jc] - rx0[jc];
-                v = sat16i(v + pyr_up_px<int16_t>(S, nx, ny, rw[jc], X, Y));
+                v = sat16i(v + pyr_up_px<int16_t>(S, cw >> 1, ch >> 1, rw[jc], X, Y));
             }
-            if (j > 0) lds[ro[j] + ty * rw[j] + tx] = (int16_t)v;
+            if (j > 0) lds[ro[j] + py * rw[j] + px] = (int16_t)v;
             else C.img[l][(size_t)pl * C.cplane[l] + (size_t)Y * C.cpitch[l] + X] = (int16_t)v;
         }
         __syncthreads();
@@ -2173,7 +2243,7 @@ void launch_blend_small(const PyrParams& p, const CanvasSet& cs, hipStream_t s) 
     }
     dim3 block(64, 4, 1);
     if (c.small_fused) {
-        dim3 gf((cw + kSmallTileW - 1) / kSmallTileW, (ch + kSmallTileH - 1) / kSmallTileH, cs.n * 3);
+        dim3 gf((cw + kFuseTileW - 1) / kFuseTileW, (ch + kFuseTileH - 1) / kFuseTileH, cs.n * 3);
         hipLaunchKernelGGL(small_fused_kernel, gf, block, 0, s, p, cs);
         return;
     }

@@ -100,7 +100,7 @@ struct CanvasParams {
                                // small_base itself: the per-frame pyrDown chain stops at level small_base
     const uint16_t* order0;    // level 0, or nullptr: per XCD band (order_per entries each, 0xffff = none) the 128 x 16-pixel
     int order_per, order_gx;   // workgroup tiles in the order they are dispatched - seam tiles first; tile = by * order_gx + bx
-    const uint8_t* small_live; // small_fused: per 32 x 8 tile of level small_base, the cameras with weight on its footprint
+    const uint8_t* small_live; // small_fused: per 64 x 16 tile of level small_base, the cameras with weight on its footprint
     int cam_lo, cam_n;         // this canvas blends cameras [cam_lo, cam_lo + cam_n) of the PyrParams it is launched with
     int w0, h0;                // padded canvas size
     int bands;
@@ -142,10 +142,10 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
 // the small levels small_base..bands in two launches (one when CanvasParams::small_fused)
 constexpr int kSmallFusedMaxLevels = 4;   // small_fused_kernel handles bands - small_base + 1 <= 4 levels
 void launch_blend_small(const PyrParams& p, const CanvasSet& cs, hipStream_t s);
-// the live-camera table of small_fused_kernel (run when masks change): one byte per 32 x 8 tile of level small_base
+// the live-camera table of small_fused_kernel (run when masks change): one byte per 64 x 16 tile of level small_base
 void launch_small_live(const PyrParams& p, const CanvasParams& c, uint8_t* table, hipStream_t s);
 inline size_t small_live_bytes(const CanvasParams& c) {
-    return (size_t)(((c.w0 >> c.small_base) + 31) / 32) * (((c.h0 >> c.small_base) + 7) / 8);
+    return (size_t)(((c.w0 >> c.small_base) + 63) / 64) * (((c.h0 >> c.small_base) + 15) / 16);  // 64 x 16 tiles
 }
 // per 128 x 16-pixel tile of level 0 (gx x gy of them over the hull of the cut): does it hold a wave with no single owner?
 void launch_tile_mixed(const CanvasParams& c, int gx, int gy, uint8_t* flags, hipStream_t s);
