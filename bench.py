@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--force-sharded-path", action="store_true", help="diagnostic: run the N>1 step code at N=1")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="N=1: frame slots / streams the K steps are dealt over round-robin (1 = one frame at a time)")
+    ap.add_argument("--cold-only", action="store_true",
+                    help="N=1: ONLY K steps one frame at a time over six rotating frame sets (the roofline.cold measurement), for a "
+                         "rocprofv3 --kernel-trace --stats summary of exactly that loop; prints the cold object alone")
     ap.add_argument("--no-isolated-pass", action="store_true",
                     help="N=1: skip the K steps composed one frame at a time (kernel durations without overlap)")
     args = ap.parse_args()
@@ -249,6 +252,29 @@ def main():
                                   "error": "camera-sharded step failed with every exchange tried %s: %s" % (tried, sharded_failed)}), flush=True)
             raise SystemExit(3)
 
+    if args.cold_only and world == 1:
+        cold_sets = 6
+        rot = [[[t.clone() for t in fr] for fr in frames] for _ in range(cold_sets)]
+        rot_ptr = [[[t.data_ptr() for t in fr] for fr in st] for st in rot]
+        for c in ctxs:
+            c.select_frame_slot(0)
+            c.set_profiling(True)
+        for k in range(args.warmup + args.steps):
+            if k == args.warmup:
+                torch.cuda.synchronize()
+                for c in ctxs:
+                    c.stage_stats(reset=True)
+            fp = rot_ptr[k % cold_sets]
+            ctxs[0].compose_pair(ctxs[1], fp[0], strides, outs[0].data_ptr(), ow * 3, fp[1], strides, outs[1].data_ptr(), ow * 3, stream)
+        torch.cuda.synchronize()
+        ms, n = ctxs[0].stage_stats(reset=True)
+        src_b, dst_b = ctxs[0].warp_bytes()
+        alg = (src_b + dst_b) * NG
+        us = ms[0] / n[0] * 1e3
+        print(json.dumps({"roofline_cold": {"kernel": "warp_tiles_lut_kernel", "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": alg,
+                                            "achieved": round(alg / us / 1e3, 1), "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4),
+                                            "frame_sets": cold_sets, "steps": args.steps}}), flush=True)
+        return
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize()

@@ -1,10 +1,10 @@
 # HBM bytes of EVERY kernel of the compose path per 8-camera frame: FETCH_SIZE and WRITE_SIZE in separate passes
-# (MI355X_MICROARCH.md, HBM section; gfx950: FETCH_SIZE x2) over tools/warp_ablate8.py.  Usage: bash tools/pmc_traffic_all.sh
+# (MI355X_MICROARCH.md, HBM section; gfx950: FETCH_SIZE x2) over tools/frames_one_at_a_time.py.  Usage: bash tools/pmc_traffic_all.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/taF $R/gpurun_out/taW
-timeout -k 10 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/taF -o run --output-format csv -- python3 $R/tools/warp_ablate8.py > $R/gpurun_out/taF.log 2>&1 || exit 1
-timeout -k 10 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/taW -o run --output-format csv -- python3 $R/tools/warp_ablate8.py > $R/gpurun_out/taW.log 2>&1 || exit 1
+timeout -k 10 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/taF -o run --output-format csv -- python3 $R/tools/frames_one_at_a_time.py > $R/gpurun_out/taF.log 2>&1 || exit 1
+timeout -k 10 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/taW -o run --output-format csv -- python3 $R/tools/frames_one_at_a_time.py > $R/gpurun_out/taW.log 2>&1 || exit 1
 python3 - <<'PY'
 import csv, collections, json, os
 R = os.environ["GRAFT_REPO_ROOT"]

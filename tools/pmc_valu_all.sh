@@ -1,9 +1,9 @@
 # one SQ pass over whole frames: vector instructions, waves and busy cycles of EVERY kernel of the compose path
-# (tools/warp_ablate8.py = 110 8-camera frames, one at a time).  Usage on the GPU box: bash tools/pmc_valu_all.sh
+# (tools/frames_one_at_a_time.py = 110 8-camera frames, one at a time).  Usage on the GPU box: bash tools/pmc_valu_all.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/sqall
-timeout -k 10 150 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_BUSY_CYCLES -d $R/gpurun_out/sqall -o run --output-format csv -- python3 $R/tools/warp_ablate8.py > $R/gpurun_out/sqall.log 2>&1 || exit 1
+timeout -k 10 150 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_BUSY_CYCLES -d $R/gpurun_out/sqall -o run --output-format csv -- python3 $R/tools/frames_one_at_a_time.py > $R/gpurun_out/sqall.log 2>&1 || exit 1
 python3 - <<'PY'
 import csv, collections, json, os
 R = os.environ["GRAFT_REPO_ROOT"]
