@@ -96,3 +96,32 @@ def test_sharded_compose_across_processes(world):
         p.join(timeout=60)
     assert sorted(r for r, _ in res) == list(range(world))
     assert all(ok for _, ok in res)
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_of_the_library_on_one_rank():
+    """what CAN be checked about the RCCL exchange on a one-GPU box: librccl loads, pano_rccl_unique_id + pano_rccl_comm_create
+    make a world-size-1 communicator on the real device, pano_gather_slots runs its ncclGroupStart / End around zero transfers
+    (every slot is owned by the root) and the blend that follows still gives the single-GPU panorama"""
+    import importlib
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import c2_group, synth_frame
+    pano = importlib.import_module("img-stitching_amd")
+    d = c2_group(w=640, h=360, f=334.0)
+    ctx = pano.Context(4, 640, 360, scale=d["scale"], num_bands=3, device=0)
+    for i in range(4):
+        ctx.set_camera(i, d["K"][i], d["R"][i])
+    ctx.prepare(); ctx.build_masks_voronoi()
+    frames = [synth_frame(640, 360, 90 + i) for i in range(4)]
+    want = ctx.compose_host(frames)
+    uid = pano.Context.rccl_unique_id()
+    comm = ctx.rccl_comm_create(uid, 1, 0)
+    try:
+        ctx.feed_cameras_host(0b1111, frames)
+        ctx.gather_slots(comm, 0, 0, [0, 0, 0, 0])          # stream 0 = the ctx's own stream
+        assert np.array_equal(ctx.blend_host(), want)
+        with pytest.raises(pano.PanoError):
+            ctx.gather_slots(None, 0, 0, [0, 0, 0, 0])      # no communicator
+    finally:
+        ctx.rccl_comm_destroy(comm)
