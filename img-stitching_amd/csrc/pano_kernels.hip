@@ -1820,7 +1820,12 @@ constexpr int kSmallLdsElems = 512;  // int16 per plane for all coarser regions 
 // One workgroup = a 32 x 8 tile of level small_base; its footprint at every coarser level fits the same 32 x 8
 // thread grid (18 x 6, 11 x 5, 8 x 5, ...), so each lane owns at most ONE pixel per level: short serial code per
 // lane, 4 workgroups per CU.
-__global__ __launch_bounds__(256) void collapse_small_kernel(CanvasSet CS) {
+// NORM: the workgroup also computes norm_l over its footprints itself (norm_small_kernel's per-pixel code) instead of reading
+// it from the canvas buffers: the small levels are then ONE launch, not two.  The footprints overlap between neighbouring tiles
+// (419 pixels per tile for 336 of its own with three levels), so a quarter more norm work than the separate launch does, for
+// one launch (~4 us of latency) less.  P is only read when NORM.
+template <bool NORM>
+__global__ __launch_bounds__(256) void collapse_small_kernel(PyrParams P, CanvasSet CS) {
     const CanvasParams& C = CS.c[blockIdx.z];
     __shared__ int16_t lds[3 * kSmallLdsElems];
     const int k0 = C.small_base, nb = C.bands;
@@ -1850,11 +1855,45 @@ __global__ __launch_bounds__(256) void collapse_small_kernel(CanvasSet CS) {
     for (int j = 0; j < kLevels; j++) {
         const int l = k0 + j;
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            int16_t v = 0;
-            if (l <= nb && tx < rw[j] && ty < rh[j])
-                v = C.img[l][(size_t)pl * C.cplane[l] + (size_t)(ry0[j] + ty) * C.cpitch[l] + rx0[j] + tx];
-            nv[j][pl] = v;
+        for (int pl = 0; pl < 3; pl++) nv[j][pl] = 0;
+        if (!(l <= nb && tx < rw[j] && ty < rh[j])) continue;
+        if (!NORM) {
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+                nv[j][pl] = C.img[l][(size_t)pl * C.cplane[l] + (size_t)(ry0[j] + ty) * C.cpitch[l] + rx0[j] + tx];
+        } else {
+            // norm_l = (short)(sum_cams (short)(lap_l * w_l) / (sum_cams w_l + 1e-5f)) at canvas pixel (X, Y) of level l
+            const int X = rx0[j] + tx, Y = ry0[j] + ty;
+            const int cam_lo = C.cam_lo, cam_n = C.cam_n;
+            // Every camera whose tile holds the pixel is read, weight or not: (short)(lap * 0.f) == 0 and W + 0.f == W, so the
+            // result is the same as skipping the weightless ones - and the pixel loads do not wait for the weight loads
+            int acc[3] = {0, 0, 0};
+            float W = 0.f;
+#pragma unroll
+            for (int i = 0; i < kCams; i++) {
+                if (i >= cam_n) continue;
+                const PyrCam& c = P.cam[cam_lo + i];
+                const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
+                const int tw = c.w0 >> l, th = c.h0 >> l;
+                if (!((unsigned)x < (unsigned)tw && (unsigned)y < (unsigned)th)) continue;
+                const float w = cam_weight(c, l, x, y);
+                W += w;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    int lap = c.lvl[l][(size_t)k * c.plane[l] + (size_t)y * c.pitch[l] + x];
+                    if (l < nb)
+                        lap = sat16i(lap - pyr_up_px<uint8_t>(c.lvl[l + 1] + (size_t)k * c.plane[l + 1], tw >> 1, th >> 1,
+                                                              c.pitch[l + 1], x, y));
+                    acc[k] = (int16_t)(acc[k] + (int16_t)(int)((float)lap * w));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                int v;
+                if (W == 1.0f) v = toward_zero_by_one(acc[k]);
+                else v = (int16_t)(int)((float)acc[k] / (W + 1e-5f));
+                nv[j][k] = (int16_t)v;
+            }
         }
     }
     // phase 2: collapse coarse -> fine through LDS
@@ -2247,10 +2286,15 @@ void launch_blend_small(const PyrParams& p, const CanvasSet& cs, hipStream_t s) 
         hipLaunchKernelGGL(small_fused_kernel, gf, block, 0, s, p, cs);
         return;
     }
+    if (c.small_merged) {  // normalise + collapse in one launch
+        dim3 gm((cw + kSmallTileW - 1) / kSmallTileW, (ch + kSmallTileH - 1) / kSmallTileH, cs.n);
+        hipLaunchKernelGGL(collapse_small_kernel<true>, gm, block, 0, s, p, cs);
+        return;
+    }
     dim3 g1((cw + 63) / 64, (ch + 3) / 4, (c.bands - k0 + 1) * cs.n);
     hipLaunchKernelGGL(norm_small_kernel, g1, block, 0, s, p, cs);
     dim3 g2((cw + kSmallTileW - 1) / kSmallTileW, (ch + kSmallTileH - 1) / kSmallTileH, cs.n);
-    hipLaunchKernelGGL(collapse_small_kernel, g2, block, 0, s, cs);
+    hipLaunchKernelGGL(collapse_small_kernel<false>, g2, block, 0, s, p, cs);
 }
 
 void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {

@@ -96,6 +96,7 @@ struct CanvasParams {
     int blend_split;           // PANO_BLEND_PLANES != 0: one colour plane per lane on the canvas levels >= 1 (default)
     int l0_strips;             // PANO_L0_STRIPS = 2 / 4 / 8: level 0 by blend_level0_strip_kernel<S>; 0 (default): one block per lane
     int small_base;            // >0: levels small_base..bands run as one normalise launch + one LDS collapse launch
+    int small_merged;          // 1: the normalise and the collapse launch are ONE launch (collapse_small_kernel<true>)
     int small_fused;           // 1: ... and as ONE launch (small_fused_kernel) that also builds the camera levels above
                                // small_base itself: the per-frame pyrDown chain stops at level small_base
     const uint16_t* order0;    // level 0, or nullptr: per XCD band (order_per entries each, 0xffff = none) the 128 x 16-pixel
