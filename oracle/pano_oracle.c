@@ -745,8 +745,9 @@ void po_blender_blend(po_blender* b, int16_t* dst, uint8_t* dst_mask) {
     }
     int nb = b->num_bands;
     for (int i = 0; i <= nb; i++) {
-        size_t cnt = (size_t)b->lw[i] * b->lh[i];
-        for (size_t k = 0; k < cnt; k++) {
+        long cnt = (long)b->lw[i] * b->lh[i];
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (long k = 0; k < cnt; k++) {
             float wv = b->wgt[i][k] + WEIGHT_EPS;
             b->lap[i][k * 3 + 0] = (int16_t)(b->lap[i][k * 3 + 0] / wv);
             b->lap[i][k * 3 + 1] = (int16_t)(b->lap[i][k * 3 + 1] / wv);
@@ -754,13 +755,16 @@ void po_blender_blend(po_blender* b, int16_t* dst, uint8_t* dst_mask) {
         }
     }
     for (int i = nb; i > 0; --i) {
-        size_t cnt = (size_t)b->lw[i - 1] * b->lh[i - 1] * 3;
+        long cnt = (long)b->lw[i - 1] * b->lh[i - 1] * 3;
         int16_t* tmp = (int16_t*)malloc(sizeof(int16_t) * cnt);
         po_pyr_up_16s(b->lap[i], b->lw[i], b->lh[i], 3, tmp);
-        for (size_t k = 0; k < cnt; k++) b->lap[i - 1][k] = sat16((int)tmp[k] + (int)b->lap[i - 1][k]);
+        int16_t* lo = b->lap[i - 1];
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (long k = 0; k < cnt; k++) lo[k] = sat16((int)tmp[k] + (int)lo[k]);
         free(tmp);
     }
     int W = b->lw[0];
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int y = 0; y < fh; y++)
         for (int x = 0; x < fw; x++) {
             size_t s = (size_t)y * W + x, d = (size_t)y * fw + x;
