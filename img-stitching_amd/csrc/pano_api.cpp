@@ -1858,6 +1858,20 @@ pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b, const uint8_t* const* fa
     return PANO_OK;
 }
 
+// is [p, p + bytes) page-locked memory known to HIP?  (plain malloc memory: an error or "unregistered", by ROCm version)
+static bool is_pinned_host(const void* p, size_t bytes) {
+    if (!p || !bytes) return false;
+    auto one = [](const void* q) {
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+            (void)hipGetLastError();  // the failed query must not surface as a later launch error
+            return false;
+        }
+        return a.type == hipMemoryTypeHost;
+    };
+    return one(p) && one(static_cast<const char*>(p) + bytes - 1);
+}
+
 // process(vector<Mat>&, Mat&) (ocvstitcher.hpp:1141): host frames in, host panorama out, synchronous.  Page-locked caller
 // memory is DMA'd directly; pageable memory goes through the ctx's page-locked staging, copied by the pool's threads while the
 // previous camera's DMA runs (pano_hostcopy.hpp).  Works in frame slot 0 (pano.h) whatever slot the caller has selected.

@@ -7,11 +7,12 @@
 // controllers saturate), and each camera's DMA is queued the moment its rows are in place, so the copy of camera i+1
 // overlaps the DMA of camera i.  Caller memory that is already page-locked (hipHostMalloc / hipHostRegister /
 // pano_host_alloc) skips the staging and is DMA'd directly.
+// This header is plain C++ (no HIP): tests/test_graphcut_host.py builds the pool under ThreadSanitizer.
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
@@ -22,20 +23,6 @@
 #include <vector>
 
 namespace pano {
-
-// is [p, p + bytes) page-locked memory known to HIP?  (plain malloc memory: an error or "unregistered", by ROCm version)
-inline bool is_pinned_host(const void* p, size_t bytes) {
-    if (!p || !bytes) return false;
-    auto one = [](const void* q) {
-        hipPointerAttribute_t a{};
-        if (hipPointerGetAttributes(&a, q) != hipSuccess) {
-            (void)hipGetLastError();  // the failed query must not surface as a later launch error
-            return false;
-        }
-        return a.type == hipMemoryTypeHost;
-    };
-    return one(p) && one(static_cast<const char*>(p) + bytes - 1);
-}
 
 class CopyPool {
   public:

@@ -44,3 +44,15 @@ def test_host_max_flow_matches_oracle_label_for_label(po, tmp_path):
         assert np.array_equal(got[o:o + n], lab.reshape(-1)), k
         o += n
     assert o == got.size
+
+
+def test_copy_pool_under_thread_sanitizer(tmp_path):
+    """the copy-thread pool behind pano_compose_host (csrc/pano_hostcopy.hpp): three caller threads at once, built with
+    -fsanitize=thread - no data race, no lost wake-up, every byte where it belongs"""
+    exe = tmp_path / "copypool_harness"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-fsanitize=thread", "-fno-omit-frame-pointer",
+                           os.path.join(ROOT, "tests", "src", "copypool_harness.cpp"), "-o", str(exe), "-lpthread"])
+    for nthreads in ("8", "1", "3"):
+        out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, PANO_HOST_THREADS=nthreads, TSAN_OPTIONS="halt_on_error=1"))
+        assert out.returncode == 0 and "bad 0" in out.stdout, out.stdout[-500:] + out.stderr[-3000:]
