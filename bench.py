@@ -158,7 +158,9 @@ def main():
     exchange = {"kind": "torch"}
     owners = [sh.owner_ranks(NG * NC, NC, world, grp) for grp in range(NG)]
 
-    def step_sharded(k=0):
+    gather_events = []   # (start, stop) torch events around rank 0's side of the exchange, filled in the event pass only
+
+    def step_sharded(k=0, timed_exchange=False):
         for grp, plan in enumerate(plans):
             if plan["bits"]:
                 ctxs[grp].feed_cameras(plan["bits"], fptr[grp], strides, stream)
@@ -166,10 +168,17 @@ def main():
             if rehearsal:
                 torch.cuda.synchronize()
             if plan["moves"]:
+                ev = None
+                if timed_exchange and rank == 0 and not rehearsal:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()       # torch's current stream IS the launch stream (set_stream above)
                 if exchange["kind"] == "cabi":
                     ctxs[grp].gather_slots(exchange["comm"], rank, 0, owners[grp], stream)   # RCCL group on the launch stream
                 else:
                     sh.exchange_slots(dist, rank, buf, slot, plan["moves"], via_host=rehearsal)
+                if ev is not None:
+                    ev[1].record()
+                    gather_events.append(ev)
             if plan["blend_here"]:
                 ctxs[grp].blend(outs[grp].data_ptr(), ow * 3, stream)
             if plan["pano_from"] != 0:
@@ -296,7 +305,10 @@ def main():
         c.stage_stats(reset=True)
     t1 = time.perf_counter()
     for k in range(args.steps):
-        step(k)
+        if world > 1:
+            step_sharded(k, timed_exchange=True)
+        else:
+            step(k)
     torch.cuda.synchronize()
     dt_profiled = time.perf_counter() - t1
     stats_timed = None
@@ -345,10 +357,20 @@ def main():
             replicas_rate = round(world * args.steps / float(trt.item()), 1)
         except Exception:  # never let the side measurement break the contract line
             replicas_rate = None
+    per_rank_warp = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # SURVEY 8(e) "report": every rank's own K1 rate (its cameras' share of the algorithmic bytes / its mean launch time)
+        try:
+            ms_n = [c.stage_stats(reset=False) for c in ctxs]
+            mine = [sum(m[0][0] for m in ms_n), sum(m[1][0] for m in ms_n)]
+            allv = [None] * world
+            dist.all_gather_object(allv, mine)
+            per_rank_warp = allv
+        except Exception:  # noqa: BLE001
+            per_rank_warp = None
 
     result = None
     if rank == 0:
@@ -463,9 +485,26 @@ def main():
             "roofline": roofline,
             "ms_per_step_event_pass": round(dt_profiled / args.steps * 1e3, 4),
             "replicas_panoramas_per_s": replicas_rate,
+            "multi_gpu": None,
             "stage_us_per_launch": {k: round(stage_ms[i] / max(stage_n[i], 1) * 1e3, 2)
                                     for i, k in enumerate(("warp", "pyramid", "blend", "blend_level0"))},
         }
+        if world > 1:
+            mg = {"exchange": exchange["kind"] if any(pl["moves"] for pl in plans) else "none (a rank owns whole stitchers; finished half panoramas move)"}
+            if gather_events:
+                us = [a.elapsed_time(b) * 1e3 for a, b in gather_events]
+                recv_bytes = sum(cnt for pl, (_, slot) in zip(plans, slot_views) for (_, _, n_) in pl["moves"] for cnt in [n_ * slot])
+                senders = sum(len(pl["moves"]) for pl in plans)
+                mean_us = sum(us) / len(us)
+                per_group = recv_bytes / max(1, sum(1 for pl in plans if pl["moves"]))
+                mg.update({"gather_us_mean": round(mean_us, 1), "gather_bytes_per_group": int(per_group), "senders_per_step": senders,
+                           "root_ingress_GBps": round(per_group / mean_us / 1e3, 2),
+                           "note": "events on rank 0's launch stream around its side of the exchange (one ncclGroup per stitcher); "
+                                   "includes waiting for the senders' warps"})
+            if per_rank_warp:
+                launch_bytes = (src_b + dst_b) / NC * min(per_rank, NC)   # the cameras of ONE K1 launch of a rank (one stitcher's share)
+                mg["per_rank_warp_GBps"] = [round(launch_bytes / (m / n * 1e-3) / 1e9, 1) if n else None for m, n in per_rank_warp]
+            result["multi_gpu"] = mg
         if world == 1 and not args.no_host_paths:
             # the reference-shaped entry (host cv::Mat in, host cv::Mat out; H2D + compose + D2H, synchronous):
             # reported for DESIGN.md, never the `value`
