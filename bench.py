@@ -243,7 +243,18 @@ def main():
             tried.append(exchange["kind"])
             try:
                 step_sharded(0)
-                torch.cuda.synchronize()
+                # a peer that never posts its half would leave this rank's stream stuck for good: poll instead of blocking,
+                # and end the run with an error line rather than in the driver's timeout
+                done = torch.cuda.Event()
+                done.record()
+                t_wait = time.perf_counter()
+                while not done.query():
+                    if time.perf_counter() - t_wait > 120.0:
+                        if rank == 0:
+                            print(json.dumps({"metric": "stitched panoramas/sec (8x1080p->pano)", "value": None, "n_gpus": world,
+                                              "error": "the sharded trial step (%s exchange) did not complete within 120 s" % exchange["kind"]}), flush=True)
+                        os._exit(3)
+                    time.sleep(0.005)
                 if rank == 0 and not all(bool(torch.equal(a, b)) for a, b in zip(outs, ref)):
                     ok, why = False, "sharded panorama differs from the single-GPU panorama"
             except Exception as exc:  # noqa: BLE001
@@ -325,7 +336,7 @@ def main():
         stats_iso = [c.stage_stats(reset=True) for c in ctxs]
     # cold pass (N = 1): the same one-frame-at-a-time loop over SIX rotating frame sets (6 x 49.8 MB of frames + 17.5 MB of
     # remap table > the 256 MiB Infinity Cache), so that no K1 launch finds its inputs where the previous launch left them
-    stats_cold, cold_sets = None, 6
+    stats_cold, cold_sets, rotating_rate = None, 6, None
     if world == 1 and not args.no_isolated_pass:
         rot = [[[t.clone() for t in fr] for fr in frames] for _ in range(cold_sets)]
         rot_ptr = [[[t.data_ptr() for t in fr] for fr in st] for st in rot]
@@ -337,6 +348,28 @@ def main():
             ctxs[0].compose_pair(ctxs[1], fp[0], strides, outs[0].data_ptr(), ow * 3, fp[1], strides, outs[1].data_ptr(), ow * 3, stream)
         torch.cuda.synchronize()
         stats_cold = [c.stage_stats(reset=True) for c in ctxs]
+        # ... and the timed loop's own shape (F frames in flight, no events) over the same rotating sets: what `value` would be
+        # if no step found its frames where an earlier step left them
+        rotating_rate = None
+        if F > 1:
+            for c in ctxs:
+                c.set_profiling(False)
+            def step_rot(k):
+                f = k % F
+                ctxs[0].select_frame_slot(f); ctxs[1].select_frame_slot(f)
+                fp = rot_ptr[k % cold_sets]
+                o = outs_f[f]
+                ctxs[0].compose_pair(ctxs[1], fp[0], strides, o[0].data_ptr(), ow * 3, fp[1], strides, o[1].data_ptr(), ow * 3, flight[f])
+            for k in range(args.warmup):
+                step_rot(k)
+            torch.cuda.synchronize()
+            tr0 = time.perf_counter()
+            for k in range(args.steps):
+                step_rot(k)
+            torch.cuda.synchronize()
+            rotating_rate = round(args.steps / (time.perf_counter() - tr0), 1)
+            for c in ctxs:
+                c.select_frame_slot(0)
         del rot, rot_ptr
     # N > 1 only, extra information: the same K steps with every rank composing its OWN whole rig (replicas, no
     # exchange).  One MI355X composes a panorama in ~0.16 ms, less than it takes to move one half panorama (11.6 MB)
@@ -484,6 +517,7 @@ def main():
                                                                            else "RCCL gather to rank 0 (torch.distributed batch_isend_irecv)")))},
             "roofline": roofline,
             "ms_per_step_event_pass": round(dt_profiled / args.steps * 1e3, 4),
+            "rotating_inputs_panoramas_per_s": rotating_rate,
             "replicas_panoramas_per_s": replicas_rate,
             "multi_gpu": None,
             "stage_us_per_launch": {k: round(stage_ms[i] / max(stage_n[i], 1) * 1e3, 2)
