@@ -1,5 +1,5 @@
 // pano_api.cpp - C-ABI of libpano_hip.so (include/pano.h): context, buffers, launch sequencing.
-// Host code only; the arithmetic is in pano_kernels.hip, the init-time geometry in pano_plan.hpp.
+// Host code only; the arithmetic is in the kernel files (pano_warp / pano_pyramid / pano_blend / pano_blend_small / pano_init .hip), the init-time geometry in pano_plan.hpp.
 // No CPU fallback exists: every compute entry point launches HIP kernels or fails.
 
 #include "../../include/pano.h"

@@ -1,0 +1,911 @@
+// pano_blend.hip - K3: one blend level per launch (generic, vector and strip forms), owner maps, launchers
+// Device helpers: pano_dev.hpp; launch interface: pano_kernels.hpp.  Compile with -ffp-contract=off.
+
+#include "pano_dev.hpp"
+
+namespace pano {
+
+// ------------------------------------------------------------------------------------------------
+// K3 (generic form, any alignment): one level of the blend, one thread per canvas pixel.
+//   acc  = sum over cameras in feed order of (short)(lap * w)          (wrapping short add)
+//   lap  = sat16(G_l - pyrUp(G_{l+1}))  (top level: G_l)
+//   W    = sum over cameras in feed order of w                          (dst_band_weights)
+//   norm = (short)(acc / (W + 1e-5f))
+//   out  = sat16(norm + pyrUp(out_{l+1}))                                (top level: norm)
+// level 0 applies dst_mask (W0 > eps), convertTo(CV_8U) and the cut, and writes the panorama.
+// Cameras whose weight is exactly 0 at the pixel add (short)(lap*0) = 0 and +0.f: they are skipped.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void blend_level_kernel(PyrParams P, CanvasSet CS, int l) {
+    const CanvasParams& C = CS.c[blockIdx.z];
+    const int cam_lo = C.cam_lo, cam_n = C.cam_n;
+    const int cw = C.w0 >> l, ch = C.h0 >> l;
+    int X = blockIdx.x * 64 + threadIdx.x;
+    int Y = blockIdx.y * 4 + threadIdx.y;
+    if (l == 0) {
+        if (X >= C.cut_w || Y >= C.cut_h) return;
+        X += C.cut_x;
+        Y += C.cut_y;
+    } else if (X >= cw || Y >= ch) {
+        return;
+    }
+    // phase A: every load that does not depend on another load - all cameras' weights and the coarser
+    // canvas level - is issued together (these levels are latency bound, not bandwidth bound)
+    float wv[kCams];
+#pragma unroll
+    for (int i = 0; i < kCams; i++) {
+        wv[i] = 0.f;
+        if (i < cam_n) {
+            const PyrCam& c = P.cam[cam_lo + i];
+            const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
+            if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l)) wv[i] = cam_weight(c, l, x, y);
+        }
+    }
+    int cup[3] = {0, 0, 0};
+    if (l < C.bands) {
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            cup[k] = pyr_up_px<int16_t>(C.img[l + 1] + (size_t)k * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X, Y);
+    }
+    // phase B: cameras with a non-zero weight (one in the interior, two or three on a seam)
+    int acc[3] = {0, 0, 0};
+    float W = 0.f;
+#pragma unroll
+    for (int i = 0; i < kCams; i++) {
+        const float w = wv[i];
+        if (w == 0.f) continue;
+        const PyrCam& c = P.cam[cam_lo + i];
+        const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
+        const int tw = c.w0 >> l, th = c.h0 >> l;
+        W += w;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint8_t* g = c.lvl[l] + (size_t)k * c.plane[l];
+            int lap = g[(size_t)y * c.pitch[l] + x];
+            if (l < C.bands)
+                lap = sat16i(lap - pyr_up_px<uint8_t>(c.lvl[l + 1] + (size_t)k * c.plane[l + 1], tw >> 1, th >> 1,
+                                                      c.pitch[l + 1], x, y));
+            acc[k] = (int16_t)(acc[k] + (int16_t)(int)((float)lap * w));
+        }
+    }
+    const float den = W + 1e-5f;
+    int v[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        // W == 1.0f: (short)(n / 1.00001f) == n - sign(n), see the vector kernel
+        if (W == 1.0f) v[k] = toward_zero_by_one(acc[k]);
+        else v[k] = (int16_t)(int)((float)acc[k] / den);
+        if (l < C.bands) v[k] = sat16i(v[k] + cup[k]);
+    }
+    if (l > 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) C.img[l][(size_t)k * C.cplane[l] + (size_t)Y * C.cpitch[l] + X] = (int16_t)v[k];
+    } else {
+        const bool on = W > 1e-5f;
+        uint8_t* d = C.out + (size_t)(Y - C.cut_y) * C.out_stride + 3 * (X - C.cut_x);
+        d[0] = on ? (uint8_t)sat8i(v[0]) : 0;
+        d[1] = on ? (uint8_t)sat8i(v[1]) : 0;
+        d[2] = on ? (uint8_t)sat8i(v[2]) : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 (vector form): one thread = 4 x 2 canvas pixels (X0 multiple of 4, Y0 even).  Used for levels where
+// every tile origin/size is a multiple of 4 x 2 at that level (C.fast[l]), i.e. all but the two coarsest.
+// Per camera and plane: 2 dword loads of G_l, 3 unaligned dword loads of G_{l+1} (the 4 x 3 coarse
+// neighbourhood serves all eight pyrUp samples).  Same arithmetic as the generic form.
+// ------------------------------------------------------------------------------------------------
+// horizontally upsample 4 coarse samples p[0..3] (columns x-1 .. x+2) to fine X0..X0+3 (X0 = 2x)
+__device__ __forceinline__ void up_h4(const int p[4], int o[4]) {
+    o[0] = p[0] + 6 * p[1] + p[2];
+    o[1] = 4 * (p[1] + p[2]);
+    o[2] = p[1] + 6 * p[2] + p[3];
+    o[3] = 4 * (p[2] + p[3]);
+}
+// the 4 x 3 coarse neighbourhood of a 4 x 2 fine block: rows y-1, y, y+1 (y = Y0/2), columns x-1 .. x+2, with
+// pyrUp's border rule (left/top reflect-101, right/bottom replicate) applied.  Branch-free, so that a caller's
+// loads can all be issued before the first is consumed: each row is ONE aligned fetch of a window that is
+// clamped into the row (8 bytes of u8 / 12 bytes of int16); the border rule is a byte permutation (v_perm_b32)
+// of that window.  The four samples of a row stay PACKED: q[r][0] = 4 bytes (u8) or q[r][0..1] = 2 x 2 shorts.
+template <typename T>
+__device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int m, int pitch, int x, int y,
+                                            unsigned q[3][2]) {
+    const int yi[3] = {y > 0 ? y - 1 : (m > 1 ? 1 : 0), y, min(y + 1, m - 1)};
+    const int xi[4] = {x > 0 ? x - 1 : (n > 1 ? 1 : 0), x, min(x + 1, n - 1), min(x + 2, n - 1)};
+    const int base = min(max(x - 1, 0), max(n - 4, 0));
+    // sample k is element xi[k] - base (0..3) of the 4-element window starting at `base`
+    const unsigned sh0 = xi[0] - base, sh1 = xi[1] - base, sh2 = xi[2] - base, sh3 = xi[3] - base;
+    if (sizeof(T) == 1) {
+        const int ab = base & ~3;  // 4-byte aligned fetch of 8 bytes; the window starts at byte base - ab (0..3)
+        const unsigned sel = sh0 | (sh1 << 8) | (sh2 << 16) | (sh3 << 24);
+        uint2 d[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint2*>(S + (unsigned)(__mul24(yi[r], pitch) + ab));  // v_mul_lo_u32 is quarter rate
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const unsigned win = __builtin_amdgcn_alignbyte(d[r].y, d[r].x, (unsigned)(base - ab));
+            q[r][0] = __builtin_amdgcn_perm(0u, win, sel);
+            q[r][1] = 0;
+        }
+    } else {
+        const int ab = base & ~1;  // even element index = 4-byte aligned fetch of 12 bytes; window at element base - ab (0..1)
+        const unsigned bs = (unsigned)(base - ab) * 2u;  // 0 or 2 bytes
+        // short k of the result = short sh[k] of the 4-short window {w1:w0}: byte selectors 2*sh, 2*sh+1
+        const unsigned selA = (2 * sh0) | ((2 * sh0 + 1) << 8) | ((2 * sh1) << 16) | ((2 * sh1 + 1) << 24);
+        const unsigned selB = (2 * sh2) | ((2 * sh2 + 1) << 8) | ((2 * sh3) << 16) | ((2 * sh3 + 1) << 24);
+        uint3 d[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint3*>(S + (unsigned)(__mul24(yi[r], pitch) + ab));
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const unsigned w0 = __builtin_amdgcn_alignbyte(d[r].y, d[r].x, bs);
+            const unsigned w1 = __builtin_amdgcn_alignbyte(d[r].z, d[r].y, bs);
+            q[r][0] = __builtin_amdgcn_perm(w1, w0, selA);
+            q[r][1] = __builtin_amdgcn_perm(w1, w0, selB);
+        }
+    }
+}
+// a . w for two packed int16 pairs, v_dot2_i32_i16 with an inline-constant 0 accumulator (w is a compile-time constant)
+__device__ __forceinline__ int sdot2_from_zero(unsigned a, unsigned w) {
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "s"(w));
+    return d;
+}
+// pyrUp of a 4 x 2 block from the packed 4 x 3 neighbourhood: up[0][..] = fine row Y0 (even), up[1][..] = row Y0+1.
+// Horizontal pass per coarse row: (p0 + 6 p1 + p2, 4 (p1 + p2), p1 + 6 p2 + p3, 4 (p2 + p3)) as dot products
+// (v_dot4_u32_u8 on the byte window / v_dot2_i32_i16 on the short pairs); vertical pass in 32-bit ints.
+template <typename T>
+__device__ __forceinline__ void up_block(const unsigned q[3][2], int up[2][4]) {
+    int h[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        if (sizeof(T) == 1) {
+            const unsigned w = q[r][0];
+            h[r][0] = (int)__builtin_amdgcn_udot4(w, 0x00010601u, 0u, false);
+            h[r][1] = (int)__builtin_amdgcn_udot4(w, 0x00040400u, 0u, false);
+            h[r][2] = (int)__builtin_amdgcn_udot4(w, 0x01060100u, 0u, false);
+            h[r][3] = (int)__builtin_amdgcn_udot4(w, 0x04040000u, 0u, false);
+        } else {
+            const s2_t A = __builtin_bit_cast(s2_t, q[r][0]), B = __builtin_bit_cast(s2_t, q[r][1]);
+            const s2_t c16 = {1, 6}, c04 = {0, 4}, c01 = {0, 1};
+            // the products that start a sum use the three-operand form with an inline 0: the builtin becomes v_dot2c,
+            // whose accumulator is the destination, and costs a v_mov to zero it first
+            h[r][0] = __builtin_amdgcn_sdot2(A, c16, (int)B.x, false);
+            h[r][1] = __builtin_amdgcn_sdot2(A, c04, sdot2_from_zero(q[r][1], 0x00000004u), false);  // B . (4, 0)
+            h[r][2] = __builtin_amdgcn_sdot2(A, c01, sdot2_from_zero(q[r][1], 0x00010006u), false);  // B . (6, 1)
+            h[r][3] = sdot2_from_zero(q[r][1], 0x00040004u);                                         // B . (4, 4)
+        }
+    }
+    // No saturate_cast here: it cannot trigger.  Camera planes are 8-bit (h <= 8*255), and a collapsed canvas level
+    // is bounded by 255 per remaining level (|norm_l| <= 255, pyrUp is a convex combination + rounding), i.e.
+    // |out_l| <= 9*255 + 9 for the maximum of 8 bands - far inside int16.
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int h1 = h[1][k];
+        up[0][k] = (h[0][k] + h[2][k] + (h1 << 2) + (h1 << 1) + 32) >> 6;
+        up[1][k] = (h1 + h[2][k] + 8) >> 4;
+    }
+}
+
+// store a finished 4 x 2 block: canvas level (planar int16) or, at level 0, dst_mask + convertTo(8U) + cut
+// ALLON: every pixel of the block carries weight (dst_mask set) - the caller's guarantee, no per-pixel select
+template <bool L0, bool ALLON = false, int NPL = 3>
+__device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0, int Y0, const int v[3][2][4], bool o00,
+                                            bool o01, bool o02, bool o03, bool o10, bool o11, bool o12, bool o13, int pb = 0) {
+    if (!L0) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                uint2 pk;
+                pk.x = ((unsigned)v[pl][r][0] & 0xffffu) | ((unsigned)v[pl][r][1] << 16);
+                pk.y = ((unsigned)v[pl][r][2] & 0xffffu) | ((unsigned)v[pl][r][3] << 16);
+                *reinterpret_cast<uint2*>(C.img[l] + (size_t)(pb + pl) * C.cplane[l] + (unsigned)(__mul24(Y0 + r, C.cpitch[l]) + X0)) = pk;
+            }
+    } else {
+        const bool on[2][4] = {{o00, o01, o02, o03}, {o10, o11, o12, o13}};
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int Y = Y0 + r;
+            if (Y < C.cut_y || Y >= C.cut_y + C.cut_h) continue;
+            unsigned b[12];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) b[3 * k + pl] = (ALLON || on[r][k]) ? (unsigned)sat8i(v[pl][r][k]) : 0u;
+            // signed: a block that starts left of the cut has a negative column offset (its bytes are masked below)
+            uint8_t* d = C.out + (int)(__mul24(Y - C.cut_y, C.out_stride) + 3 * (X0 - C.cut_x));
+            const bool whole = X0 >= C.cut_x && X0 + 4 <= C.cut_x + C.cut_w;
+            if (whole && (((size_t)d) & 3) == 0) {
+                uint3 pk;
+                pk.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                pk.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                pk.z = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+                *reinterpret_cast<uint3*>(d) = pk;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (X0 + k >= C.cut_x && X0 + k < C.cut_x + C.cut_w) {
+                        d[3 * k] = (uint8_t)b[3 * k];
+                        d[3 * k + 1] = (uint8_t)b[3 * k + 1];
+                        d[3 * k + 2] = (uint8_t)b[3 * k + 2];
+                    }
+            }
+        }
+    }
+}
+
+// One 4 x 2 block of a vector level (X0 multiple of 4, Y0 even; the caller has checked that it lies inside the level /
+// the cut hull): the wave-uniform single-owner path when every lane of the wave sits on the same owner, else the general
+// path.  pb: first plane of this lane (NPL == 1: one plane per lane)
+template <bool L0, int NPL>
+__device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasParams& C, const int l, const int X0, const int Y0,
+                                            const int pb) {
+    const int cam_lo = C.cam_lo;
+    const int cw = C.w0 >> l, ch = C.h0 >> l;
+    // Away from the seams a block belongs to exactly one camera with weight 1.0f everywhere (or to none):
+    // the static owner map says so in one byte, and the block needs no weights, no float math and no division:
+    //   acc = lap, W = 1  =>  norm = lap - sign(lap)  (see below)
+    // one 16-bit entry per block: low byte = owner code, high byte = the cameras that carry weight anywhere on the block
+    const unsigned entry = C.owner[l][(unsigned)(__mul24(Y0 >> 1, C.opitch[l]) + (X0 >> 2))];
+    const unsigned code = entry & 0xffu;
+    const unsigned ucode = __builtin_amdgcn_readfirstlane(code);
+    if (ucode != 0xffu && __builtin_amdgcn_ballot_w64(code != ucode) == 0) {
+        // the whole wave (a 256 x 2 strip) has one owner: its parameters are scalar, the code is straight-line
+        // and every load is in flight before the first use
+        int v[3][2][4];
+        unsigned cp[3][3][2];
+        if (l < C.bands) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; pl++) {
+                load_coarse<int16_t>(C.img[l + 1] + (size_t)(pb + pl) * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1],
+                                     X0 >> 1, Y0 >> 1, cp[pl]);
+            }
+        }
+        if (ucode < 8u) {
+            const PyrCam& c = P.cam[cam_lo + ucode];
+            const int x = X0 - (c.tx >> l), y = Y0 - (c.ty >> l);
+            const int tw = c.w0 >> l, th = c.h0 >> l;
+            unsigned g0[3], g1[3];
+            unsigned p[3][3][2];
+#pragma unroll
+            for (int pl = 0; pl < NPL; pl++) {
+                const uint8_t* g = c.lvl[l] + (size_t)(pb + pl) * c.plane[l] + (unsigned)(__mul24(y, c.pitch[l]) + x);
+                g0[pl] = *reinterpret_cast<const unsigned*>(g);
+                g1[pl] = *reinterpret_cast<const unsigned*>(g + c.pitch[l]);
+                if (l < C.bands)
+                    load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)(pb + pl) * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1],
+                                         x >> 1, y >> 1, p[pl]);
+            }
+#pragma unroll
+            for (int pl = 0; pl < NPL; pl++) {
+                int up[2][4];
+                if (l < C.bands) {
+                    up_block<uint8_t>(p[pl], up);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) up[0][k] = up[1][k] = 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int l0 = (int)((g0[pl] >> (8 * k)) & 0xffu) - up[0][k];  // |lap| <= 255: no saturation possible
+                    const int l1 = (int)((g1[pl] >> (8 * k)) & 0xffu) - up[1][k];
+                    v[pl][0][k] = toward_zero_by_one(l0);
+                    v[pl][1][k] = toward_zero_by_one(l1);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < NPL; pl++)
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[pl][r][k] = 0;
+        }
+        if (l < C.bands) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; pl++) {
+                int up[2][4];
+                up_block<int16_t>(cp[pl], up);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[pl][r][k] += up[r][k];  // bounded by 9*255+9: see up_block
+            }
+        }
+        if (L0 && ucode >= 8u) {
+            // an unowned block has W == 0: dst_mask is clear and the pixel is black whatever the coarser levels hold
+#pragma unroll
+            for (int pl = 0; pl < NPL; pl++)
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[pl][r][k] = 0;
+        }
+        store_block<L0, true, NPL>(C, l, X0, Y0, v, true, true, true, true, true, true, true, true, pb);
+        return;
+    }
+    // which cameras carry weight on this 4 x 2 block is static (it follows the masks): the high byte of the owner entry.
+    // A seam wave used to spend its first round trip loading every covering camera's weights only to find that out
+    const unsigned live = entry >> 8;
+    // the coarser canvas level: early on the latency-bound small levels, late (fewer live registers) on level 0
+    unsigned cp[3][3][2];
+    if (!L0 && l < C.bands) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++)
+            load_coarse<int16_t>(C.img[l + 1] + (size_t)(pb + pl) * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
+                                 Y0 >> 1, cp[pl]);
+    }
+    int acc[3][2][4];
+    float W[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            W[r][k] = 0.f;
+            acc[0][r][k] = acc[1][r][k] = acc[2][r][k] = 0;
+        }
+    // phase B: cameras with weight, in feed order
+#pragma unroll
+    for (int i = 0; i < kCams; i++) {
+        if (!((live >> i) & 1u)) continue;
+        const PyrCam& c = P.cam[cam_lo + i];
+        const int x = X0 - (c.tx >> l), y = Y0 - (c.ty >> l);
+        const int tw = c.w0 >> l, th = c.h0 >> l;
+        float w[2][4];
+        if (L0) {
+            const unsigned mk[2] = {*reinterpret_cast<const unsigned*>(c.mask0 + (unsigned)(__mul24(y, c.pitch[0]) + x)),
+                                    *reinterpret_cast<const unsigned*>(c.mask0 + (unsigned)(__mul24(y + 1, c.pitch[0]) + x))};
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) w[r][k] = (float)((mk[r] >> (8 * k)) & 0xffu) * (float)(1. / 255.);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const float4 f = *reinterpret_cast<const float4*>(c.wgt[l] + (size_t)(y + r) * c.wpitch[l] + x);
+                w[r][0] = f.x; w[r][1] = f.y; w[r][2] = f.z; w[r][3] = f.w;
+            }
+        }
+        // away from the seams the weight is exactly 1.0f on the whole block: no float path
+        bool unit = true;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) unit &= w[r][k] == 1.0f;
+        // issue every load of this camera before using any
+        unsigned g0[3], g1[3];
+        unsigned p[3][3][2];
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++) {
+            const uint8_t* g = c.lvl[l] + (size_t)(pb + pl) * c.plane[l] + (size_t)y * c.pitch[l] + x;
+            g0[pl] = *reinterpret_cast<const unsigned*>(g);
+            g1[pl] = *reinterpret_cast<const unsigned*>(g + c.pitch[l]);
+            if (l < C.bands)
+                load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)(pb + pl) * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1], x >> 1,
+                                     y >> 1, p[pl]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) W[r][k] += w[r][k];  // + 0.f is exact
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++) {
+            int up[2][4];
+            if (l < C.bands) {
+                up_block<uint8_t>(p[pl], up);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) up[0][k] = up[1][k] = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int l0 = sat16i((int)((g0[pl] >> (8 * k)) & 0xffu) - up[0][k]);
+                const int l1 = sat16i((int)((g1[pl] >> (8 * k)) & 0xffu) - up[1][k]);
+                if (unit) {  // (short)(lap * 1.0f) == lap
+                    acc[pl][0][k] = (int16_t)(acc[pl][0][k] + l0);
+                    acc[pl][1][k] = (int16_t)(acc[pl][1][k] + l1);
+                } else {
+                    acc[pl][0][k] = (int16_t)(acc[pl][0][k] + (int16_t)(int)((float)l0 * w[0][k]));
+                    acc[pl][1][k] = (int16_t)(acc[pl][1][k] + (int16_t)(int)((float)l1 * w[1][k]));
+                }
+            }
+        }
+    }
+    if (L0 && l < C.bands) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++)
+            load_coarse<int16_t>(C.img[l + 1] + (size_t)(pb + pl) * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
+                                 Y0 >> 1, cp[pl]);
+    }
+    // (short)(n / (1.0f + 1e-5f)) == n - sign(n) for every int16 n: the quotient lies strictly between
+    // |n|-1 and |n| (|n| * 1e-5 < 1, and far more than an ulp of n), and the cast truncates toward zero.
+    // So where the summed weight is exactly 1.0f (everywhere but the seams) no division is needed.
+    bool unitW = true;
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) unitW &= W[r][k] == 1.0f;
+    int v[3][2][4];
+#pragma unroll
+    for (int pl = 0; pl < NPL; pl++) {
+        int up[2][4];
+        if (l < C.bands) {
+            up_block<int16_t>(cp[pl], up);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) up[0][k] = up[1][k] = 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int a = acc[pl][r][k];
+                int nrm;
+                if (unitW) nrm = toward_zero_by_one(a);
+                else nrm = (int16_t)(int)((float)a / (W[r][k] + 1e-5f));
+                v[pl][r][k] = l < C.bands ? sat16i(nrm + up[r][k]) : nrm;
+            }
+    }
+    bool on[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) on[r][k] = W[r][k] > 1e-5f;
+    store_block<L0, false, NPL>(C, l, X0, Y0, v, on[0][0], on[0][1], on[0][2], on[0][3], on[1][0], on[1][1], on[1][2], on[1][3], pb);
+}
+
+// NPL = 3: a lane does the three colour planes of its block.  NPL = 1 (canvas levels >= 1 only, where planes are stored
+// apart): grid.z = canvas * 3 + plane and a lane does one plane - a third of the serial work per wave, three times the
+// waves: these levels are one round of waves whose seam waves set the kernel's duration.
+template <bool L0, int NPL = 3>
+__global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, CanvasSet CS, int lvl) {
+    static_assert(NPL == 3 || !L0, "level 0 writes interleaved BGR");
+    unsigned bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+    if (L0 && NPL == 3 && ((lvl >> 8) & 15) == 4) {
+        // XCD bands with the seam tiles first (shape 4, level 0): the band of XCD k is walked in the order of the static table
+        // CanvasParams::order0 - tiles that hold a wave without a single owner (the general path: four times the instructions,
+        // two dependent rounds of loads) come first, so their long chains run under the bulk instead of behind it
+        const unsigned maxper = ((unsigned)lvl >> 12) & 0xfffffu;
+        const unsigned k = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const unsigned cvi = j / maxper, jj = j - cvi * maxper;
+        if (cvi >= (unsigned)CS.n) return;
+        const CanvasParams& Cq = CS.c[cvi];
+        if (jj >= (unsigned)Cq.order_per) return;
+        const unsigned tile = Cq.order0[k * Cq.order_per + jj];
+        if (tile == 0xffffu) return;
+        bxi = tile % (unsigned)Cq.order_gx; byi = tile / (unsigned)Cq.order_gx; bzi = cvi;
+    } else if (((lvl >> 8) & 15) == 3) {
+        // XCD bands (shape 3, the default): a 1-D grid of 8 * per workgroups; the hardware deals consecutive ids round-robin
+        // over the 8 XCDs, so XCD k is given the logical workgroups [k * per, (k + 1) * per) - a contiguous band of canvas
+        // rows, whose neighbouring workgroups share their cache lines and pyrUp halos in ONE L2
+        const unsigned gx = ((unsigned)lvl >> 12) & 0x3ffu, gy = ((unsigned)lvl >> 22) & 0x3ffu;
+        const unsigned total = gx * gy * (unsigned)(NPL == 3 ? CS.n : CS.n * 3);
+        const unsigned per = (total + 7u) / 8u;
+        const unsigned logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= per || logical >= total) return;
+        bxi = logical % gx; byi = (logical / gx) % gy; bzi = logical / (gx * gy);
+    }
+    const int pb = NPL == 3 ? 0 : (int)(bzi % 3);  // first plane of this lane
+    const CanvasParams& C = CS.c[NPL == 3 ? bzi : bzi / 3];
+    const int l = L0 ? 0 : (lvl & 0xff);
+    const int cw = C.w0 >> l, ch = C.h0 >> l;
+    // level 0 covers only the block-aligned hull of the cut rectangle
+    const int bx0 = L0 ? (C.cut_x & ~3) : 0, by0 = L0 ? (C.cut_y & ~1) : 0;
+    // a wave is 16 x 4 blocks = 64 x 8 pixels (not a 256-pixel strip): four times fewer waves straddle a seam,
+    // and a wave that does not straddle one takes the single-owner fast path below.
+    // The four waves of a workgroup form a 2 x 2 patch (128 x 16 pixels).  Consecutive workgroups go to different XCDs,
+    // each with its own L2, so what a workgroup reads of a row should be whole 128-byte lines: stacked (64 x 32 pixels,
+    // shape 1) the 64 bytes a wave reads of a u8 plane row are half a line and the level-0 launch fetched 152 MB for the
+    // ~45 MB it uses; side by side (256 x 8, shape 0) it fetches 74 MB.  Measured per frame (levels 0-2, C2), stacked /
+    // side by side / 2 x 2: HBM bytes of these launches 247 / 145 / 182 MB, panoramas/s one frame at a time 7.18 / 7.35 /
+    // 7.27 k, with four frames in flight 11.77 / 11.64 / 11.83 k (same box, alternating): bytes are not what bounds the
+    // pipeline, and 2 x 2 is the fastest of the three.  On top of 2 x 2, XCD bands (above): blend stage 76.6 -> 72.8 us,
+    // 7.24 -> 7.46 k one frame at a time, 11.71 -> 11.92 k in flight.  PANO_K3_SHAPE=0|1|2|3.
+    int X0, Y0;
+    if (((lvl >> 8) & 15) == 1) {         // stacked
+        const int tid = threadIdx.y * 64 + threadIdx.x;
+        X0 = bx0 + (bxi * 16 + (tid & 15)) * 4;
+        Y0 = by0 + (byi * 16 + (tid >> 4)) * 2;
+    } else if (((lvl >> 8) & 15) == 0) {  // side by side
+        X0 = bx0 + ((bxi * 4 + threadIdx.y) * 16 + (threadIdx.x & 15)) * 4;
+        Y0 = by0 + (byi * 4 + (threadIdx.x >> 4)) * 2;
+    } else {                              // 2 x 2
+        X0 = bx0 + ((bxi * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
+        Y0 = by0 + ((byi * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * 2;
+    }
+    if (L0) {
+        if (X0 >= C.cut_x + C.cut_w || Y0 >= C.cut_y + C.cut_h) return;
+    } else if (X0 >= cw || Y0 >= ch) {
+        return;
+    }
+    blend_block<L0, NPL>(P, C, l, X0, Y0, pb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 level 0, strip form.  blend_level_vec_kernel spends 700 vector instructions on a single-owner 4 x 2 block, most of them
+// on the two pyrUps (camera level 1 and canvas level 1): every block redoes the horizontal pass of THREE coarse rows of each,
+// although vertically adjacent blocks share two of them, and the whole chain runs one value per instruction.
+// Here a lane owns a strip of S blocks stacked vertically (4 x 2S pixels) and walks down it:
+//   * one new coarse row per step and source - the horizontal pass of a coarse row is done once, a sliding window of three
+//     rows feeds the vertical pass (S + 2 rows per S blocks instead of 3 S);
+//   * the camera side runs two values per instruction: horizontal sums <= 8 * 255 and vertical sums <= 64 * 255 + 32 fit
+//     uint16 (v_pk_add_u16, v_pk_mad_u16, v_pk_lshrrev_b16), with the rounding terms (+32 on even rows, +8 on odd rows) riding
+//     as +4 in every horizontal sum (1 + 6 + 1 = 8 = 32 / 4, 1 + 1 = 2 = 8 / 4);
+//   * Laplacian, n - sign(n), + canvas, saturate and byte packing on int16 pairs (v_pk_sub_i16, v_pk_min/max_i16, v_perm_b32).
+//   The canvas side stays 32-bit in the vertical pass (|out_1| <= 9 * 255 + 9 makes 64-fold sums that do not fit 16 bits).
+// A wave is 16 x 4 strips (64 x 8S pixels): as narrow as before, so no more waves straddle a seam than before.  Waves that
+// do (or that lie on no single owner) run blend_block on each of their blocks.
+// ------------------------------------------------------------------------------------------------
+
+// horizontal position of a lane's 4-sample coarse window (columns x-1 .. x+2 with pyrUp's border rule): what load_coarse
+// derives per block, derived once per strip
+struct CoarseX {
+    unsigned fetch;  // element offset of the aligned fetch inside a row
+    unsigned shift;  // byte shift of the window inside the fetched bytes
+    unsigned selA, selB;
+};
+template <typename T>
+__device__ __forceinline__ CoarseX coarse_x(int n, int x) {
+    const int xi[4] = {x > 0 ? x - 1 : (n > 1 ? 1 : 0), x, min(x + 1, n - 1), min(x + 2, n - 1)};
+    const int base = min(max(x - 1, 0), max(n - 4, 0));
+    const unsigned sh0 = xi[0] - base, sh1 = xi[1] - base, sh2 = xi[2] - base, sh3 = xi[3] - base;
+    CoarseX cx;
+    if (sizeof(T) == 1) {
+        const int ab = base & ~3;
+        cx.fetch = (unsigned)ab;
+        cx.shift = (unsigned)(base - ab);
+        cx.selA = sh0 | (sh1 << 8) | (sh2 << 16) | (sh3 << 24);
+        cx.selB = 0;
+    } else {
+        const int ab = base & ~1;
+        cx.fetch = (unsigned)ab;
+        cx.shift = (unsigned)(base - ab) * 2u;
+        cx.selA = (2 * sh0) | ((2 * sh0 + 1) << 8) | ((2 * sh1) << 16) | ((2 * sh1 + 1) << 24);
+        cx.selB = (2 * sh2) | ((2 * sh2 + 1) << 8) | ((2 * sh3) << 16) | ((2 * sh3 + 1) << 24);
+    }
+    return cx;
+}
+// coarse row j of the sliding window (j = -1 .. m): pyrUp's vertical border rule (top reflect-101, bottom replicate)
+__device__ __forceinline__ int coarse_row(int j, int m) { return j < 0 ? (m > 1 ? 1 : 0) : min(j, m - 1); }
+
+// camera level-1 row (u8): fetched 8 bytes -> the four horizontal sums as two uint16 pairs, each carrying +4
+__device__ __forceinline__ void cam_hrow(uint2 d, const CoarseX& cx, us2_t& h01, us2_t& h23) {
+    const unsigned w = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(d.y, d.x, cx.shift), cx.selA);
+    const unsigned h0 = __builtin_amdgcn_udot4(w, 0x00010601u, 4u, false), h1 = __builtin_amdgcn_udot4(w, 0x00040400u, 4u, false);
+    const unsigned h2 = __builtin_amdgcn_udot4(w, 0x01060100u, 4u, false), h3 = __builtin_amdgcn_udot4(w, 0x04040000u, 4u, false);
+    h01 = __builtin_bit_cast(us2_t, h0 | (h1 << 16));
+    h23 = __builtin_bit_cast(us2_t, h2 | (h3 << 16));
+}
+// canvas level-1 row (int16): fetched 12 bytes -> the four horizontal sums, 32-bit
+__device__ __forceinline__ void cv_hrow(uint3 d, const CoarseX& cx, int h[4]) {
+    const unsigned w0 = __builtin_amdgcn_alignbyte(d.y, d.x, cx.shift), w1 = __builtin_amdgcn_alignbyte(d.z, d.y, cx.shift);
+    const unsigned q0 = __builtin_amdgcn_perm(w1, w0, cx.selA), q1 = __builtin_amdgcn_perm(w1, w0, cx.selB);
+    const s2_t A = __builtin_bit_cast(s2_t, q0), B = __builtin_bit_cast(s2_t, q1);
+    const s2_t c16 = {1, 6}, c04 = {0, 4}, c01 = {0, 1};
+    h[0] = __builtin_amdgcn_sdot2(A, c16, (int)B.x, false);
+    h[1] = __builtin_amdgcn_sdot2(A, c04, sdot2_from_zero(q1, 0x00000004u), false);
+    h[2] = __builtin_amdgcn_sdot2(A, c01, sdot2_from_zero(q1, 0x00010006u), false);
+    h[3] = sdot2_from_zero(q1, 0x00040004u);
+}
+// one output row of level 0 (4 pixels) from the three planes' bytes: dst_mask is all set here (single owner), so
+// convertTo(8U) + the cut is all that is left
+__device__ __forceinline__ void store_row_l0(const CanvasParams& C, int X0, int Y, uint3 pk) {
+    if (Y < C.cut_y || Y >= C.cut_y + C.cut_h) return;
+    uint8_t* d = C.out + (int)(__mul24(Y - C.cut_y, C.out_stride) + 3 * (X0 - C.cut_x));
+    const bool whole = X0 >= C.cut_x && X0 + 4 <= C.cut_x + C.cut_w;
+    if (whole && (((size_t)d) & 3) == 0) {
+        *reinterpret_cast<uint3*>(d) = pk;
+    } else {
+        const unsigned w[3] = {pk.x, pk.y, pk.z};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (X0 + k >= C.cut_x && X0 + k < C.cut_x + C.cut_w) {
+#pragma unroll
+                for (int q = 0; q < 3; q++) d[3 * k + q] = (uint8_t)(w[(3 * k + q) >> 2] >> (8 * ((3 * k + q) & 3)));
+            }
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void blend_level0_strip_kernel(PyrParams P, CanvasSet CS, int lvl) {
+    // XCD bands over workgroups of 2 x 2 waves (see blend_level_vec_kernel): gx, gy = logical grid, packed in lvl
+    const unsigned gx = ((unsigned)lvl >> 12) & 0x3ffu, gy = ((unsigned)lvl >> 22) & 0x3ffu;
+    const unsigned total = gx * gy * (unsigned)CS.n;
+    const unsigned per = (total + 7u) / 8u;
+    const unsigned logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || logical >= total) return;
+    const unsigned bxi = logical % gx, byi = (logical / gx) % gy, bzi = logical / (gx * gy);
+    const CanvasParams& C = CS.c[bzi];
+    const int cw = C.w0, ch = C.h0;
+    const int bx0 = C.cut_x & ~3, by0 = C.cut_y & ~1;
+    const int X0 = bx0 + ((bxi * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
+    const int Yb = by0 + ((byi * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * (2 * S);
+    const int y_end = min(C.cut_y + C.cut_h, ch);
+    if (X0 >= C.cut_x + C.cut_w || Yb >= y_end) return;
+    // the strip's owner entries: single owner for the whole wave?
+    unsigned entry[S];
+#pragma unroll
+    for (int s = 0; s < S; s++)
+        entry[s] = C.owner[0][(unsigned)(__mul24(min(Yb + 2 * s, ch - 2) >> 1, C.opitch[0]) + (X0 >> 2))];
+    const unsigned ucode = __builtin_amdgcn_readfirstlane(entry[0] & 0xffu);
+    bool same = true;
+#pragma unroll
+    for (int s = 0; s < S; s++) same &= (entry[s] & 0xffu) == ucode;
+    if (ucode == 0xffu || __builtin_amdgcn_ballot_w64(!same) != 0) {
+        for (int s = 0; s < S; s++) {
+            const int Y0 = Yb + 2 * s;
+            if (Y0 < y_end) blend_block<true, 3>(P, C, 0, X0, Y0, 0);
+        }
+        return;
+    }
+    if (ucode >= 8u) {  // no camera carries weight here: dst_mask clear, black
+#pragma unroll
+        for (int r = 0; r < 2 * S; r++)
+            if (Yb + r < y_end) store_row_l0(C, X0, Yb + r, make_uint3(0u, 0u, 0u));
+        return;
+    }
+    // ---- the whole wave lies on camera `ucode` with weight 1: acc = lap, W = 1, norm = lap - sign(lap)
+    const PyrCam& c = P.cam[C.cam_lo + ucode];
+    const int x = X0 - c.tx, y = Yb - c.ty;      // tile coordinates (y even: tile origins are multiples of 2^bands)
+    const int n1 = c.w0 >> 1, m1 = c.h0 >> 1;    // camera level 1
+    const int cn = cw >> 1, cm = ch >> 1;        // canvas level 1
+    const CoarseX kx = coarse_x<uint8_t>(n1, x >> 1), vx = coarse_x<int16_t>(cn, X0 >> 1);
+    const int kr0 = (y >> 1) - 1, vr0 = (Yb >> 1) - 1;  // first row of the two sliding windows
+    // plane by plane: the loads of a plane - 2S fine rows, S + 2 coarse rows of the camera and of the canvas - are issued
+    // together and consumed before the next plane's are issued (all three planes at once: 183 VGPRs at S = 4, two waves
+    // per SIMD)
+    // The plane loop is a real loop: unrolled, the compiler overlaps the planes and allocates 179 VGPRs at S = 4 (two waves per
+    // SIMD).  A plane's four bytes per row are inserted into the row's three interleaved BGR dwords (B0 G0 R0 B1 | G1 R1 B2 G2
+    // | R2 B3 G3 R3) by v_perm_b32 with per-plane selectors (0-3 = old bytes, 4-7 = the plane's pixels 0-3)
+    uint3 out[2 * S];
+#pragma unroll
+    for (int r = 0; r < 2 * S; r++) out[r] = make_uint3(0u, 0u, 0u);
+#pragma unroll 1
+    for (int pl = 0; pl < 3; pl++) {
+        const unsigned ins0 = pl == 0 ? 0x05020104u : (pl == 1 ? 0x03020400u : 0x03040100u);
+        const unsigned ins1 = pl == 0 ? 0x03060100u : (pl == 1 ? 0x06020105u : 0x03020500u);
+        const unsigned ins2 = pl == 0 ? 0x03020700u : (pl == 1 ? 0x03070100u : 0x07020106u);
+        unsigned g[2 * S];
+        uint2 kq[S + 2];
+        uint3 vq[S + 2];
+        {
+            const uint8_t* g0 = c.lvl[0] + (size_t)pl * c.plane[0] + (unsigned)(__mul24(y, c.pitch[0]) + x);
+#pragma unroll
+            for (int r = 0; r < 2 * S; r++) g[r] = *reinterpret_cast<const unsigned*>(g0 + __mul24(min(r, c.h0 - 1 - y), c.pitch[0]));
+            const uint8_t* k1 = c.lvl[1] + (size_t)pl * c.plane[1] + kx.fetch;
+#pragma unroll
+            for (int r = 0; r < S + 2; r++) kq[r] = *reinterpret_cast<const uint2*>(k1 + (unsigned)__mul24(coarse_row(kr0 + r, m1), c.pitch[1]));
+            const int16_t* v1 = C.img[1] + (size_t)pl * C.cplane[1] + vx.fetch;
+#pragma unroll
+            for (int r = 0; r < S + 2; r++) vq[r] = *reinterpret_cast<const uint3*>(v1 + (unsigned)__mul24(coarse_row(vr0 + r, cm), C.cpitch[1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        us2_t ka01, ka23, kb01, kb23, kc01, kc23;
+        int va[4], vb[4], vc[4];
+        cam_hrow(kq[0], kx, ka01, ka23);
+        cam_hrow(kq[1], kx, kb01, kb23);
+        cv_hrow(vq[0], vx, va);
+        cv_hrow(vq[1], vx, vb);
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            cam_hrow(kq[s + 2], kx, kc01, kc23);
+            cv_hrow(vq[s + 2], vx, vc);
+            // pyrUp of the camera's level 1: rows 2k (1 6 1) and 2k + 1 (4 4); the +4 in every sum is the rounding term
+            const us2_t e01 = (us2_t)(ka01 + kc01 + kb01 * (us2_t)6) >> (us2_t)6, e23 = (us2_t)(ka23 + kc23 + kb23 * (us2_t)6) >> (us2_t)6;
+            const us2_t o01 = (us2_t)(kb01 + kc01) >> (us2_t)4, o23 = (us2_t)(kb23 + kc23) >> (us2_t)4;
+            // pyrUp of the canvas' level 1, packed to int16 pairs (|out_1| <= 9 * 255 + 9)
+            int ve[4], vo[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                ve[k] = (va[k] + vc[k] + 32 + vb[k] * 6) >> 6;
+                vo[k] = (vb[k] + vc[k] + 8) >> 4;
+            }
+            const s2_t ce01 = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm((unsigned)ve[1], (unsigned)ve[0], 0x05040100u));
+            const s2_t ce23 = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm((unsigned)ve[3], (unsigned)ve[2], 0x05040100u));
+            const s2_t co01 = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm((unsigned)vo[1], (unsigned)vo[0], 0x05040100u));
+            const s2_t co23 = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm((unsigned)vo[3], (unsigned)vo[2], 0x05040100u));
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const unsigned gw = g[2 * s + r];
+                const s2_t g01 = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm(0u, gw, 0x0c010c00u));
+                const s2_t g23 = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm(0u, gw, 0x0c030c02u));
+                const s2_t u01 = __builtin_bit_cast(s2_t, r == 0 ? e01 : o01), u23 = __builtin_bit_cast(s2_t, r == 0 ? e23 : o23);
+                const s2_t one = {1, 1}, mone = {-1, -1}, zero = {0, 0}, top = {255, 255};
+                s2_t l01 = g01 - u01, l23 = g23 - u23;                                // |lap| <= 255
+                l01 -= __builtin_elementwise_max(__builtin_elementwise_min(l01, one), mone);   // n - sign(n)
+                l23 -= __builtin_elementwise_max(__builtin_elementwise_min(l23, one), mone);
+                l01 += r == 0 ? ce01 : co01;
+                l23 += r == 0 ? ce23 : co23;
+                l01 = __builtin_elementwise_min(__builtin_elementwise_max(l01, zero), top);    // convertTo(CV_8U)
+                l23 = __builtin_elementwise_min(__builtin_elementwise_max(l23, zero), top);
+                const unsigned px = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, l23), __builtin_bit_cast(unsigned, l01), 0x06040200u);
+                out[2 * s + r].x = __builtin_amdgcn_perm(px, out[2 * s + r].x, ins0);
+                out[2 * s + r].y = __builtin_amdgcn_perm(px, out[2 * s + r].y, ins1);
+                out[2 * s + r].z = __builtin_amdgcn_perm(px, out[2 * s + r].z, ins2);
+            }
+            ka01 = kb01; ka23 = kb23; kb01 = kc01; kb23 = kc23;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { va[k] = vb[k]; vb[k] = vc[k]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 2 * S; r++)
+        if (Yb + r < y_end) store_row_l0(C, X0, Yb + r, out[r]);
+}
+
+
+// owner map of a vector level: one byte per 4 x 2 block (see CanvasParams::owner)
+__global__ __launch_bounds__(256) void build_owner_kernel(PyrParams P, CanvasParams C, int l, uint16_t* owner) {
+    const int cw = C.w0 >> l, ch = C.h0 >> l;
+    const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+    if (bx * 4 >= cw || by * 2 >= ch) return;
+    int holders = 0, unit_cam = -1;
+    unsigned mask = 0;
+    bool all_unit = true;
+    for (int i = 0; i < P.ncam; i++) {
+        const PyrCam& c = P.cam[i];
+        const int x = bx * 4 - (c.tx >> l), y = by * 2 - (c.ty >> l);
+        if ((unsigned)x >= (unsigned)(c.w0 >> l) || (unsigned)y >= (unsigned)(c.h0 >> l)) continue;
+        bool any = false, unit = true;
+        for (int r = 0; r < 2; r++)
+            for (int k = 0; k < 4; k++) {
+                const float w = cam_weight(c, l, x + k, y + r);
+                any |= w != 0.f;
+                unit &= w == 1.0f;
+            }
+        if (any) {
+            holders++;
+            unit_cam = i;
+            mask |= 1u << i;
+            all_unit &= unit;
+        }
+    }
+    uint8_t code = 0xff;
+    if (holders == 0) code = 0xfe;
+    else if (holders == 1 && all_unit) code = (uint8_t)unit_cam;
+    owner[(size_t)by * C.opitch[l] + bx] = (uint16_t)(code | (mask << 8));
+}
+void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint16_t* owner, hipStream_t s) {
+    const int bw = (c.w0 >> l) / 4, bh = (c.h0 >> l) / 2;
+    dim3 block(64, 4, 1), grid((bw + 63) / 64, (bh + 3) / 4, 1);
+    hipLaunchKernelGGL(build_owner_kernel, grid, block, 0, s, p, c, l, owner);
+}
+
+// which 128 x 16-pixel workgroup tiles of level 0 hold a wave that takes the general path (no single owner)?  One flag per tile,
+// the same lane -> block mapping as blend_level_vec_kernel's 2 x 2 shape over the hull of the cut
+__global__ __launch_bounds__(256) void tile_mixed_kernel(CanvasParams C, int gx, uint8_t* flags) {
+    const int bx0 = C.cut_x & ~3, by0 = C.cut_y & ~1;
+    const int X0 = bx0 + ((blockIdx.x * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
+    const int Y0 = by0 + ((blockIdx.y * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * 2;
+    const bool valid = X0 < C.cut_x + C.cut_w && Y0 < C.cut_y + C.cut_h;
+    unsigned code = 0;
+    if (valid) code = C.owner[0][(unsigned)(__mul24(Y0 >> 1, C.opitch[0]) + (X0 >> 2))] & 0xffu;
+    const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+    int mixed = 0;
+    if (vm) {
+        const unsigned c0 = (unsigned)__shfl((int)code, __ffsll((long long)vm) - 1);
+        mixed = c0 == 0xffu || __builtin_amdgcn_ballot_w64(valid && code != c0) != 0;
+    }
+    mixed = __syncthreads_or(mixed);
+    if (threadIdx.x == 0 && threadIdx.y == 0) flags[blockIdx.y * gx + blockIdx.x] = (uint8_t)(mixed != 0);
+}
+void launch_tile_mixed(const CanvasParams& c, int gx, int gy, uint8_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(tile_mixed_kernel, dim3(gx, gy, 1), dim3(64, 4, 1), 0, s, c, gx, flags);
+}
+
+void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+#define PANO_LAUNCH_L0(K, G)                                                                         \
+    do {                                                                                             \
+        if (ev_start && ev_stop) hipExtLaunchKernelGGL(K, G, block, 0, s, ev_start, ev_stop, 0, p, cs, karg); \
+        else hipLaunchKernelGGL(K, G, block, 0, s, p, cs, karg);                                    \
+    } while (0)
+    const CanvasParams& c = cs.c[0];
+    if (c.fast[l]) {
+        int w = 0, h = 0;
+        for (int g = 0; g < cs.n; g++) {
+            const CanvasParams& cg = cs.c[g];
+            if (l == 0) {
+                w = max(w, cg.cut_x + cg.cut_w - (cg.cut_x & ~3));
+                h = max(h, cg.cut_y + cg.cut_h - (cg.cut_y & ~1));
+            } else {
+                w = max(w, cg.w0 >> l);
+                h = max(h, cg.h0 >> l);
+            }
+        }
+        // workgroup shape (see the kernel): 3 = 2 x 2 waves in XCD bands (default), 2 = 2 x 2 waves, 0 = side by side, 1 = stacked
+        const int shape_env = c.k3_shape & 3;
+        // one plane per lane on the canvas levels >= 1 (measured: levels 1 + 2 29 -> 23 us, in flight no worse);
+        // PANO_BLEND_PLANES=0 keeps three planes per lane
+        const bool split = c.blend_split != 0;
+        int shape = shape_env;
+        if (shape == 3 && ((w + 127) / 128 > 1023 || (h + 15) / 16 > 1023)) shape = 2;  // the band form packs the extents in 10 bits each
+        dim3 block(64, 4, 1), grid((w + 127) / 128, (h + 15) / 16, cs.n);
+        if (shape == 0) grid = dim3((w + 255) / 256, (h + 7) / 8, cs.n);
+        if (shape == 1) grid = dim3((w + 63) / 64, (h + 31) / 32, cs.n);
+        int larg = l | (shape << 8);
+        const dim3 grid3 = grid;  // the logical extents
+        if (shape == 3) {       // XCD bands over the 2 x 2 shape: a 1-D grid of 8 * ceil(workgroups / 8)
+            larg |= (int)((grid3.x & 0x3ffu) << 12) | (int)((grid3.y & 0x3ffu) << 22);
+            const unsigned zext = (l == 0 || !split) ? cs.n : cs.n * 3;
+            grid = dim3(8u * ((grid3.x * grid3.y * zext + 7u) / 8u), 1, 1);
+        }
+        // level 0 in strips of S blocks per lane (blend_level0_strip_kernel): opt-in, PANO_L0_STRIPS=2 / 4 / 8 pick S.  Measured on
+        // config 2: half the vector instructions per pixel, yet 36.7 / 49.4 / 72.5 us against 31.4 us
+        // for one block per lane alone and the same panoramas/s with frames in flight
+        const int strips = c.l0_strips;
+        if (l == 0 && c.bands >= 1 && (strips == 2 || strips == 4 || strips == 8)) {
+            const unsigned sgx = (w + 127) / 128, sgy = (h + 16 * strips - 1) / (16 * strips);
+            if (sgx <= 1023 && sgy <= 1023) {
+                const int karg = (int)(sgx << 12) | (int)(sgy << 22);
+                const dim3 sgrid(8u * ((sgx * sgy * cs.n + 7u) / 8u), 1, 1);
+                if (strips == 2) PANO_LAUNCH_L0(blend_level0_strip_kernel<2>, sgrid);
+                else if (strips == 4) PANO_LAUNCH_L0(blend_level0_strip_kernel<4>, sgrid);
+                else PANO_LAUNCH_L0(blend_level0_strip_kernel<8>, sgrid);
+                return;
+            }
+        }
+        if (l == 0) {
+            bool ordered = shape == 3;
+            unsigned maxper = 0;
+            for (int g = 0; g < cs.n; g++) {
+                ordered = ordered && cs.c[g].order0 != nullptr;
+                maxper = max(maxper, (unsigned)cs.c[g].order_per);
+            }
+            if (ordered && maxper > 0 && maxper < (1u << 20)) {  // XCD bands, seam tiles first
+                const int karg = (4 << 8) | (int)(maxper << 12);
+                PANO_LAUNCH_L0((blend_level_vec_kernel<true, 3>), dim3(8u * maxper * cs.n, 1, 1));
+            } else {
+                const int karg = larg;
+                PANO_LAUNCH_L0((blend_level_vec_kernel<true, 3>), grid);
+            }
+        } else {
+            if (split) hipLaunchKernelGGL((blend_level_vec_kernel<false, 1>), shape == 3 ? grid : dim3(grid.x, grid.y, cs.n * 3), block, 0, s, p, cs, larg);
+            else hipLaunchKernelGGL((blend_level_vec_kernel<false, 3>), grid, block, 0, s, p, cs, larg);
+        }
+        return;
+    }
+    int w = 0, h = 0;
+    for (int g = 0; g < cs.n; g++) {
+        w = max(w, l == 0 ? cs.c[g].cut_w : (cs.c[g].w0 >> l));
+        h = max(h, l == 0 ? cs.c[g].cut_h : (cs.c[g].h0 >> l));
+    }
+    dim3 block(64, 4, 1), grid((w + 63) / 64, (h + 3) / 4, cs.n);
+    hipLaunchKernelGGL(blend_level_kernel, grid, block, 0, s, p, cs, l);
+}
+
+// Blender::NO: Blender::feed masked copy in feed order, Blender::blend zeroing, convertTo(8U), cut.
+// The level-0 tile is the ROI itself (no border) and mask0 the blend mask.
+__global__ __launch_bounds__(256) void no_blend_kernel(PyrParams P, CanvasSet CS) {
+    const CanvasParams& C = CS.c[blockIdx.z];
+    const int cam_lo = C.cam_lo, cam_n = C.cam_n;
+    int X = blockIdx.x * 64 + threadIdx.x;
+    int Y = blockIdx.y * 4 + threadIdx.y;
+    if (X >= C.cut_w || Y >= C.cut_h) return;
+    X += C.cut_x;
+    Y += C.cut_y;
+    int v[3] = {0, 0, 0};
+    for (int i = 0; i < cam_n; i++) {
+        const PyrCam& c = P.cam[cam_lo + i];
+        const int x = X - c.tx, y = Y - c.ty;
+        if ((unsigned)x >= (unsigned)c.w0 || (unsigned)y >= (unsigned)c.h0) continue;
+        if (!c.mask0[(size_t)y * c.pitch[0] + x]) continue;
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = c.lvl[0][(size_t)k * c.plane[0] + (size_t)y * c.pitch[0] + x];
+    }
+    uint8_t* d = C.out + (size_t)(Y - C.cut_y) * C.out_stride + 3 * (X - C.cut_x);
+    d[0] = (uint8_t)v[0];
+    d[1] = (uint8_t)v[1];
+    d[2] = (uint8_t)v[2];
+}
+void launch_no_blend(const PyrParams& p, const CanvasSet& cs, hipStream_t s) {
+    int w = 0, h = 0;
+    for (int g = 0; g < cs.n; g++) {
+        w = max(w, cs.c[g].cut_w);
+        h = max(h, cs.c[g].cut_h);
+    }
+    dim3 block(64, 4, 1), grid((w + 63) / 64, (h + 3) / 4, cs.n);
+    hipLaunchKernelGGL(no_blend_kernel, grid, block, 0, s, p, cs);
+}
+
+}  // namespace pano

@@ -5,7 +5,7 @@
 // augmentation per found path, orphan adoption by time stamp and distance.  The algorithm is sequential by construction
 // (the labelling of vertices that end up in neither tree depends on the order of growth), so it runs on the host, as it
 // does in the reference; the pixel work around it - terminal and edge weights from the warped images and masks, and the
-// mask update from the labels - are GPU kernels (pano_kernels.hip).  All weights are integers below 2^24 carried in f32
+// mask update from the labels - are GPU kernels (pano_init.hip).  All weights are integers below 2^24 carried in f32
 // (squared colour distances + 1 + penalties), so the arithmetic is exact and the order of operations does not matter.
 #pragma once
 #include <climits>

@@ -1,5 +1,5 @@
 // pano_kernels.hpp - launch interface between the C-ABI host code (pano_api.cpp) and the gfx950
-// kernels (pano_kernels.hip).  Plain structs passed by value as kernel arguments.
+// kernels (pano_warp / pano_pyramid / pano_blend / pano_blend_small / pano_init .hip).  Plain structs passed by value as kernel arguments.
 #pragma once
 
 #include <hip/hip_runtime.h>
