@@ -591,12 +591,12 @@ def main():
             ts = time.perf_counter()
             for k in range(nstream + 1):
                 s = k & 1
-                if k >= 1:
-                    for grp in range(NG):
-                        ctxs[grp].stream_wait(1 - s)
-                if k < nstream:
+                if k < nstream:          # panorama k goes into slot s (panorama k - 2, its last user, was waited for at k - 1) ...
                     for grp in range(NG):
                         ctxs[grp].stream_submit(s)
+                if k >= 1:               # ... and only then panorama k - 1 is waited for: two panoramas in flight
+                    for grp in range(NG):
+                        ctxs[grp].stream_wait(1 - s)
             rate = round(nstream / (time.perf_counter() - ts), 1)
             # "pano_compose incl. H2D of inputs ... >= 300 frames": the streaming entry (page-locked slots, H2D,
             # compose and D2H of consecutive panoramas overlapped); PCIe-inclusive, so never `value`

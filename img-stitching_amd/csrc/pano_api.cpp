@@ -254,8 +254,7 @@ void free_device(pano_ctx* c) {
         if (sl.h_out) (void)hipHostFree(sl.h_out);
         sl.h_out = nullptr;
         dfree(sl.d_out);
-        if (sl.h2d) (void)hipStreamDestroy(sl.h2d);
-        if (sl.d2h) (void)hipStreamDestroy(sl.d2h);
+        // (the copy streams are process-wide: not this context's to destroy)
         if (sl.in_ready) (void)hipEventDestroy(sl.in_ready);
         if (sl.composed) (void)hipEventDestroy(sl.composed);
         if (sl.out_ready) (void)hipEventDestroy(sl.out_ready);
@@ -274,10 +273,7 @@ void free_device(pano_ctx* c) {
     }
     if (c->pin_out) (void)hipHostFree(c->pin_out);
     c->pin_out = nullptr;
-    for (auto& hs : c->host_h2d) {
-        if (hs) (void)hipStreamDestroy(hs);
-        hs = nullptr;
-    }
+    for (auto& hs : c->host_h2d) hs = nullptr;  // the device's shared copy queues: not this context's to destroy
     for (auto& he : c->host_in_ready) {
         if (he) (void)hipEventDestroy(he);
         he = nullptr;
@@ -1875,6 +1871,9 @@ static bool is_pinned_host(const void* p, size_t bytes) {
 // process(vector<Mat>&, Mat&) (ocvstitcher.hpp:1141): host frames in, host panorama out, synchronous.  Page-locked caller
 // memory is DMA'd directly; pageable memory goes through the ctx's page-locked staging, copied by the pool's threads while the
 // previous camera's DMA runs (pano_hostcopy.hpp).  Works in frame slot 0 (pano.h) whatever slot the caller has selected.
+namespace {
+hipError_t shared_copy_streams(int device, hipStream_t* h2d, hipStream_t* d2h);  // below, with the streaming slots
+}
 static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides, uint8_t* h_out,
                               size_t out_stride) {
     pano_status st = check_compute(c);
@@ -1905,9 +1904,13 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
     }
     c->stage_out_pitch = out_pitch;
     if (!c->host_h2d[0]) {
-        for (auto& hs : c->host_h2d) HIP_TRY(c, hipStreamCreateWithFlags(&hs, hipStreamNonBlocking));
+        // the device's shared upload / download queues (see shared_copy_streams): both stitcher threads of a rig feed the same
+        // two queues, so the link runs in both directions at once instead of the contexts' streams colliding on hardware queues
+        hipError_t se = shared_copy_streams(c->device, &c->host_h2d[0], &c->host_h2d[1]);
+        if (se != hipSuccess) HIP_TRY(c, se);
         for (auto& he : c->host_in_ready) HIP_TRY(c, hipEventCreateWithFlags(&he, hipEventDisableTiming));
     }
+    hipStream_t up = c->host_h2d[0], down = c->host_h2d[1];
     const int prev_slot = c->cur_slot;
     if (c->nslots > 1 && prev_slot != 0) bind_slot(c, 0);
     hipStream_t s = c->own_stream;
@@ -1942,7 +1945,7 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
         // link rate (1.3 GB/s measured for 11679-byte rows), slower than staging them
         if (strides[i] != in_pitch || !is_pinned_host(h_frames[i], strides[i] * (size_t)(c->frame_h - 1) + row_in)) {
             if (!c->pin_in[i] || c->pin_in_pitch != in_pitch) {
-                HIP_TRY(c, hipStreamSynchronize(c->host_h2d[i & 1]));
+                HIP_TRY(c, hipStreamSynchronize(up));
                 if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
                 c->pin_in[i] = nullptr;
                 HIP_TRY(c, hipHostMalloc((void**)&c->pin_in[i], in_pitch * c->frame_h, hipHostMallocDefault));
@@ -1954,19 +1957,15 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
     }
     for (int i = 0; i < P.n; i++) {
         pool.wait(staged[i]);
-        // two copy queues: consecutive cameras can use two DMA engines
-        HIP_TRY(c, hipMemcpyAsync(c->stage_in[i], dma_src[i], in_pitch * (size_t)(c->frame_h - 1) + row_in, hipMemcpyHostToDevice,
-                                  c->host_h2d[i & 1]));
+        HIP_TRY(c, hipMemcpyAsync(c->stage_in[i], dma_src[i], in_pitch * (size_t)(c->frame_h - 1) + row_in, hipMemcpyHostToDevice, up));
         frames[i] = c->stage_in[i];
         pitches[i] = in_pitch;
     }
     c->pin_in_pitch = in_pitch;
-    for (int k = 0; k < 2; k++) {
-        HIP_TRY(c, hipEventRecord(c->host_in_ready[k], c->host_h2d[k]));
-        HIP_TRY(c, hipStreamWaitEvent(s, c->host_in_ready[k], 0));
-    }
+    HIP_TRY(c, hipEventRecord(c->host_in_ready[0], up));
+    HIP_TRY(c, hipStreamWaitEvent(s, c->host_in_ready[0], 0));
     if (!any_staged)  // nothing was staged, so queueing took no time: the turn lasts until the frames have crossed the link
-        for (int k = 0; k < 2; k++) HIP_TRY(c, hipEventSynchronize(c->host_in_ready[k]));
+        HIP_TRY(c, hipEventSynchronize(c->host_in_ready[0]));
     turn.unlock();
     if (trace) tp[1] = now();
     // a page-locked panorama buffer whose rows fit the staging buffer: the blend writes rows at the CALLER's stride (it takes
@@ -1990,9 +1989,13 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
         c->host_trace_n++;
     };
     const size_t out_bytes = dev_pitch * (size_t)(P.cut.h - 1) + row_out;
+    // the way back runs on the device's download queue, behind the kernels of THIS context only
+    HIP_TRY(c, hipEventRecord(c->host_in_ready[1], s));
+    HIP_TRY(c, hipStreamWaitEvent(down, c->host_in_ready[1], 0));
     if (direct_out) {
-        HIP_TRY(c, hipMemcpyAsync(h_out, c->stage_out, out_bytes, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, hipMemcpyAsync(h_out, c->stage_out, out_bytes, hipMemcpyDeviceToHost, down));
+        HIP_TRY(c, hipEventRecord(c->host_in_ready[1], down));
+        HIP_TRY(c, hipEventSynchronize(c->host_in_ready[1]));
         account();
         return PANO_OK;
     }
@@ -2000,12 +2003,13 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
     // the panorama comes back in two halves so that the host copy of the first overlaps the DMA of the second
     const int h0 = P.cut.h / 2;
     const size_t b0 = out_pitch * (size_t)h0;
-    if (h0 > 0) HIP_TRY(c, hipMemcpyAsync(c->pin_out, c->stage_out, b0, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipEventRecord(c->host_in_ready[0], s));
-    HIP_TRY(c, hipMemcpyAsync(c->pin_out + b0, c->stage_out + b0, out_bytes - b0, hipMemcpyDeviceToHost, s));
+    if (h0 > 0) HIP_TRY(c, hipMemcpyAsync(c->pin_out, c->stage_out, b0, hipMemcpyDeviceToHost, down));
+    HIP_TRY(c, hipEventRecord(c->host_in_ready[0], down));
+    HIP_TRY(c, hipMemcpyAsync(c->pin_out + b0, c->stage_out + b0, out_bytes - b0, hipMemcpyDeviceToHost, down));
+    HIP_TRY(c, hipEventRecord(c->host_in_ready[1], down));
     HIP_TRY(c, hipEventSynchronize(c->host_in_ready[0]));
     pool.copy2d(h_out, out_stride, c->pin_out, out_pitch, row_out, h0);
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipEventSynchronize(c->host_in_ready[1]));
     if (trace) tp[4] = now();
     pool.copy2d(h_out + (size_t)h0 * out_stride, out_stride, c->pin_out + b0, out_pitch, row_out, P.cut.h - h0);
     account();
@@ -2101,8 +2105,25 @@ pano_status pano_stack_finalcut_host(pano_ctx* c, const uint8_t* h_up, int up_w,
 }
 
 namespace {
+// process-wide copy streams, one pair per device, created on first use and never destroyed
+hipError_t shared_copy_streams(int device, hipStream_t* h2d, hipStream_t* d2h) {
+    static std::mutex m;
+    static hipStream_t up[64] = {}, down[64] = {};
+    std::lock_guard<std::mutex> g(m);
+    if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+    if (!up[device]) {
+        hipError_t e = hipStreamCreateWithFlags(&up[device], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        e = hipStreamCreateWithFlags(&down[device], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *h2d = up[device];
+    *d2h = down[device];
+    return hipSuccess;
+}
 pano_status ensure_slots(pano_ctx* c) {
     if (c->slots_ready) return PANO_OK;
+    hipError_t st_ = hipSuccess;
     const Plan& P = c->plan;
     c->slot_in_pitch = align_up((size_t)c->frame_w * 3, 256);
     c->slot_out_pitch = align_up((size_t)P.pano.w * 3, 256);  // room for any later cut
@@ -2113,8 +2134,11 @@ pano_status ensure_slots(pano_ctx* c) {
         }
         HIP_TRY(c, hipHostMalloc((void**)&sl.h_out, c->slot_out_pitch * P.pano.h, hipHostMallocDefault));
         HIP_TRY(c, hipMalloc((void**)&sl.d_out, c->slot_out_pitch * P.pano.h));
-        HIP_TRY(c, hipStreamCreateWithFlags(&sl.h2d, hipStreamNonBlocking));
-        HIP_TRY(c, hipStreamCreateWithFlags(&sl.d2h, hipStreamNonBlocking));
+        // ONE upload and ONE download queue per device, shared by every slot of every context: uploads all cross the same link
+        // anyway, and the runtime multiplexes streams onto a few hardware queues (4 by default) - with a pair of copy streams
+        // per slot and context (8 + 2 compute streams for the two stitchers of a rig) uploads, downloads and kernels of
+        // unrelated slots landed on the same hardware queue and the link ran in one direction at a time
+        if ((st_ = shared_copy_streams(c->device, &sl.h2d, &sl.d2h)) != hipSuccess) HIP_TRY(c, st_);
         HIP_TRY(c, hipEventCreateWithFlags(&sl.in_ready, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&sl.composed, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&sl.out_ready, hipEventDisableTiming));
