@@ -106,6 +106,7 @@ struct pano_ctx {
     int live[kMaxCams][kMaxLevels][4] = {};
     // dead columns {x0, x1} (inclusive, x1 < x0 = none) inside the live rect: the middle of a +-pi straddler's tile
     int gap[kMaxCams][kMaxLevels][2] = {};
+    PyrTailCfg pyr_tail{0, 64, 2, 32};  // PANO_PYR_HEAD / PANO_PYR_TAIL (+ _TS): how the pyrDown chain is cut into launches
     bool full_tiles = false;  // PANO_FULL_TILES=1: produce every pixel of every level (stage inspection)
     int nslots = 1, cur_slot = 0;
     char* slot_pyr[PANO_MAX_FRAME_SLOTS] = {};
@@ -1255,6 +1256,10 @@ static pano_status prepare_impl(pano_ctx* c) {
         c->cv.small_live = c->small_live;
     }
     c->full_tiles = getenv("PANO_FULL_TILES") && atoi(getenv("PANO_FULL_TILES"));
+    if (getenv("PANO_PYR_TAIL")) c->pyr_tail.base = std::max(atoi(getenv("PANO_PYR_TAIL")), 0);
+    if (getenv("PANO_PYR_TAIL_TS")) c->pyr_tail.ts = atoi(getenv("PANO_PYR_TAIL_TS")) == 64 ? 64 : 32;
+    if (getenv("PANO_PYR_HEAD")) c->pyr_tail.head = std::max(atoi(getenv("PANO_PYR_HEAD")), 0);
+    if (getenv("PANO_PYR_HEAD_TS")) c->pyr_tail.head_ts = atoi(getenv("PANO_PYR_HEAD_TS")) == 64 ? 64 : 32;
     // launch-shape knobs of the blend (A/B levers of DESIGN.md section 6/8; none changes a result)
     c->l0_order = !(getenv("PANO_L0_ORDER") && atoi(getenv("PANO_L0_ORDER")) == 0);
     c->cv.k3_shape = getenv("PANO_K3_SHAPE") ? atoi(getenv("PANO_K3_SHAPE")) & 3 : 3;
@@ -1672,7 +1677,7 @@ pano_status pano_feed_cameras(pano_ctx* c, unsigned cam_bits, const uint8_t* con
     } else {
         launch_warp_tiles(wp, k, mw, mh, s);
     }
-    for (int l = 0; l < pyr_levels(c); l++) launch_pyr_down(c->pyr, cam_bits, l, s);
+    launch_pyr_chain(c->pyr, cam_bits, pyr_levels(c), c->pyr_tail, s);
     if (c->profiling && (st = record(c, 2, s)) != PANO_OK) return st;
     HIP_TRY(c, hipGetLastError());
     return PANO_OK;
@@ -1816,7 +1821,7 @@ pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b, const uint8_t* const* fa
     for (int i = 0; i < B.n; i++) pp.cam[A.n + i] = b->pyr.cam[i];
     pp.ncam = A.n + B.n;
     const unsigned all = (1u << pp.ncam) - 1u;
-    for (int l = 0; l < pyr_levels(a); l++) launch_pyr_down(pp, all, l, s);
+    launch_pyr_chain(pp, all, pyr_levels(a), a->pyr_tail, s);
     if (prof && (st = record(a, 2, s)) != PANO_OK) return st;
     // K3: both canvases per launch
     CanvasSet cs{};

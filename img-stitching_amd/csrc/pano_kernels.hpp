@@ -135,6 +135,34 @@ void launch_warp_mask(const WarpCam& c, uint8_t* dst, int dst_stride, hipStream_
 
 // K2: one pyrDown level (16S x3) for the selected cameras: level `l` -> level `l+1`
 void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s);
+// K2 tail: levels b -> b+1 -> ... -> t (1 <= t - b <= 4) in ONE launch, tiled through LDS with the halo recomputed;
+// ts = 32 | 64: the tile of level b + 1 a workgroup owns
+void launch_pyr_tail(const PyrParams& p, unsigned cam_bits, int b, int t, int ts, hipStream_t s);
+bool pyr_tail_ok(const PyrParams& p, unsigned cam_bits, int t);  // every source level of the tail at least 4 x 4
+// how the per-frame pyrDown chain 0 -> levels is cut into launches: levels 0 .. head as one pyr_tail launch (head <= 1: plain
+// launches), plain launches up to level base, levels base .. top as one pyr_tail launch (base = 0 or fewer than two levels
+// left: plain launches)
+struct PyrTailCfg {
+    int head, head_ts;  // PANO_PYR_HEAD, PANO_PYR_HEAD_TS
+    int base, ts;       // PANO_PYR_TAIL, PANO_PYR_TAIL_TS
+};
+inline void launch_pyr_chain(const PyrParams& p, unsigned cam_bits, int levels, PyrTailCfg cfg, hipStream_t s) {
+    int l = 0;
+    const int head = cfg.head < levels ? cfg.head : levels;
+    if (head >= 1 && head <= 4 && ((cfg.head_ts == 64 ? 64 : 32) >> (head - 1)) >= 4 && pyr_tail_ok(p, cam_bits, head)) {
+        launch_pyr_tail(p, cam_bits, 0, head, cfg.head_ts, s);
+        l = head;
+    }
+    int plain = levels;
+    if (cfg.base > 0) {
+        int b = cfg.base > levels - 4 ? cfg.base : levels - 4;
+        if (b < l) b = l;
+        const int T = (cfg.ts == 64 ? 64 : 32) >> (levels - b - 1);
+        if (levels - b >= 2 && levels - b <= 4 && T >= 4 && pyr_tail_ok(p, cam_bits, levels)) plain = b;
+    }
+    for (; l < plain; l++) launch_pyr_down(p, cam_bits, l, s);
+    if (l < levels) launch_pyr_tail(p, cam_bits, l, levels, cfg.ts, s);
+}
 // K3: one blend level for the whole canvas (Laplacian, weight, accumulate, normalise, collapse);
 // level 0 writes the cut 8U panorama
 // ev_start / ev_stop (optional, level 0): the dispatch's own begin / end timestamps

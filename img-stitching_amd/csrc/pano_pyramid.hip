@@ -90,6 +90,256 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam
     if (y0 + 1 < dh) *reinterpret_cast<unsigned*>(d + c.pitch[l + 1]) = p1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2 tail: the pyrDown chain level b -> b+1 -> ... -> t (t - b <= 4) of a camera plane in ONE launch.
+// One at a time the small levels are launches of 4 - 5 us with almost no work (config 2: 216 x 124 pixels and fewer per
+// plane above level 2): every launch pays its ramp - dispatch, cold instruction cache, a round trip of dependent loads, the
+// drain of its stores - and the chain pays it per level.  Here a workgroup owns a TS x TS tile of level b+1 (and the tiles
+// half, a quarter, an eighth that size of the levels above that lie over it), stages the pixels of level b that its chain
+// depends on in LDS once (the footprint grows by 2 pixels per side and level, h_l = 2 h_{l+1} + 2: at most 30 per side), and
+// walks up level by level through LDS with the halo recomputed; every level's owned pixels are written on the way.
+// Same arithmetic as pyr_down_kernel bit for bit: 4 x 2 outputs per lane and step from seven 16-byte windows, pyr_down_hrow's
+// chained v_dot4.  The LDS boxes hold REFLECT_101 pads (rows -2, -1, h; columns -2, -1, w: written by whoever writes the cell
+// they mirror, in workgroups whose boxes touch a border), so the windows are read with no border logic: three ds_read_b64
+// per row, of which the middle 16 bytes are the window.
+// What is produced follows the live rects like pyr_down_kernel: per level the owned tile is cut to the live rect, what
+// is computed is the bounding box of that and of the footprint of the level above ("need"), nothing else.
+// Needs every source level (b .. t-1) to be at least 4 x 4 (the pads mirror rows / columns 1 and 2): pyr_tail_ok.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTailMaxJ = 4;
+constexpr int kTailSlack = 16;  // bytes in front of and behind every LDS row: the column pads, and the part of a 24-byte
+                                // read that lies outside the stored columns (it feeds outputs nobody needs)
+// worst-case LDS box of level b + j for a TS x TS tile of level b + 1 and a chain of at most MJ levels (pitch x rows incl. 2
+// pad rows on top and 3 below): halo 2^(MJ - j + 1) - 2 pixels per side; columns stored from a multiple of 16 (level b) / 8
+__host__ __device__ constexpr int tail_halo(int MJ, int j) { return j >= MJ ? 0 : (2 << (MJ - j)) - 2; }
+__host__ __device__ constexpr int tail_tile(int TS, int j) { return j == 0 ? 2 * TS : TS >> (j - 1); }
+__host__ __device__ constexpr int tail_pitch(int TS, int MJ, int j) {
+    return (tail_tile(TS, j) < 8 ? 8 : tail_tile(TS, j)) + 2 * ((tail_halo(MJ, j) + (j == 0 ? 15 : 7)) & ~(j == 0 ? 15 : 7)) + 2 * kTailSlack;
+}
+__host__ __device__ constexpr int tail_cap(int TS, int MJ, int j) {
+    return j > MJ ? 0 : tail_pitch(TS, MJ, j) * (tail_tile(TS, j) + 2 * tail_halo(MJ, j) + 5);
+}
+__host__ __device__ constexpr int tail_lds_bytes(int TS, int MJ) {
+    return tail_cap(TS, MJ, 0) + tail_cap(TS, MJ, 1) + tail_cap(TS, MJ, 2) + tail_cap(TS, MJ, 3) + tail_cap(TS, MJ, 4);
+}
+static_assert(tail_lds_bytes(64, 4) <= 64 * 1024 && tail_pitch(64, 4, 0) == 224 && tail_pitch(64, 4, 1) == 128 && tail_pitch(64, 4, 3) == 64, "static LDS");
+struct TailBox {
+    int x0, y0, x1, y1;  // inclusive; x1 < x0: empty
+};
+__device__ __forceinline__ bool tail_empty(const TailBox& b) { return b.x1 < b.x0 || b.y1 < b.y0; }
+
+// Stores N dwords d[] = columns x .. x + 4N - 1 of row y of a w x h level into its LDS box (row 0 of the box = level row
+// by0 - 2, byte kTailSlack of a box row = level column bx0); EDGE: also into the REFLECT_101 pads that mirror them
+template <int N, bool EDGE>
+__device__ __forceinline__ void tail_put(uint8_t* box, int pitch, int bx0, int by0, int w, int h, int x, int y, const unsigned (&d)[N]) {
+    const int rows[3] = {y, (y == 1 || y == 2) ? -y : INT_MIN, y == h - 2 ? h : INT_MIN};
+#pragma unroll
+    for (int k = 0; k < (EDGE ? 3 : 1); k++) {
+        if (rows[k] == INT_MIN) continue;
+        uint8_t* r = box + (rows[k] - by0 + 2) * pitch + kTailSlack + (x - bx0);
+#pragma unroll
+        for (int i = 0; i < N; i++) reinterpret_cast<unsigned*>(r)[i] = d[i];
+        if (!EDGE) continue;
+        if (x == 0) {  // columns -1, -2 = columns 1, 2
+            r[-1] = (uint8_t)(d[0] >> 8);
+            r[-2] = (uint8_t)(d[0] >> 16);
+        }
+        const int m = w - 2 - x;  // column w = column w - 2
+        if (m >= 0 && m < 4 * N) {
+            unsigned v = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++)
+                if ((m >> 2) == i) v = d[i];
+            r[m + 2] = (uint8_t)(v >> (8 * (m & 3)));
+        }
+    }
+}
+
+template <int TS, int THREADS, int MJ>
+__global__ __launch_bounds__(THREADS) void pyr_tail_kernel(PyrParams P, unsigned cam_bits, int b, int t) {
+    static_assert(MJ >= 1 && MJ <= kTailMaxJ && tail_cap(TS, MJ, 0) % 8 == 0 && tail_cap(TS, MJ, 1) % 8 == 0 && tail_cap(TS, MJ, 2) % 8 == 0 &&
+                      tail_cap(TS, MJ, 3) % 8 == 0, "LDS boxes 8-byte aligned");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[tail_lds_bytes(TS, MJ)];
+    const int ci = blockIdx.z / 3, pl = blockIdx.z - ci * 3;
+    if (!((cam_bits >> ci) & 1u)) return;
+    const PyrCam& c = P.cam[ci];
+    const int J = t - b;  // <= MJ
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    // what this workgroup owns and needs of every level, top down (block-uniform: scalar registers)
+    TailBox own[kTailMaxJ + 1], need[kTailMaxJ + 1];
+    TailBox nx = {0, 0, -1, -1};
+#pragma unroll
+    for (int j = kTailMaxJ; j >= 1; j--) {
+        own[j] = need[j] = TailBox{0, 0, -1, -1};
+        if (j > J || j > MJ) continue;
+        const int l = b + j;
+        const int Tl = TS >> (j - 1);
+        const int w = c.w0 >> l, h = c.h0 >> l;
+        TailBox o;
+        o.x0 = max((int)blockIdx.x * Tl, c.live[l][0]);
+        o.x1 = min(min((int)blockIdx.x * Tl + Tl - 1, w - 1), c.live[l][2]);
+        o.y0 = max((int)blockIdx.y * Tl, c.live[l][1]);
+        o.y1 = min(min((int)blockIdx.y * Tl + Tl - 1, h - 1), c.live[l][3]);
+        if (o.x0 >= c.gap[l][0] && o.x1 <= c.gap[l][1]) o.x1 = o.x0 - 1;  // inside the dead middle of a +-pi straddler's tile
+        if (tail_empty(o)) o = TailBox{0, 0, -1, -1};
+        own[j] = o;
+        TailBox n = o;
+        if (!tail_empty(nx)) {  // the pyrDown footprint of what the level above needs
+            const TailBox f = {max(2 * nx.x0 - 2, 0), max(2 * nx.y0 - 2, 0), min(2 * nx.x1 + 2, w - 1), min(2 * nx.y1 + 2, h - 1)};
+            n = tail_empty(o) ? f : TailBox{min(o.x0, f.x0), min(o.y0, f.y0), max(o.x1, f.x1), max(o.y1, f.y1)};
+        }
+        need[j] = n;
+        nx = n;
+    }
+    if (tail_empty(nx)) return;  // nothing of this tile is live at any level (the whole workgroup leaves)
+    {
+        const int w = c.w0 >> b, h = c.h0 >> b;
+        own[0] = TailBox{0, 0, -1, -1};
+        need[0] = TailBox{max(2 * nx.x0 - 2, 0), max(2 * nx.y0 - 2, 0), min(2 * nx.x1 + 2, w - 1), min(2 * nx.y1 + 2, h - 1)};
+    }
+    // LDS boxes: columns from sx0 (16-byte aligned at level b, else 8-byte), rows from sy0 - 2; edge: the box holds cells
+    // that a REFLECT_101 pad mirrors (rows 1, 2, h - 2; columns 1, 2, w - 2)
+    int sx0[kTailMaxJ + 1], sy0[kTailMaxJ + 1], pitch[kTailMaxJ + 1], off[kTailMaxJ + 1];
+    bool edge[kTailMaxJ + 1];
+    {
+        int o = 0;
+#pragma unroll
+        for (int j = 0; j <= kTailMaxJ; j++) {
+            const int ax = j == 0 ? 15 : 7;
+            const int w = c.w0 >> (b + j), h = c.h0 >> (b + j);
+            sx0[j] = need[j].x0 & ~ax;
+            sy0[j] = need[j].y0;
+            pitch[j] = tail_empty(need[j]) ? 0 : ((need[j].x1 | ax) - sx0[j] + 1) + 2 * kTailSlack;
+            edge[j] = sx0[j] == 0 || (need[j].x1 | ax) >= w - 2 || need[j].y0 <= 2 || need[j].y1 >= h - 2;
+            off[j] = o;
+            o += tail_cap(TS, MJ, j);
+        }
+    }
+    // level b: global -> LDS, 16-byte chunks; lanes = 16 chunk columns x THREADS / 16 rows, every load in flight before the
+    // first store
+    {
+        const int w = c.w0 >> b, h = c.h0 >> b;
+        const int nrows = need[0].y1 - need[0].y0 + 1;  // <= 2 TS + 2 halo
+        const uint8_t* g = c.lvl[b] + (size_t)pl * c.plane[b] + (unsigned)(sy0[0] * c.pitch[b] + sx0[0]);
+        const int cpr = (pitch[0] - 2 * kTailSlack) >> 4;
+        static_assert((tail_pitch(TS, MJ, 0) - 2 * kTailSlack) / 16 <= 16, "16 chunk columns");
+        const int cx = tid & 15, cy = tid >> 4;
+        if (cx < cpr) {
+            constexpr int kRowsPerPass = THREADS / 16;
+            constexpr int kBatch = (2 * TS + 2 * tail_halo(MJ, 0) + kRowsPerPass - 1) / kRowsPerPass;
+            uint4 d[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                const int r = min(cy + kRowsPerPass * k, nrows - 1);
+                d[k] = *reinterpret_cast<const uint4*>(g + (unsigned)(r * c.pitch[b] + 16 * cx));
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                const int r = cy + kRowsPerPass * k;
+                if (r < nrows) {
+                    const unsigned dd[4] = {d[k].x, d[k].y, d[k].z, d[k].w};
+                    if (edge[0]) tail_put<4, true>(lds + off[0], pitch[0], sx0[0], sy0[0], w, h, sx0[0] + 16 * cx, sy0[0] + r, dd);
+                    else tail_put<4, false>(lds + off[0], pitch[0], sx0[0], sy0[0], w, h, sx0[0] + 16 * cx, sy0[0] + r, dd);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 1; j <= MJ; j++) {
+        if (j > J || tail_empty(need[j])) continue;  // block-uniform
+        const int l = b + j;
+        const int dw = c.w0 >> l, dh = c.h0 >> l;
+        const uint8_t* S = lds + off[j - 1];
+        const int ps = pitch[j - 1];
+        // items = column groups need.x0 >> 2 .. need.x1 >> 2 (<= 24) x row pairs need.y0 >> 1 .. need.y1 >> 1 (<= 47), dealt
+        // to the lanes in row-major order: the waves beyond the last item leave at once
+        const int g0 = need[j].x0 >> 2, ngx = (need[j].x1 >> 2) - g0 + 1;
+        const int r0 = need[j].y0 >> 1, nry = (need[j].y1 >> 1) - r0 + 1;
+        const int nitems = ngx * nry;
+        const unsigned rcp = (65536u + (unsigned)ngx - 1u) / (unsigned)ngx;  // item / ngx == item * rcp >> 16 for item < 2730
+        uint8_t* const gl = c.lvl[l] + (size_t)pl * c.plane[l];
+        const int gp = c.pitch[l];
+        for (int item = tid; item < nitems; item += THREADS) {
+            const int rp = (int)(((unsigned)item * rcp) >> 16);
+            const int tg = g0 + item - rp * ngx;  // group of four output columns 4 tg .. 4 tg + 3
+            const int y0 = 2 * (r0 + rp);
+            // source bytes 8 tg - 8 .. 8 tg + 15 (8-byte aligned in LDS); the window is columns 8 tg - 4 .. 8 tg + 11
+            const uint8_t* Sr = S + (2 * y0 - sy0[j - 1]) * ps + kTailSlack + (8 * tg - 8 - sx0[j - 1]);
+            int acc0[4] = {128, 128, 128, 128}, acc1[4] = {128, 128, 128, 128};
+#pragma unroll
+            for (int r = 0; r < 7; r++) {
+                const uint2* r64 = reinterpret_cast<const uint2*>(Sr + r * ps);
+                const uint2 A = r64[0], B = r64[1], C = r64[2];
+                int h[4];
+                pyr_down_hrow(make_uint4(A.y, B.x, B.y, C.x), h);
+                const int wa = r == 0 ? 1 : (r == 1 ? 4 : (r == 2 ? 6 : (r == 3 ? 4 : (r == 4 ? 1 : 0))));
+                const int wb = r == 2 ? 1 : (r == 3 ? 4 : (r == 4 ? 6 : (r == 5 ? 4 : (r == 6 ? 1 : 0))));
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    acc0[k] += h[k] * wa;
+                    acc1[k] += h[k] * wb;
+                }
+            }
+            unsigned p0 = 0, p1 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                p0 |= (unsigned)(acc0[k] >> 8) << (8 * k);
+                p1 |= (unsigned)(acc1[k] >> 8) << (8 * k);
+            }
+            if (j < J) {  // this level is the source of the next
+                const unsigned d0[1] = {p0}, d1[1] = {p1};
+                if (edge[j]) {
+                    tail_put<1, true>(lds + off[j], pitch[j], sx0[j], sy0[j], dw, dh, 4 * tg, y0, d0);
+                    tail_put<1, true>(lds + off[j], pitch[j], sx0[j], sy0[j], dw, dh, 4 * tg, y0 + 1, d1);
+                } else {
+                    tail_put<1, false>(lds + off[j], pitch[j], sx0[j], sy0[j], dw, dh, 4 * tg, y0, d0);
+                    tail_put<1, false>(lds + off[j], pitch[j], sx0[j], sy0[j], dw, dh, 4 * tg, y0 + 1, d1);
+                }
+            }
+            if (4 * tg + 3 >= own[j].x0 && 4 * tg <= own[j].x1) {
+                if (y0 >= own[j].y0 && y0 <= own[j].y1) *reinterpret_cast<unsigned*>(gl + (unsigned)(y0 * gp + 4 * tg)) = p0;
+                if (y0 + 1 >= own[j].y0 && y0 + 1 <= own[j].y1) *reinterpret_cast<unsigned*>(gl + (unsigned)((y0 + 1) * gp + 4 * tg)) = p1;
+            }
+        }
+        if (j < J) __syncthreads();
+    }
+}
+
+// the tail needs source levels of at least 4 x 4
+bool pyr_tail_ok(const PyrParams& p, unsigned cam_bits, int t) {
+    for (int i = 0; i < p.ncam; i++)
+        if (((cam_bits >> i) & 1u) && ((p.cam[i].w0 >> (t - 1)) < 4 || (p.cam[i].h0 >> (t - 1)) < 4)) return false;
+    return true;
+}
+
+// ts: tile of level b + 1 per workgroup (64: 512 lanes, 32: 256 lanes)
+void launch_pyr_tail(const PyrParams& p, unsigned cam_bits, int b, int t, int ts, hipStream_t s) {
+    int mw = 0, mh = 0;
+    for (int i = 0; i < p.ncam; i++)
+        if ((cam_bits >> i) & 1u) {
+            mw = max(mw, p.cam[i].w0 >> t);
+            mh = max(mh, p.cam[i].h0 >> t);
+        }
+    const int J = t - b;
+    if (mw == 0 || mh == 0 || J < 1 || J > kTailMaxJ) return;
+    ts = ts == 64 ? 64 : 32;
+    const int T = ts >> (J - 1);  // tile of the top level
+    if (T < 1) return;
+    dim3 grid((mw + T - 1) / T, (mh + T - 1) / T, p.ncam * 3);
+#define PANO_TAIL(TS_, TH_, MJ_) hipLaunchKernelGGL((pyr_tail_kernel<TS_, TH_, MJ_>), grid, dim3(64, TH_ / 64, 1), 0, s, p, cam_bits, b, t)
+    if (ts == 64) {
+        if (J == 1) PANO_TAIL(64, 512, 1);
+        else if (J == 2) PANO_TAIL(64, 512, 2);
+        else PANO_TAIL(64, 512, 4);
+    } else {
+        if (J <= 2) PANO_TAIL(32, 256, 2);
+        else if (J == 3) PANO_TAIL(32, 256, 3);
+        else PANO_TAIL(32, 256, 4);
+    }
+#undef PANO_TAIL
+}
+
 void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s) {
     int mw = 0, mh = 0;
     for (int i = 0; i < p.ncam; i++)
