@@ -90,7 +90,7 @@ struct pano_ctx {
     bool use_lut = true;
     uint16_t* owner[kMaxLevels] = {};
     uint8_t* small_live = nullptr;   // CanvasParams::small_live
-    uint16_t* order0 = nullptr;      // CanvasParams::order0
+    uint32_t* order0 = nullptr;      // CanvasParams::order0
     size_t order_cap = 0;
     bool order_dirty = false;
     bool l0_order = true;            // PANO_L0_ORDER=0: plain band order
@@ -526,29 +526,31 @@ pano_status build_tile_order(pano_ctx* c, hipStream_t s) {
     const size_t T = (size_t)gx * gy;
     if (T == 0 || T >= 0xffffu) return PANO_OK;
     const size_t per = (T + 7) / 8;
-    uint8_t* d_flags = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_flags, T));
+    uint16_t* d_flags = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_flags, T * sizeof(uint16_t)));
     launch_tile_mixed(cv, gx, gy, d_flags, s);
-    std::vector<uint8_t> flags(T);
-    hipError_t fe = hipMemcpyAsync(flags.data(), d_flags, T, hipMemcpyDeviceToHost, s);
+    std::vector<uint16_t> flags(T);  // four owner nibbles per tile, one per wave (0xF: that wave takes the general path)
+    hipError_t fe = hipMemcpyAsync(flags.data(), d_flags, T * sizeof(uint16_t), hipMemcpyDeviceToHost, s);
     if (fe == hipSuccess) fe = hipStreamSynchronize(s);
     (void)hipFree(d_flags);
     HIP_TRY(c, fe);
-    std::vector<uint16_t> order(8 * per, 0xffffu);
+    const bool hints = !(getenv("PANO_L0_HINTS") && atoi(getenv("PANO_L0_HINTS")) == 0);  // 0: every wave looks its owners up
+    auto mixed = [](uint16_t f) { return (f & 0xf) == 0xf || ((f >> 4) & 0xf) == 0xf || ((f >> 8) & 0xf) == 0xf || (f >> 12) == 0xf; };
+    std::vector<uint32_t> order(8 * per, 0xffffu);
     for (size_t k = 0; k < 8; k++) {
         const size_t lo = k * per, hi = std::min(T, lo + per);
         size_t o = lo;
         for (int pass = 1; pass >= 0; pass--)
             for (size_t t = lo; t < hi; t++)
-                if (flags[t] == pass) order[o++] = (uint16_t)t;
+                if ((int)mixed(flags[t]) == pass) order[o++] = (uint32_t)t | (uint32_t)(hints ? flags[t] : 0xffffu) << 16;
     }
     if (c->order_cap < order.size()) {
         dfree(c->order0);
         c->order_cap = 0;
-        HIP_TRY(c, hipMalloc((void**)&c->order0, order.size() * sizeof(uint16_t)));
+        HIP_TRY(c, hipMalloc((void**)&c->order0, order.size() * sizeof(uint32_t)));
         c->order_cap = order.size();
     }
-    HIP_TRY(c, hipMemcpy(c->order0, order.data(), order.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->order0, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->cv.order0 = c->order0;
     c->cv.order_per = (int)per;
     c->cv.order_gx = gx;

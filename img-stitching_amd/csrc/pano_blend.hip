@@ -239,17 +239,27 @@ __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0
 // path.  pb: first plane of this lane (NPL == 1: one plane per lane)
 template <bool L0, int NPL>
 __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasParams& C, const int l, const int X0, const int Y0,
-                                            const int pb) {
+                                            const int pb, const unsigned hint = 0xfu) {
     const int cam_lo = C.cam_lo;
     const int cw = C.w0 >> l, ch = C.h0 >> l;
     // Away from the seams a block belongs to exactly one camera with weight 1.0f everywhere (or to none):
     // the static owner map says so in one byte, and the block needs no weights, no float math and no division:
     //   acc = lap, W = 1  =>  norm = lap - sign(lap)  (see below)
     // one 16-bit entry per block: low byte = owner code, high byte = the cameras that carry weight anywhere on the block
-    const unsigned entry = C.owner[l][(unsigned)(__mul24(Y0 >> 1, C.opitch[l]) + (X0 >> 2))];
-    const unsigned code = entry & 0xffu;
-    const unsigned ucode = __builtin_amdgcn_readfirstlane(code);
-    if (ucode != 0xffu && __builtin_amdgcn_ballot_w64(code != ucode) == 0) {
+    // hint (wave-uniform, from a static per-wave table): 0..7 / 0xE = every block of this wave has that single owner / none, so
+    // the wave does not wait for its owner entries before it can issue its pixel loads; 0xF = look
+    unsigned entry = 0, ucode;
+    bool single;
+    if (hint != 0xfu) {
+        ucode = hint < 8u ? hint : 0xfeu;
+        single = true;
+    } else {
+        entry = C.owner[l][(unsigned)(__mul24(Y0 >> 1, C.opitch[l]) + (X0 >> 2))];
+        const unsigned code = entry & 0xffu;
+        ucode = __builtin_amdgcn_readfirstlane(code);
+        single = ucode != 0xffu && __builtin_amdgcn_ballot_w64(code != ucode) == 0;
+    }
+    if (single) {
         // the whole wave (a 256 x 2 strip) has one owner: its parameters are scalar, the code is straight-line
         // and every load is in flight before the first use
         int v[3][2][4];
@@ -461,6 +471,7 @@ template <bool L0, int NPL = 3>
 __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, CanvasSet CS, int lvl) {
     static_assert(NPL == 3 || !L0, "level 0 writes interleaved BGR");
     unsigned bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+    unsigned hint = 0xfu;  // what the wave will find in the owner map, when a static table has said so (else 0xF: look)
     if (L0 && NPL == 3 && ((lvl >> 8) & 15) == 4) {
         // XCD bands with the seam tiles first (shape 4, level 0): the band of XCD k is walked in the order of the static table
         // CanvasParams::order0 - tiles that hold a wave without a single owner (the general path: four times the instructions,
@@ -471,9 +482,11 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         if (cvi >= (unsigned)CS.n) return;
         const CanvasParams& Cq = CS.c[cvi];
         if (jj >= (unsigned)Cq.order_per) return;
-        const unsigned tile = Cq.order0[k * Cq.order_per + jj];
+        const unsigned ent = Cq.order0[k * Cq.order_per + jj];  // uniform: a scalar load
+        const unsigned tile = ent & 0xffffu;
         if (tile == 0xffffu) return;
         bxi = tile % (unsigned)Cq.order_gx; byi = tile / (unsigned)Cq.order_gx; bzi = cvi;
+        hint = (ent >> (16 + 4 * __builtin_amdgcn_readfirstlane(threadIdx.y))) & 0xfu;
     } else if (((lvl >> 8) & 15) == 3) {
         // XCD bands (shape 3, the default): a 1-D grid of 8 * per workgroups; the hardware deals consecutive ids round-robin
         // over the 8 XCDs, so XCD k is given the logical workgroups [k * per, (k + 1) * per) - a contiguous band of canvas
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     } else if (X0 >= cw || Y0 >= ch) {
         return;
     }
-    blend_block<L0, NPL>(P, C, l, X0, Y0, pb);
+    blend_block<L0, NPL>(P, C, l, X0, Y0, pb, hint);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -772,9 +785,11 @@ void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint16
     hipLaunchKernelGGL(build_owner_kernel, grid, block, 0, s, p, c, l, owner);
 }
 
-// which 128 x 16-pixel workgroup tiles of level 0 hold a wave that takes the general path (no single owner)?  One flag per tile,
-// the same lane -> block mapping as blend_level_vec_kernel's 2 x 2 shape over the hull of the cut
-__global__ __launch_bounds__(256) void tile_mixed_kernel(CanvasParams C, int gx, uint8_t* flags) {
+// What will the four waves of every 128 x 16-pixel workgroup tile of level 0 find in the owner map?  One nibble per wave
+// (wave = threadIdx.y of blend_level_vec_kernel's 2 x 2 shape over the hull of the cut): 0..7 = every block of the wave inside
+// the cut has that single owner, 0xE = none of them has an owner, 0xF = anything else (the wave has to look).  Static: it
+// follows the owner map and the cut.
+__global__ __launch_bounds__(256) void tile_mixed_kernel(CanvasParams C, int gx, uint16_t* flags) {
     const int bx0 = C.cut_x & ~3, by0 = C.cut_y & ~1;
     const int X0 = bx0 + ((blockIdx.x * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
     const int Y0 = by0 + ((blockIdx.y * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * 2;
@@ -782,15 +797,20 @@ __global__ __launch_bounds__(256) void tile_mixed_kernel(CanvasParams C, int gx,
     unsigned code = 0;
     if (valid) code = C.owner[0][(unsigned)(__mul24(Y0 >> 1, C.opitch[0]) + (X0 >> 2))] & 0xffu;
     const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
-    int mixed = 0;
+    unsigned nib = 0xEu;  // a wave with no block inside the cut does nothing at all
     if (vm) {
         const unsigned c0 = (unsigned)__shfl((int)code, __ffsll((long long)vm) - 1);
-        mixed = c0 == 0xffu || __builtin_amdgcn_ballot_w64(valid && code != c0) != 0;
+        const bool uniform = __builtin_amdgcn_ballot_w64(valid && code != c0) == 0;
+        nib = !uniform ? 0xFu : (c0 < 8u ? c0 : (c0 == 0xFEu ? 0xEu : 0xFu));
     }
-    mixed = __syncthreads_or(mixed);
-    if (threadIdx.x == 0 && threadIdx.y == 0) flags[blockIdx.y * gx + blockIdx.x] = (uint8_t)(mixed != 0);
+    __shared__ unsigned all;
+    if (threadIdx.x == 0 && threadIdx.y == 0) all = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicOr(&all, nib << (4 * threadIdx.y));
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) flags[blockIdx.y * gx + blockIdx.x] = (uint16_t)all;
 }
-void launch_tile_mixed(const CanvasParams& c, int gx, int gy, uint8_t* flags, hipStream_t s) {
+void launch_tile_mixed(const CanvasParams& c, int gx, int gy, uint16_t* flags, hipStream_t s) {
     hipLaunchKernelGGL(tile_mixed_kernel, dim3(gx, gy, 1), dim3(64, 4, 1), 0, s, c, gx, flags);
 }
 

@@ -99,8 +99,10 @@ struct CanvasParams {
     int small_merged;          // 1: the normalise and the collapse launch are ONE launch (collapse_small_kernel<true>)
     int small_fused;           // 1: ... and as ONE launch (small_fused_kernel) that also builds the camera levels above
                                // small_base itself: the per-frame pyrDown chain stops at level small_base
-    const uint16_t* order0;    // level 0, or nullptr: per XCD band (order_per entries each, 0xffff = none) the 128 x 16-pixel
-    int order_per, order_gx;   // workgroup tiles in the order they are dispatched - seam tiles first; tile = by * order_gx + bx
+    const uint32_t* order0;    // level 0, or nullptr: per XCD band (order_per entries each, low half 0xffff = none) the 128 x 16-pixel
+    int order_per, order_gx;   // workgroup tiles in the order they are dispatched - seam tiles first; tile = by * order_gx + bx;
+                               // high half: what the tile's four waves will find in the owner map, a nibble each (wave = threadIdx.y):
+                               // 0..7 the single owner of every block of the wave, 0xE no owner anywhere, 0xF look it up
     const uint8_t* small_live; // small_fused: per 64 x 16 tile of level small_base, the cameras with weight on its footprint
     int cam_lo, cam_n;         // this canvas blends cameras [cam_lo, cam_lo + cam_n) of the PyrParams it is launched with
     int w0, h0;                // padded canvas size
@@ -176,8 +178,8 @@ void launch_small_live(const PyrParams& p, const CanvasParams& c, uint8_t* table
 inline size_t small_live_bytes(const CanvasParams& c) {
     return (size_t)(((c.w0 >> c.small_base) + 63) / 64) * (((c.h0 >> c.small_base) + 15) / 16);  // 64 x 16 tiles
 }
-// per 128 x 16-pixel tile of level 0 (gx x gy of them over the hull of the cut): does it hold a wave with no single owner?
-void launch_tile_mixed(const CanvasParams& c, int gx, int gy, uint8_t* flags, hipStream_t s);
+// per 128 x 16-pixel tile of level 0 (gx x gy of them over the hull of the cut): the owner nibbles of its four waves (0xF: no single owner)
+void launch_tile_mixed(const CanvasParams& c, int gx, int gy, uint16_t* flags, hipStream_t s);
 // owner map of a vector level (run when masks change)
 void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint16_t* owner, hipStream_t s);
 // Blender::NO path
