@@ -94,6 +94,7 @@ struct pano_ctx {
     size_t order_cap = 0;
     bool order_dirty = false;
     bool l0_order = true;            // PANO_L0_ORDER=0: plain band order
+    bool l0_hints = true;            // PANO_L0_HINTS=0: the order table carries no owner codes (every wave looks its owners up)
     float* wsum[kMaxLevels] = {};
     int16_t* canvas[kMaxLevels] = {};
 
@@ -534,7 +535,7 @@ pano_status build_tile_order(pano_ctx* c, hipStream_t s) {
     if (fe == hipSuccess) fe = hipStreamSynchronize(s);
     (void)hipFree(d_flags);
     HIP_TRY(c, fe);
-    const bool hints = !(getenv("PANO_L0_HINTS") && atoi(getenv("PANO_L0_HINTS")) == 0);  // 0: every wave looks its owners up
+    const bool hints = c->l0_hints;
     auto mixed = [](uint16_t f) { return (f & 0xf) == 0xf || ((f >> 4) & 0xf) == 0xf || ((f >> 8) & 0xf) == 0xf || (f >> 12) == 0xf; };
     std::vector<uint32_t> order(8 * per, 0xffffu);
     for (size_t k = 0; k < 8; k++) {
@@ -1264,6 +1265,7 @@ static pano_status prepare_impl(pano_ctx* c) {
     if (getenv("PANO_PYR_HEAD_TS")) c->pyr_tail.head_ts = atoi(getenv("PANO_PYR_HEAD_TS")) == 64 ? 64 : 32;
     // launch-shape knobs of the blend (A/B levers of DESIGN.md section 6/8; none changes a result)
     c->l0_order = !(getenv("PANO_L0_ORDER") && atoi(getenv("PANO_L0_ORDER")) == 0);
+    c->l0_hints = !(getenv("PANO_L0_HINTS") && atoi(getenv("PANO_L0_HINTS")) == 0);
     c->cv.k3_shape = getenv("PANO_K3_SHAPE") ? atoi(getenv("PANO_K3_SHAPE")) & 3 : 3;
     c->cv.blend_split = !(getenv("PANO_BLEND_PLANES") && atoi(getenv("PANO_BLEND_PLANES")) == 0);
     c->cv.l0_strips = getenv("PANO_L0_STRIPS") ? atoi(getenv("PANO_L0_STRIPS")) : 0;
