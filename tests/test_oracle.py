@@ -102,6 +102,26 @@ def test_pyramids_known_answers_and_numpy(po):
     assert np.array_equal(po.pyr_down_32f(w), npo.pyr_down_32f(w))
 
 
+def test_pyramids_vs_scipy(po):
+    """a third, library-made statement of the two filters: cv::pyrDown = the separable [1 4 6 4 1] correlation with
+    BORDER_REFLECT_101 (scipy 'mirror') sampled at the even positions, (v + 128) >> 8; cv::pyrUp (away from the right / bottom
+    edge, which OpenCV replicates) = zero-stuffing, the same kernel, (v + 32) >> 6"""
+    from scipy import ndimage
+    rng = np.random.default_rng(11)
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    for shape in ((16, 24), (9, 7), (32, 10)):
+        x = rng.integers(-3000, 3000, size=shape).astype(np.int16)
+        full = ndimage.correlate1d(ndimage.correlate1d(x.astype(np.int64), k, axis=0, mode="mirror"), k, axis=1, mode="mirror")
+        assert np.array_equal(po.pyr_down_16s(x), ((full[::2, ::2] + 128) >> 8).astype(np.int16))
+        z = np.zeros((2 * shape[0], 2 * shape[1]), np.int64)
+        z[::2, ::2] = x
+        up = ndimage.correlate1d(ndimage.correlate1d(z, k, axis=0, mode="mirror"), k, axis=1, mode="mirror")
+        got = po.pyr_up_16s(x)
+        # zero-stuffing + 'mirror' reproduces OpenCV's reflect-101 at the left / top edge; the last two rows / columns are
+        # OpenCV's replicated ones (pinned by the known answers above)
+        assert np.array_equal(got[:-2, :-2], ((up[:-2, :-2] + 32) >> 6).astype(np.int16))
+
+
 def test_blender_vs_numpy(po, c1):
     import np_oracle as npo
     rois, warped = [], []
