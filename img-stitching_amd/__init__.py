@@ -87,7 +87,7 @@ EXPORTS = [
     "pano_create", "pano_destroy", "pano_last_error", "pano_version", "pano_set_camera",
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_get_camera", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
-    "pano_build_masks_voronoi", "pano_build_masks_graphcut", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
+    "pano_build_masks_voronoi", "pano_build_masks_graphcut", "pano_refresh_masks_begin", "pano_refresh_masks_poll", "pano_refresh_masks_wait", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
     "pano_compose_host", "pano_host_alloc", "pano_host_free", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_feed_cameras_host", "pano_blend_host", "pano_rccl_unique_id", "pano_rccl_comm_create", "pano_rccl_comm_destroy", "pano_gather_slots", "pano_stack_master", "pano_stack_finalcut", "pano_stack_master_host", "pano_stack_finalcut_host", "pano_stream_input", "pano_stream_output",
     "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
     "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_get_live_rect", "pano_get_live_gap", "pano_get_warp_table_stats", "pano_debug_get_level", "pano_debug_get_weights",
@@ -228,6 +228,23 @@ class Context:
         ptrs = (C.c_void_p * self.n)(*[f.ctypes.data for f in frames])
         strides = (C.c_size_t * self.n)(*[f.strides[0] for f in frames])
         self._ck(self.lib.pano_build_masks_graphcut(self.h, ptrs, strides))
+
+    def refresh_masks_begin(self, frames):
+        """updateMask beside the frame loop (pano_refresh_masks_begin): the frames are consumed before this returns"""
+        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        assert len(frames) == self.n
+        ptrs = (C.c_void_p * self.n)(*[f.ctypes.data for f in frames])
+        strides = (C.c_size_t * self.n)(*[f.strides[0] for f in frames])
+        self._ck(self.lib.pano_refresh_masks_begin(self.h, ptrs, strides))
+
+    def refresh_masks_poll(self):
+        """True the one time the refreshed masks get installed"""
+        done = C.c_int(0)
+        self._ck(self.lib.pano_refresh_masks_poll(self.h, C.byref(done)))
+        return bool(done.value)
+
+    def refresh_masks_wait(self):
+        self._ck(self.lib.pano_refresh_masks_wait(self.h))
 
     def get_mask(self, i):
         r = self.roi(i)

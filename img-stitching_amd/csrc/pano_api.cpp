@@ -20,6 +20,8 @@
 #include <stdexcept>
 #include <sstream>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "pano_graphcut.hpp"
@@ -40,6 +42,8 @@ struct DevBuf {
 };
 
 }  // namespace
+
+struct MaskJob;  // a graph-cut mask refresh running beside the frame loop (pano_refresh_masks_*)
 
 struct pano_ctx {
     pano_config cfg{};
@@ -169,6 +173,8 @@ struct pano_ctx {
     };
     std::vector<GraphEntry> graphs;
     bool use_graph = false;
+
+    MaskJob* job = nullptr;
 
     std::string err;
 };
@@ -909,6 +915,7 @@ static pano_status create_impl(const pano_config* cfg, pano_ctx** out) {
     return PANO_OK;
 }
 
+static void drop_job(pano_ctx* c);
 void pano_destroy(pano_ctx* ctx) {
     if (!ctx) return;
     if (ctx->host_trace_n)
@@ -917,6 +924,7 @@ void pano_destroy(pano_ctx* ctx) {
                 ctx->host_trace[2] / ctx->host_trace_n, ctx->host_trace[3] / ctx->host_trace_n, ctx->host_trace[4] / ctx->host_trace_n);
     if (ctx->device >= 0 && ctx->prepared) {
         (void)hipSetDevice(ctx->device);
+        drop_job(ctx);
         (void)hipDeviceSynchronize();
         free_device(ctx);
     }
@@ -1441,21 +1449,20 @@ static pano_status build_masks_voronoi_impl(pano_ctx* c) {
     return finish_seam_masks(c, sm, tmp, s);
 }
 
-static pano_status build_masks_graphcut_impl(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides) {
-    pano_status st = check_compute(c);
-    if (st != PANO_OK) return st;
-    if (!h_frames || !strides) return PANO_EINVAL;
-    const int n = c->plan.n;
-    for (int i = 0; i < n; i++)
-        if (!h_frames[i] || strides[i] < (size_t)c->plan.src_w * 3) return fail(c, PANO_EINVAL, "frame pointer / stride");
-    hipStream_t s = c->own_stream;
-    Scratch tmp;
-    SeamWarps sm;
-    if ((st = seam_scale_warps(c, h_frames, strides, tmp, s, sm)) != PANO_OK) return st;
+// GraphCutSeamFinder over the seam-scale warps `sm` (PairwiseSeamFinder::run order; GraphCutSeamFinder::Impl::findInPair per
+// overlapping pair: weights on the GPU, the max-flow on the host - pano_graphcut.hpp -, the mask update on the GPU; a later pair
+// sees the masks the earlier left).  Touches nothing of a context: it also runs on the refresh thread (pano_refresh_masks_begin)
+static pano_status graphcut_pairs(int n, SeamWarps& sm, Scratch& tmp, hipStream_t s, std::string& err) {
+#define GC_TRY(expr)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            err = std::string(#expr) + ": " + hipGetErrorString(e_);              \
+            return PANO_EHIP;                                                     \
+        }                                                                         \
+    } while (0)
     GainImages gi{};
     for (int i = 0; i < n; i++) { gi.img[i] = sm.img[i]; gi.mask[i] = sm.mask[i]; gi.w[i] = sm.roi[i].w; }
-    // PairwiseSeamFinder::run order; GraphCutSeamFinder::Impl::findInPair per overlapping pair: weights on the GPU, the
-    // max-flow on the host (pano_graphcut.hpp), the mask update on the GPU - a later pair sees the masks the earlier left
     const int gap = 10;
     std::vector<float> term, wh, wv;
     std::vector<uint8_t> in_source;
@@ -1473,22 +1480,121 @@ static pano_status build_masks_graphcut_impl(pano_ctx* c, const uint8_t* const* 
             float *d_term = nullptr, *d_wh = nullptr, *d_wv = nullptr;
             uint8_t* d_lab = nullptr;
             if (!tmp.alloc(&d_term, nv * sizeof(float)) || !tmp.alloc(&d_wh, nv * sizeof(float)) || !tmp.alloc(&d_wv, nv * sizeof(float)) ||
-                !tmp.alloc(&d_lab, nv))
-                return fail(c, PANO_EHIP, "hipMalloc (graph cut)");
+                !tmp.alloc(&d_lab, nv)) {
+                err = "hipMalloc (graph cut)";
+                return PANO_EHIP;
+            }
             launch_graphcut_weights(gi, q, d_term, d_wh, d_wv, s);
-            HIP_TRY(c, hipGetLastError());
+            GC_TRY(hipGetLastError());
             term.resize(nv); wh.resize(nv); wv.resize(nv); in_source.resize(nv);
-            HIP_TRY(c, hipMemcpyAsync(term.data(), d_term, nv * sizeof(float), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipMemcpyAsync(wh.data(), d_wh, nv * sizeof(float), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipMemcpyAsync(wv.data(), d_wv, nv * sizeof(float), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
+            GC_TRY(hipMemcpyAsync(term.data(), d_term, nv * sizeof(float), hipMemcpyDeviceToHost, s));
+            GC_TRY(hipMemcpyAsync(wh.data(), d_wh, nv * sizeof(float), hipMemcpyDeviceToHost, s));
+            GC_TRY(hipMemcpyAsync(wv.data(), d_wv, nv * sizeof(float), hipMemcpyDeviceToHost, s));
+            GC_TRY(hipStreamSynchronize(s));
             GridMaxFlow flow(q.W, q.H, term.data(), wh.data(), wv.data());
             flow.run();
             for (size_t k = 0; k < nv; k++) in_source[k] = flow.inSource((int)k) ? 1 : 0;
-            HIP_TRY(c, hipMemcpyAsync(d_lab, in_source.data(), nv, hipMemcpyHostToDevice, s));
+            GC_TRY(hipMemcpyAsync(d_lab, in_source.data(), nv, hipMemcpyHostToDevice, s));
             launch_graphcut_apply(q, sm.mask[i], sm.mask[j], d_lab, gap, s);
-            HIP_TRY(c, hipStreamSynchronize(s));  // in_source is reused by the next pair
+            GC_TRY(hipStreamSynchronize(s));  // in_source is reused by the next pair
         }
+#undef GC_TRY
+    return PANO_OK;
+}
+
+// pano_refresh_masks_*: updateMask beside the frame loop.  begin() uploads the frames and warps them at the seam scale (a few ms
+// on a stream of the job's own), then a thread runs the graph cuts (the host max-flow: tens of ms); poll() installs the masks
+// once the thread is through - on the caller's thread, like pano_build_masks_graphcut does at its end
+struct MaskJob {
+    std::thread th;
+    std::atomic<int> state{0};  // 1 running, 2 masks ready, 3 failed
+    Scratch tmp;
+    SeamWarps sm;
+    hipStream_t s = nullptr;
+    pano_status st = PANO_OK;
+    std::string err;
+};
+static void drop_job(pano_ctx* c) {
+    MaskJob* j = c->job;
+    if (!j) return;
+    if (j->th.joinable()) j->th.join();
+    if (j->s) (void)hipStreamDestroy(j->s);
+    c->job = nullptr;
+    delete j;  // frees the job's device scratch
+}
+static pano_status refresh_begin_impl(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (!h_frames || !strides) return PANO_EINVAL;
+    const int n = c->plan.n;
+    for (int i = 0; i < n; i++)
+        if (!h_frames[i] || strides[i] < (size_t)c->plan.src_w * 3) return fail(c, PANO_EINVAL, "frame pointer / stride");
+    if (c->job) return fail(c, PANO_ESTATE, "a mask refresh is under way: pano_refresh_masks_poll / _wait first");
+    MaskJob* j = new MaskJob;
+    c->job = j;
+    if (hipStreamCreateWithFlags(&j->s, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        drop_job(c);
+        return fail(c, PANO_EHIP, "hipStreamCreate (mask refresh)");
+    }
+    if ((st = seam_scale_warps(c, h_frames, strides, j->tmp, j->s, j->sm)) == PANO_OK && hipStreamSynchronize(j->s) != hipSuccess)
+        st = fail(c, PANO_EHIP, "hipStreamSynchronize (mask refresh)");
+    if (st != PANO_OK) {  // the caller's frames are no longer needed either way
+        drop_job(c);
+        return st;
+    }
+    j->state = 1;
+    const int device = c->device;
+    j->th = std::thread([j, n, device]() {
+        pano_status r = PANO_EHIP;
+        try {
+            if (hipSetDevice(device) == hipSuccess) r = graphcut_pairs(n, j->sm, j->tmp, j->s, j->err);
+            else j->err = "hipSetDevice (mask refresh thread)";
+        } catch (const std::exception& e) {
+            r = PANO_ERR;
+            j->err = e.what();
+        } catch (...) {
+            r = PANO_ERR;
+            j->err = "unknown exception (mask refresh thread)";
+        }
+        j->st = r;
+        j->state = r == PANO_OK ? 2 : 3;
+    });
+    return PANO_OK;
+}
+static pano_status refresh_poll_impl(pano_ctx* c, int* done, bool wait) {
+    if (done) *done = 0;
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    MaskJob* j = c->job;
+    if (!j) return PANO_OK;
+    if (j->state == 1 && !wait) return PANO_OK;
+    if (j->th.joinable()) j->th.join();
+    if (j->state == 3) {
+        st = fail(c, j->st, j->err.c_str());
+        drop_job(c);
+        return st;
+    }
+    st = finish_seam_masks(c, j->sm, j->tmp, c->own_stream);
+    drop_job(c);
+    if (st == PANO_OK && done) *done = 1;
+    return st;
+}
+
+static pano_status build_masks_graphcut_impl(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (!h_frames || !strides) return PANO_EINVAL;
+    if (c->job && (st = refresh_poll_impl(c, nullptr, true)) != PANO_OK) return st;  // a refresh under way ends first
+    const int n = c->plan.n;
+    for (int i = 0; i < n; i++)
+        if (!h_frames[i] || strides[i] < (size_t)c->plan.src_w * 3) return fail(c, PANO_EINVAL, "frame pointer / stride");
+    hipStream_t s = c->own_stream;
+    Scratch tmp;
+    SeamWarps sm;
+    if ((st = seam_scale_warps(c, h_frames, strides, tmp, s, sm)) != PANO_OK) return st;
+    std::string err;
+    if ((st = graphcut_pairs(n, sm, tmp, s, err)) != PANO_OK) return fail(c, st, err.c_str());
     return finish_seam_masks(c, sm, tmp, s);
 }
 
@@ -2570,6 +2676,15 @@ pano_status pano_build_masks_voronoi(pano_ctx* c) {
     return guarded(c, [&]() { return build_masks_voronoi_impl(c); });
 }
 
+pano_status pano_refresh_masks_begin(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides) {
+    return guarded(c, [&] { return refresh_begin_impl(c, h_frames, strides); });
+}
+pano_status pano_refresh_masks_poll(pano_ctx* c, int* done) {
+    return guarded(c, [&] { return refresh_poll_impl(c, done, false); });
+}
+pano_status pano_refresh_masks_wait(pano_ctx* c) {
+    return guarded(c, [&] { return refresh_poll_impl(c, nullptr, true); });
+}
 pano_status pano_build_masks_graphcut(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides) {
     return guarded(c, [&]() { return build_masks_graphcut_impl(c, h_frames, strides); });
 }

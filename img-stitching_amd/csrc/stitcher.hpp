@@ -169,6 +169,8 @@ class Stitcher {
     int projector = PANO_SPHERICAL;   // reference: SphericalWarperGpu (ocvstitcher.hpp:1000)
     int device = 0;
     int maskRefreshPeriod = 200;      // process() refreshes the masks every 200 calls (ocvstitcher.hpp:1152)
+    bool asyncMaskRefresh = false;    // ... beside the frame loop (pano_refresh_masks_*) instead of inside process(): the frame
+                                      // that triggers it and its successors are composed with the old masks until the cuts are done
     // seam finder of initSeam / updateMask: the reference creates GraphCutSeamFinder(COST_COLOR) (ocvstitcher.hpp:1033,
     // :860) and has NoSeamFinder commented beside it; the one-shot twin also offers Voronoi (stitching_detailed.cpp:728)
     enum SeamFinder { SeamGraphCut = 0, SeamVoronoi = 1 };
@@ -259,9 +261,16 @@ class Stitcher {
         status_ = PANO_OK;
         if (!ctx_) { status_ = PANO_ESTATE; ret.release(); return; }
         if (!borrow(imgs, frames, strides)) { status_ = PANO_EINVAL; ret.release(); return; }  // count, size, null data
+        if (refreshing_) {  // a refresh started on an earlier frame: its masks go in as soon as its thread is through
+            int done = 0;
+            if (pano_refresh_masks_poll(ctx_, &done) != PANO_OK || done) refreshing_ = false;
+        }
         if (maskRefreshPeriod > 0 && ++frame_ > maskRefreshPeriod) {  // updateMask cadence (:1152-1159)
             frame_ = 0;
-            if (buildMasks(imgs) != RET_OK) { status_ = PANO_ERR; ret.release(); return; }
+            if (asyncMaskRefresh && seamFinder == SeamGraphCut) {
+                // beside the frame loop: the reference's inline updateMask costs several frame periods at 60 fps
+                if (!refreshing_ && pano_refresh_masks_begin(ctx_, frames, strides) == PANO_OK) refreshing_ = true;
+            } else if (buildMasks(imgs) != RET_OK) { status_ = PANO_ERR; ret.release(); return; }
         }
         int w = 0, h = 0;
         if ((status_ = pano_get_output_size(ctx_, &w, &h)) != PANO_OK) { ret.release(); return; }
@@ -298,6 +307,7 @@ class Stitcher {
     std::string defaultCamParams_;
     std::vector<int> cut_;
     int frame_ = 0;
+    bool refreshing_ = false;
     pano_status status_ = PANO_OK;
 };
 

@@ -121,6 +121,17 @@ pano_status pano_build_masks_voronoi(pano_ctx* ctx);
  * Boykov-Kolmogorov max-flow (sequential by construction; csrc/pano_graphcut.hpp), the GPU applies the labels; then dilate
  * 3x3, resize INTER_LINEAR_EXACT, AND as in pano_build_masks_voronoi. */
 pano_status pano_build_masks_graphcut(pano_ctx* ctx, const uint8_t* const* h_frames, const size_t* strides);
+/* The same refresh BESIDE the frame loop.  ocvStitcher::process runs updateMask inline every 200 frames
+ * (ocvstitcher.hpp:1152-1159), and the graph cuts cost several frame periods (77 ms for four 1080p cameras: the host
+ * max-flow) - a capture loop at 60 fps loses frames there.  pano_refresh_masks_begin uploads the frames and warps them at
+ * the seam scale on a stream of its own (a few ms; the caller's buffers are free again when it returns) and hands the graph
+ * cuts to a thread of the library; pano_refresh_masks_poll returns at once and, the first time it finds the thread through,
+ * installs the masks (*done = 1; the weights are rebuilt with the next frame, exactly as after pano_build_masks_graphcut:
+ * same masks, bit for bit); pano_refresh_masks_wait blocks until then.  One refresh at a time (PANO_ESTATE otherwise);
+ * pano_build_masks_graphcut and pano_destroy wait for a refresh under way.  Call all three from the thread that composes. */
+pano_status pano_refresh_masks_begin(pano_ctx* ctx, const uint8_t* const* h_frames, const size_t* strides);
+pano_status pano_refresh_masks_poll(pano_ctx* ctx, int* done);
+pano_status pano_refresh_masks_wait(pano_ctx* ctx);
 pano_status pano_get_mask(pano_ctx* ctx, int i, uint8_t* h_mask, size_t stride);
 
 /* ---- fused undistort front end (reference include/nvcam.hpp:823-833, :898-921, :1094) ----------------------

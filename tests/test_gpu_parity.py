@@ -916,6 +916,45 @@ def test_mask_refresh_with_frames_in_flight(pano, po, torch):
         assert np.array_equal(outs[k].cpu().numpy(), want), k
 
 
+def test_mask_refresh_beside_the_frame_loop(pano, po, torch):
+    """pano_refresh_masks_*: the graph cuts run on a thread of the library while frames keep being composed; frames composed
+    before the masks are installed equal the oracle under the old masks, frames after it under the graph-cut masks - the same
+    masks pano_build_masks_graphcut gives; one refresh at a time; a refresh under way ends before pano_destroy"""
+    d = c2_group(w=960, h=540, f=501.0)
+    n = d["n"]
+    ctx = make_ctx(pano, d, 0, num_bands=4)
+    ctx.build_masks_voronoi()
+    vor = [ctx.get_mask(i) for i in range(n)]
+    frames = [[synth_frame(d["w"], d["h"], 900 + 10 * k + i) for i in range(n)] for k in range(3)]
+    gc_masks = po.prepare_masks_graphcut(frames[0], d["K"], d["R"], d["scale"])
+    ctx.refresh_masks_begin(frames[0])
+    with pytest.raises(Exception):
+        ctx.refresh_masks_begin(frames[0])          # one at a time
+    frames[0][0][:] = 0                              # the caller's buffers are its own again after begin()
+    before = []
+    installed = False
+    for k in range(400):                             # the frame loop goes on; poll() never blocks
+        if ctx.refresh_masks_poll():
+            installed = True
+            break
+        before.append(ctx.compose_host(frames[1]))
+    if not installed:
+        ctx.refresh_masks_wait()
+    assert all(np.array_equal(ctx.get_mask(i), gc_masks[i]) for i in range(n))
+    want_old, _ = po.compose(frames[1], d["K"], d["R"], d["scale"], vor, 4)
+    assert all(np.array_equal(b, want_old) for b in before[:3])
+    want_new, _ = po.compose(frames[2], d["K"], d["R"], d["scale"], gc_masks, 4)
+    assert np.array_equal(ctx.compose_host(frames[2]), want_new)
+    assert not ctx.refresh_masks_poll()              # nothing under way: not an error
+    # the synchronous entry waits for a refresh under way and then does its own
+    ctx.refresh_masks_begin(frames[2])
+    ctx.build_masks_graphcut(frames[1])
+    gc1 = po.prepare_masks_graphcut(frames[1], d["K"], d["R"], d["scale"])
+    assert all(np.array_equal(ctx.get_mask(i), gc1[i]) for i in range(n))
+    ctx.refresh_masks_begin(frames[2])               # left running: destroying the context joins it
+    ctx.close()
+
+
 def test_bench_shape_bit_exact(pano, po, torch):
     """the exact launch shape bench.py times (config 2): pano_compose_pair over 2 x 4 x 1080p, 5 bands, Voronoi seams,
     pano_set_frame_slots(4) with step k in slot k % 4 on stream k % 4 - three distinct frame sets dealt over 12 steps in

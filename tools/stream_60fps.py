@@ -24,8 +24,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=False, device=0, pipeline=None):
-    """pipeline: True = wait for tick k's panorama after submitting tick k + 1 (two in flight, what throughput needs), False = wait
+def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=False, device=0, pipeline=None, refresh_every=0,
+        refresh_async=True):
+    """refresh_every: N > 0 refreshes the graph-cut masks of both stitchers every N ticks like ocvStitcher::process (every 200
+    frames, ocvstitcher.hpp:1152-1159) - inline (refresh_async False: pano_build_masks_graphcut inside the tick, as the reference
+    does) or beside the loop (pano_refresh_masks_begin / _poll).
+    pipeline: True = wait for tick k's panorama after submitting tick k + 1 (two in flight, what throughput needs), False = wait
     right after the submit (lowest latency); None = False when a period leaves room for it (fps <= 100)"""
     if pipeline is None:
         pipeline = fps > 100.0
@@ -49,6 +53,7 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
     sample = {}
     dropped = 0
     pending = None   # (frame index, slot)
+    refreshed = [0]
 
     def finish(p):
         k, s = p
@@ -80,6 +85,16 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
             now = time.perf_counter()
         tick_t[k] = target
         fs = sets[k % nsets]
+        if refresh_every:
+            for grp in range(NG):
+                if refresh_async:
+                    if ctxs[grp].refresh_masks_poll():
+                        refreshed[0] += 1
+                    if k and k % refresh_every == 0:
+                        ctxs[grp].refresh_masks_begin(fs[grp])
+                elif k and k % refresh_every == 0:
+                    ctxs[grp].build_masks_graphcut(fs[grp])
+                    refreshed[0] += 1
         for grp in range(NG):
             for i in range(NC):
                 ins[slot][grp][i][:] = fs[grp][i]          # the capture thread's write into the slot
@@ -95,6 +110,9 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
     if pending is not None:
         finish(pending)
     t_end = time.perf_counter()
+    if refresh_every and refresh_async:
+        for grp in range(NG):
+            ctxs[grp].refresh_masks_wait()
     lat = np.array([done_t[k] - tick_t[k] for k in sorted(done_t)]) * 1e3
     out = {"config": "C5: %d x %dx%d -> 2 panoramas, %d bands, paced at %.1f fps, %d frames, pano_stream_* (2 slots)%s" %
                      (NG * NC, width, height, bands, fps, frames, ", hipGraph replay" if os.environ.get("PANO_GRAPH") == "1" else ""),
@@ -103,6 +121,9 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
            "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 3), "p99": round(float(np.percentile(lat, 99)), 3),
                           "max": round(float(lat.max()), 3)},
            "pipelined": bool(pipeline),
+           "mask_refresh": None if not refresh_every else {"every_ticks": refresh_every, "how": "beside the loop (pano_refresh_masks_*)" if refresh_async else
+                                                            "inline (pano_build_masks_graphcut inside the tick, as ocvStitcher::process does)",
+                                                            "masks_installed": refreshed[0]},
            "latency_definition": "frame tick (frames in host memory) -> panorama in host memory, including the write of the 8 frames "
                                  "into the page-locked slot" + (" and one tick of pipelining (the wait happens after the next submit)" if pipeline else "")}
     if check:
@@ -129,10 +150,13 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bands", type=int, default=5)
     ap.add_argument("--check", action="store_true", help="compare two sampled panoramas with the CPU oracle")
+    ap.add_argument("--refresh-every", type=int, default=0, help="refresh the graph-cut masks every N ticks (the reference: 200)")
+    ap.add_argument("--refresh-inline", action="store_true", help="... inside the tick like the reference, instead of beside the loop")
     ap.add_argument("--pipeline", type=int, default=-1, help="1: two panoramas in flight, 0: wait after every submit, -1: by fps")
     a = ap.parse_args()
     print(json.dumps(run(a.fps, a.frames, a.width, a.height, a.bands, check=a.check,
-                         pipeline=None if a.pipeline < 0 else bool(a.pipeline))), flush=True)
+                         pipeline=None if a.pipeline < 0 else bool(a.pipeline), refresh_every=a.refresh_every,
+                         refresh_async=not a.refresh_inline)), flush=True)
 
 
 if __name__ == "__main__":
