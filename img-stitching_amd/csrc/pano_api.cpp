@@ -175,6 +175,7 @@ struct pano_ctx {
     bool use_graph = false;
 
     MaskJob* job = nullptr;
+    MaskJob* job_trash = nullptr;  // a finished refresh whose device scratch is being freed on a thread of its own
 
     std::string err;
 };
@@ -708,8 +709,10 @@ void linearExactCoeffs(int ssize, int dsize, double inv_scale, std::vector<int>&
 // device allocations that live for one init-time call
 struct Scratch {
     std::vector<void*> p;
-    ~Scratch() {
+    ~Scratch() { release(); }
+    void release() {
         for (void* q : p) (void)hipFree(q);
+        p.clear();
     }
     template <typename T>
     bool alloc(T** d, size_t bytes) {
@@ -1514,13 +1517,36 @@ struct MaskJob {
     pano_status st = PANO_OK;
     std::string err;
 };
+static void reap_trash(pano_ctx* c) {
+    MaskJob* j = c->job_trash;
+    if (!j) return;
+    if (j->th.joinable()) j->th.join();
+    c->job_trash = nullptr;
+    delete j;
+}
 static void drop_job(pano_ctx* c) {
+    reap_trash(c);
     MaskJob* j = c->job;
     if (!j) return;
     if (j->th.joinable()) j->th.join();
     if (j->s) (void)hipStreamDestroy(j->s);
     c->job = nullptr;
     delete j;  // frees the job's device scratch
+}
+// the masks are installed: the job's few dozen device buffers go back on a thread of their own (every hipFree waits for the
+// device, which the frame loop has better things to do with)
+static void retire_job(pano_ctx* c) {
+    reap_trash(c);
+    MaskJob* j = c->job;
+    c->job = nullptr;
+    c->job_trash = j;
+    const int device = c->device;
+    j->th = std::thread([j, device]() {
+        (void)hipSetDevice(device);
+        j->tmp.release();
+        if (j->s) (void)hipStreamDestroy(j->s);
+        j->s = nullptr;
+    });
 }
 static pano_status refresh_begin_impl(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides) {
     pano_status st = check_compute(c);
@@ -1530,6 +1556,7 @@ static pano_status refresh_begin_impl(pano_ctx* c, const uint8_t* const* h_frame
     for (int i = 0; i < n; i++)
         if (!h_frames[i] || strides[i] < (size_t)c->plan.src_w * 3) return fail(c, PANO_EINVAL, "frame pointer / stride");
     if (c->job) return fail(c, PANO_ESTATE, "a mask refresh is under way: pano_refresh_masks_poll / _wait first");
+    reap_trash(c);
     MaskJob* j = new MaskJob;
     c->job = j;
     if (hipStreamCreateWithFlags(&j->s, hipStreamNonBlocking) != hipSuccess) {
@@ -1548,7 +1575,10 @@ static pano_status refresh_begin_impl(pano_ctx* c, const uint8_t* const* h_frame
     j->th = std::thread([j, n, device]() {
         pano_status r = PANO_EHIP;
         try {
-            if (hipSetDevice(device) == hipSuccess) r = graphcut_pairs(n, j->sm, j->tmp, j->s, j->err);
+            if (hipSetDevice(device) == hipSuccess) {
+                Scratch pairs;  // the graphs of the pairs: freed here, on this thread
+                r = graphcut_pairs(n, j->sm, pairs, j->s, j->err);
+            }
             else j->err = "hipSetDevice (mask refresh thread)";
         } catch (const std::exception& e) {
             r = PANO_ERR;
@@ -1576,7 +1606,7 @@ static pano_status refresh_poll_impl(pano_ctx* c, int* done, bool wait) {
         return st;
     }
     st = finish_seam_masks(c, j->sm, j->tmp, c->own_stream);
-    drop_job(c);
+    retire_job(c);
     if (st == PANO_OK && done) *done = 1;
     return st;
 }

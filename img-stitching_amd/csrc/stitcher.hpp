@@ -265,17 +265,18 @@ class Stitcher {
             int done = 0;
             if (pano_refresh_masks_poll(ctx_, &done) != PANO_OK || done) refreshing_ = false;
         }
+        bool begin = false;
         if (maskRefreshPeriod > 0 && ++frame_ > maskRefreshPeriod) {  // updateMask cadence (:1152-1159)
             frame_ = 0;
-            if (asyncMaskRefresh && seamFinder == SeamGraphCut) {
-                // beside the frame loop: the reference's inline updateMask costs several frame periods at 60 fps
-                if (!refreshing_ && pano_refresh_masks_begin(ctx_, frames, strides) == PANO_OK) refreshing_ = true;
-            } else if (buildMasks(imgs) != RET_OK) { status_ = PANO_ERR; ret.release(); return; }
+            if (asyncMaskRefresh && seamFinder == SeamGraphCut) begin = !refreshing_;
+            else if (buildMasks(imgs) != RET_OK) { status_ = PANO_ERR; ret.release(); return; }
         }
         int w = 0, h = 0;
         if ((status_ = pano_get_output_size(ctx_, &w, &h)) != PANO_OK) { ret.release(); return; }
         ret.create(h, w);
         if ((status_ = pano_compose_host(ctx_, frames, strides, ret.data, ret.step)) != PANO_OK) ret.release();
+        // beside the frame loop, and behind this frame's panorama: the reference's inline updateMask costs several frame periods
+        if (begin && pano_refresh_masks_begin(ctx_, frames, strides) == PANO_OK) refreshing_ = true;
     }
 
     pano_ctx* handle() { return ctx_; }

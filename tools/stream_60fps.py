@@ -85,14 +85,9 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
             now = time.perf_counter()
         tick_t[k] = target
         fs = sets[k % nsets]
-        if refresh_every:
+        if refresh_every and not refresh_async:
             for grp in range(NG):
-                if refresh_async:
-                    if ctxs[grp].refresh_masks_poll():
-                        refreshed[0] += 1
-                    if k and k % refresh_every == 0:
-                        ctxs[grp].refresh_masks_begin(fs[grp])
-                elif k and k % refresh_every == 0:
+                if k and k % refresh_every == 0:     # inside the tick, in front of the frame, like ocvStitcher::process
                     ctxs[grp].build_masks_graphcut(fs[grp])
                     refreshed[0] += 1
         for grp in range(NG):
@@ -100,6 +95,14 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
                 ins[slot][grp][i][:] = fs[grp][i]          # the capture thread's write into the slot
         for grp in range(NG):
             ctxs[grp].stream_submit(slot)
+        if refresh_every and refresh_async:
+            # behind the submit: the frame is on its way while the refresh's frames are uploaded and warped (begin) or its
+            # masks installed (poll); the two stitchers half a period apart
+            for grp in range(NG):
+                if ctxs[grp].refresh_masks_poll():
+                    refreshed[0] += 1
+                if k and k % refresh_every == (grp * refresh_every) // NG:
+                    ctxs[grp].refresh_masks_begin(fs[grp])
         if pipeline:
             if pending is not None:
                 finish(pending)
