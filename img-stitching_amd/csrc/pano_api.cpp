@@ -175,7 +175,8 @@ struct pano_ctx {
     bool use_graph = false;
 
     MaskJob* job = nullptr;
-    MaskJob* job_trash = nullptr;  // a finished refresh whose device scratch is being freed on a thread of its own
+    MaskJob* job_trash = nullptr;  // (unused since the pool: kept for a refresh that failed half way)
+    std::vector<std::pair<size_t, void*>> refresh_pool;  // device buffers of the last refresh, reused by the next (Scratch::pool)
 
     std::string err;
 };
@@ -223,6 +224,8 @@ void drop_graphs(pano_ctx* c) {
 
 void free_device(pano_ctx* c) {
     drop_graphs(c);
+    for (auto& q : c->refresh_pool) (void)hipFree(q.second);
+    c->refresh_pool.clear();
     // slot 0 owns what pyr_base / canvas[] were allocated as; the current slot may be another one
     if (c->nslots > 1) {
         c->pyr_base = c->slot_pyr[0];
@@ -706,19 +709,35 @@ void linearExactCoeffs(int ssize, int dsize, double inv_scale, std::vector<int>&
     if (mx < mn) mx = mn;
 }
 
-// device allocations that live for one init-time call
+// device allocations that live for one init-time call.  With a pool (pano_ctx::refresh_pool: the mask refresh beside the frame
+// loop, whose buffer sizes repeat from one refresh to the next) buffers come from it and go back to it instead of through
+// hipMalloc / hipFree - every hipFree waits for the device, and a few dozen hipMallocs are milliseconds of a 16.7 ms tick
 struct Scratch {
-    std::vector<void*> p;
+    typedef std::vector<std::pair<size_t, void*>> Pool;
+    std::vector<std::pair<size_t, void*>> p;
+    Pool* pool = nullptr;
     ~Scratch() { release(); }
     void release() {
-        for (void* q : p) (void)hipFree(q);
+        for (auto& q : p) {
+            if (pool) pool->push_back(q);
+            else (void)hipFree(q.second);
+        }
         p.clear();
     }
     template <typename T>
     bool alloc(T** d, size_t bytes) {
         *d = nullptr;
-        if (hipMalloc((void**)d, bytes ? bytes : 16) != hipSuccess) return false;
-        p.push_back(*d);
+        if (!bytes) bytes = 16;
+        if (pool)
+            for (size_t k = 0; k < pool->size(); k++)
+                if ((*pool)[k].first == bytes) {
+                    *d = (T*)(*pool)[k].second;
+                    p.push_back((*pool)[k]);
+                    pool->erase(pool->begin() + (long)k);
+                    return true;
+                }
+        if (hipMalloc((void**)d, bytes) != hipSuccess) return false;
+        p.push_back({bytes, (void*)*d});
         return true;
     }
     template <typename T>
@@ -1533,20 +1552,14 @@ static void drop_job(pano_ctx* c) {
     c->job = nullptr;
     delete j;  // frees the job's device scratch
 }
-// the masks are installed: the job's few dozen device buffers go back on a thread of their own (every hipFree waits for the
-// device, which the frame loop has better things to do with)
+// the masks are installed: the job's device buffers go back to the context's pool (the next refresh asks for the same sizes)
 static void retire_job(pano_ctx* c) {
     reap_trash(c);
     MaskJob* j = c->job;
     c->job = nullptr;
-    c->job_trash = j;
-    const int device = c->device;
-    j->th = std::thread([j, device]() {
-        (void)hipSetDevice(device);
-        j->tmp.release();
-        if (j->s) (void)hipStreamDestroy(j->s);
-        j->s = nullptr;
-    });
+    j->tmp.release();  // pooled: no hipFree
+    if (j->s) (void)hipStreamDestroy(j->s);
+    delete j;
 }
 static pano_status refresh_begin_impl(pano_ctx* c, const uint8_t* const* h_frames, const size_t* strides) {
     pano_status st = check_compute(c);
@@ -1558,6 +1571,7 @@ static pano_status refresh_begin_impl(pano_ctx* c, const uint8_t* const* h_frame
     if (c->job) return fail(c, PANO_ESTATE, "a mask refresh is under way: pano_refresh_masks_poll / _wait first");
     reap_trash(c);
     MaskJob* j = new MaskJob;
+    j->tmp.pool = &c->refresh_pool;
     c->job = j;
     if (hipStreamCreateWithFlags(&j->s, hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
