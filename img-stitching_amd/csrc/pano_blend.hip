@@ -352,14 +352,16 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
             load_coarse<int16_t>(C.img[l + 1] + (size_t)(pb + pl) * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
                                  Y0 >> 1, cp[pl]);
     }
-    int acc[3][2][4];
+    // the accumulators are int16 by definition (dst += static_cast<short>(..) wraps): two per register (v_pk_add_i16) - the general
+    // path sets the kernel's register allocation, and with it the waves in flight that the single-owner path lives on
+    s2_t acc[3][2][2];
     float W[2][4];
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             W[r][k] = 0.f;
-            acc[0][r][k] = acc[1][r][k] = acc[2][r][k] = 0;
+            acc[0][r][k >> 1] = acc[1][r][k >> 1] = acc[2][r][k >> 1] = s2_t{0, 0};
         }
     // phase B: cameras with weight, in feed order
 #pragma unroll
@@ -414,17 +416,19 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
 #pragma unroll
                 for (int k = 0; k < 4; k++) up[0][k] = up[1][k] = 0;
             }
+            short t0[4], t1[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int l0 = sat16i((int)((g0[pl] >> (8 * k)) & 0xffu) - up[0][k]);
                 const int l1 = sat16i((int)((g1[pl] >> (8 * k)) & 0xffu) - up[1][k]);
-                if (unit) {  // (short)(lap * 1.0f) == lap
-                    acc[pl][0][k] = (int16_t)(acc[pl][0][k] + l0);
-                    acc[pl][1][k] = (int16_t)(acc[pl][1][k] + l1);
-                } else {
-                    acc[pl][0][k] = (int16_t)(acc[pl][0][k] + (int16_t)(int)((float)l0 * w[0][k]));
-                    acc[pl][1][k] = (int16_t)(acc[pl][1][k] + (int16_t)(int)((float)l1 * w[1][k]));
-                }
+                // (short)(lap * 1.0f) == lap
+                t0[k] = unit ? (short)l0 : (short)(int)((float)l0 * w[0][k]);
+                t1[k] = unit ? (short)l1 : (short)(int)((float)l1 * w[1][k]);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                acc[pl][0][h] += s2_t{t0[2 * h], t0[2 * h + 1]};  // wraps like the short += of the reference
+                acc[pl][1][h] += s2_t{t1[2 * h], t1[2 * h + 1]};
             }
         }
     }
@@ -456,7 +460,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
         for (int r = 0; r < 2; r++)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int a = acc[pl][r][k];
+                const int a = (k & 1) ? acc[pl][r][k >> 1].y : acc[pl][r][k >> 1].x;
                 int nrm;
                 if (unitW) nrm = toward_zero_by_one(a);
                 else nrm = (int16_t)(int)((float)a / (W[r][k] + 1e-5f));
