@@ -1635,6 +1635,7 @@ static pano_status build_masks_graphcut_impl(pano_ctx* c, const uint8_t* const* 
         if (!h_frames[i] || strides[i] < (size_t)c->plan.src_w * 3) return fail(c, PANO_EINVAL, "frame pointer / stride");
     hipStream_t s = c->own_stream;
     Scratch tmp;
+    tmp.pool = &c->refresh_pool;  // calibration's cut leaves the buffers the refreshes beside the loop will ask for
     SeamWarps sm;
     if ((st = seam_scale_warps(c, h_frames, strides, tmp, s, sm)) != PANO_OK) return st;
     std::string err;

@@ -83,6 +83,17 @@ def test_replay_frames_on_gpu(replay_bin, rig_r, tmp_path):
     assert r.returncode == 0 and "wrote final.ppm 1470x500" in r.stdout, r.stderr + r.stdout
 
 
+@pytest.mark.gpu
+def test_replay_paced_loop_with_mask_refresh_beside_it(replay_bin, rig_r, tmp_path):
+    """the capture loop of src/master.cpp paced at 60 fps with a graph-cut mask refresh every 30 frames: run beside the loop
+    (pano::Stitcher::asyncMaskRefresh -> pano_refresh_masks_*) no tick is lost"""
+    cfg = write_cfgs(tmp_path, rig_r)
+    r = subprocess.run([replay_bin, str(cfg), "--frames", "120", "--fps", "60", "--refresh-every", "30", "--async-refresh"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "120 composed, dropped 0" in r.stdout and "beside the loop" in r.stdout, r.stdout
+
+
 @pytest.fixture(scope="module")
 def sharded_bin(tmp_path_factory, pano):
     """examples/sharded_replay.cpp: the camera-sharded flow (feed -> pano_gather_slots over RCCL -> blend) for a C++ caller,
