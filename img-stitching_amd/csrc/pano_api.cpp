@@ -177,6 +177,7 @@ struct pano_ctx {
     MaskJob* job = nullptr;
     MaskJob* job_trash = nullptr;  // (unused since the pool: kept for a refresh that failed half way)
     std::vector<std::pair<size_t, void*>> refresh_pool;  // device buffers of the last refresh, reused by the next (Scratch::pool)
+    std::vector<std::pair<size_t, void*>> pairs_pool;    // ... and the graphs of its pairs: the refresh thread's while it runs
 
     std::string err;
 };
@@ -226,6 +227,8 @@ void free_device(pano_ctx* c) {
     drop_graphs(c);
     for (auto& q : c->refresh_pool) (void)hipFree(q.second);
     c->refresh_pool.clear();
+    for (auto& q : c->pairs_pool) (void)hipFree(q.second);
+    c->pairs_pool.clear();
     // slot 0 owns what pyr_base / canvas[] were allocated as; the current slot may be another one
     if (c->nslots > 1) {
         c->pyr_base = c->slot_pyr[0];
@@ -1586,11 +1589,13 @@ static pano_status refresh_begin_impl(pano_ctx* c, const uint8_t* const* h_frame
     }
     j->state = 1;
     const int device = c->device;
-    j->th = std::thread([j, n, device]() {
+    Scratch::Pool* pool = &c->pairs_pool;
+    j->th = std::thread([j, n, device, pool]() {
         pano_status r = PANO_EHIP;
         try {
             if (hipSetDevice(device) == hipSuccess) {
-                Scratch pairs;  // the graphs of the pairs: freed here, on this thread
+                Scratch pairs;  // the graphs of the pairs, from a pool that is this thread's while it runs: a hipFree here
+                pairs.pool = pool;  // would hold up the frame loop's launches too (it waits for the device under the runtime's lock)
                 r = graphcut_pairs(n, j->sm, pairs, j->s, j->err);
             }
             else j->err = "hipSetDevice (mask refresh thread)";
@@ -1639,7 +1644,11 @@ static pano_status build_masks_graphcut_impl(pano_ctx* c, const uint8_t* const* 
     SeamWarps sm;
     if ((st = seam_scale_warps(c, h_frames, strides, tmp, s, sm)) != PANO_OK) return st;
     std::string err;
-    if ((st = graphcut_pairs(n, sm, tmp, s, err)) != PANO_OK) return fail(c, st, err.c_str());
+    {
+        Scratch pairs;
+        pairs.pool = &c->pairs_pool;  // no refresh thread is running (waited for above)
+        if ((st = graphcut_pairs(n, sm, pairs, s, err)) != PANO_OK) return fail(c, st, err.c_str());
+    }
     return finish_seam_masks(c, sm, tmp, s);
 }
 
