@@ -128,7 +128,8 @@ pano_status pano_build_masks_graphcut(pano_ctx* ctx, const uint8_t* const* h_fra
  * cuts to a thread of the library; pano_refresh_masks_poll returns at once and, the first time it finds the thread through,
  * installs the masks (*done = 1; the weights are rebuilt with the next frame, exactly as after pano_build_masks_graphcut:
  * same masks, bit for bit); pano_refresh_masks_wait blocks until then.  One refresh at a time (PANO_ESTATE otherwise);
- * pano_build_masks_graphcut and pano_destroy wait for a refresh under way.  Call all three from the thread that composes. */
+ * pano_build_masks_graphcut and pano_destroy wait for a refresh under way; masks set by pano_set_mask / pano_build_masks_voronoi
+ * while one runs are replaced when it is installed.  Call all three from the thread that composes. */
 pano_status pano_refresh_masks_begin(pano_ctx* ctx, const uint8_t* const* h_frames, const size_t* strides);
 pano_status pano_refresh_masks_poll(pano_ctx* ctx, int* done);
 pano_status pano_refresh_masks_wait(pano_ctx* ctx);
