@@ -93,12 +93,10 @@ struct pano_ctx {
     long long k1_blocks[kMaxCams] = {}, k1_flagged[kMaxCams] = {};
     bool use_lut = true;
     uint16_t* owner[kMaxLevels] = {};
-    uint8_t* small_live = nullptr;   // CanvasParams::small_live
     uint32_t* order0 = nullptr;      // CanvasParams::order0
     size_t order_cap = 0;
     bool order_dirty = false;
     bool l0_order = true;            // PANO_L0_ORDER=0: plain band order
-    bool l0_hints = true;            // PANO_L0_HINTS=0: the order table carries no owner codes (every wave looks its owners up)
     float* wsum[kMaxLevels] = {};
     int16_t* canvas[kMaxLevels] = {};
 
@@ -111,7 +109,6 @@ struct pano_ctx {
     int live[kMaxCams][kMaxLevels][4] = {};
     // dead columns {x0, x1} (inclusive, x1 < x0 = none) inside the live rect: the middle of a +-pi straddler's tile
     int gap[kMaxCams][kMaxLevels][2] = {};
-    PyrTailCfg pyr_tail{0, 64, 2, 32};  // PANO_PYR_HEAD / PANO_PYR_TAIL (+ _TS): how the pyrDown chain is cut into launches
     bool full_tiles = false;  // PANO_FULL_TILES=1: produce every pixel of every level (stage inspection)
     int nslots = 1, cur_slot = 0;
     char* slot_pyr[PANO_MAX_FRAME_SLOTS] = {};
@@ -252,7 +249,6 @@ void free_device(pano_ctx* c) {
         dfree(c->stage_in[i]);
         for (int l = 0; l < kMaxLevels; l++) dfree(c->wgt[i][l]);
     }
-    dfree(c->small_live);
     dfree(c->order0);
     c->order_cap = 0;
     for (int l = 0; l < kMaxLevels; l++) {
@@ -548,7 +544,6 @@ pano_status build_tile_order(pano_ctx* c, hipStream_t s) {
     if (fe == hipSuccess) fe = hipStreamSynchronize(s);
     (void)hipFree(d_flags);
     HIP_TRY(c, fe);
-    const bool hints = c->l0_hints;
     auto mixed = [](uint16_t f) { return (f & 0xf) == 0xf || ((f >> 4) & 0xf) == 0xf || ((f >> 8) & 0xf) == 0xf || (f >> 12) == 0xf; };
     std::vector<uint32_t> order(8 * per, 0xffffu);
     for (size_t k = 0; k < 8; k++) {
@@ -556,7 +551,7 @@ pano_status build_tile_order(pano_ctx* c, hipStream_t s) {
         size_t o = lo;
         for (int pass = 1; pass >= 0; pass--)
             for (size_t t = lo; t < hi; t++)
-                if ((int)mixed(flags[t]) == pass) order[o++] = (uint32_t)t | (uint32_t)(hints ? flags[t] : 0xffffu) << 16;
+                if ((int)mixed(flags[t]) == pass) order[o++] = (uint32_t)t | (uint32_t)flags[t] << 16;
     }
     if (c->order_cap < order.size()) {
         dfree(c->order0);
@@ -599,7 +594,6 @@ pano_status ensure_weights(pano_ctx* c, hipStream_t s) {
     // owner maps of the vector levels
     for (int l = 0; l <= P.bands; l++)
         if (c->cv.fast[l]) launch_build_owner(c->pyr, c->cv, l, c->owner[l], s);
-    if (c->cv.small_fused) launch_small_live(c->pyr, c->cv, c->small_live, s);
     {
         pano_status os = build_tile_order(c, s);
         if (os != PANO_OK) return os;
@@ -1246,7 +1240,7 @@ static pano_status prepare_impl(pano_ctx* c) {
         // 200 K pixels: on the 1080p rig levels 0..2 run the vector kernel, 3..5 the fused small-level pair.  Measured with
         // two frames in flight (the GPU is VALU-issue bound there and the small-level kernels spend 3x the instructions
         // per pixel): 600 K -> 8860, 200 K -> 9200, 50 K -> 9080 panoramas/s
-        static const size_t vec_min_px = getenv("PANO_VEC_MIN_PIXELS") ? (size_t)atol(getenv("PANO_VEC_MIN_PIXELS")) : 200000;
+        constexpr size_t vec_min_px = 200000;
         bool fast = P.bands >= 0 && ((P.canvas.w >> l) % 4 == 0) && ((P.canvas.h >> l) % 2 == 0) &&
                     (size_t)(P.canvas.w >> l) * (P.canvas.h >> l) >= vec_min_px;
         for (int i = 0; i < n && fast; i++) {
@@ -1268,40 +1262,10 @@ static pano_status prepare_impl(pano_ctx* c) {
         while (k <= P.bands && c->cv.fast[k]) k++;
         if (k >= 1 && P.bands - k + 1 >= 2) c->cv.small_base = k;
     }
-    // ... or as ONE launch that builds the camera levels above small_base itself (small_fused_kernel), at most four levels.
-    // PANO_SMALL_FUSED: 0 = the separate pyrDown / normalise / collapse launches; 1 = fused from the level above the last
-    // vector level; 2 = fused from level max(1, bands - 3), which on the 1080p rig also takes blend level 2 in (six launches
-    // per frame instead of eleven)
-    // the normalise and collapse launches of the small levels as one: opt-in (PANO_SMALL_MERGED=1).  Bit-exact, one launch
-    // less - and 27.6 us where the two launches take 8.4 + 5.4: a tile's three levels run one after the other on its 256 lanes,
-    // where norm_small_kernel spreads them over three times the workgroups
-    c->cv.small_merged = getenv("PANO_SMALL_MERGED") && atoi(getenv("PANO_SMALL_MERGED")) == 1;
-    {
-        const int mode = getenv("PANO_SMALL_FUSED") ? atoi(getenv("PANO_SMALL_FUSED")) : 0;
-        c->cv.small_fused = 0;
-        if (mode == 2 && P.bands >= 2) {
-            c->cv.small_base = std::max(1, P.bands - (kSmallFusedMaxLevels - 1));
-            c->cv.small_fused = 1;
-        } else if (mode == 1 && c->cv.small_base > 0 && P.bands - c->cv.small_base + 1 <= kSmallFusedMaxLevels) {
-            c->cv.small_fused = 1;
-        }
-    }
-    if (c->cv.small_fused) {
-        c->cv.w0 = P.canvas.w; c->cv.h0 = P.canvas.h;  // (set again below with the rest)
-        HIP_TRY(c, hipMalloc((void**)&c->small_live, small_live_bytes(c->cv)));
-        c->cv.small_live = c->small_live;
-    }
     c->full_tiles = getenv("PANO_FULL_TILES") && atoi(getenv("PANO_FULL_TILES"));
-    if (getenv("PANO_PYR_TAIL")) c->pyr_tail.base = std::max(atoi(getenv("PANO_PYR_TAIL")), 0);
-    if (getenv("PANO_PYR_TAIL_TS")) c->pyr_tail.ts = atoi(getenv("PANO_PYR_TAIL_TS")) == 64 ? 64 : 32;
-    if (getenv("PANO_PYR_HEAD")) c->pyr_tail.head = std::max(atoi(getenv("PANO_PYR_HEAD")), 0);
-    if (getenv("PANO_PYR_HEAD_TS")) c->pyr_tail.head_ts = atoi(getenv("PANO_PYR_HEAD_TS")) == 64 ? 64 : 32;
-    // launch-shape knobs of the blend (A/B levers of DESIGN.md section 6/8; none changes a result)
+    // level 0 walks its tiles seam tiles first, with the owner codes of their waves in the order table (A/B lever; PANO_L0_ORDER=0:
+    // plain XCD-band order, every wave looks its owners up; no result changes)
     c->l0_order = !(getenv("PANO_L0_ORDER") && atoi(getenv("PANO_L0_ORDER")) == 0);
-    c->l0_hints = !(getenv("PANO_L0_HINTS") && atoi(getenv("PANO_L0_HINTS")) == 0);
-    c->cv.k3_shape = getenv("PANO_K3_SHAPE") ? atoi(getenv("PANO_K3_SHAPE")) & 3 : 3;
-    c->cv.blend_split = !(getenv("PANO_BLEND_PLANES") && atoi(getenv("PANO_BLEND_PLANES")) == 0);
-    c->cv.l0_strips = getenv("PANO_L0_STRIPS") ? atoi(getenv("PANO_L0_STRIPS")) : 0;
     live_rects(c, {});  // no masks yet: every pixel of every level is live
     c->cv.cam_lo = 0;
     c->cv.cam_n = n;
@@ -1805,7 +1769,7 @@ pano_status pano_warp_mask(pano_ctx* c, int i, uint8_t* d_dst, size_t dst_stride
 
 // pyrDown launches per frame: every level, or - when the small levels run fused - only up to small_base (the fused kernel
 // builds the levels above it in LDS)
-static int pyr_levels(const pano_ctx* c) { return c->cv.small_fused ? c->cv.small_base : c->plan.bands; }
+static int pyr_levels(const pano_ctx* c) { return c->plan.bands; }
 
 pano_status pano_feed_cameras(pano_ctx* c, unsigned cam_bits, const uint8_t* const* d_frames, const size_t* strides,
                               void* stream) {
@@ -1841,7 +1805,7 @@ pano_status pano_feed_cameras(pano_ctx* c, unsigned cam_bits, const uint8_t* con
     } else {
         launch_warp_tiles(wp, k, mw, mh, s);
     }
-    launch_pyr_chain(c->pyr, cam_bits, pyr_levels(c), c->pyr_tail, s);
+    launch_pyr_chain(c->pyr, cam_bits, pyr_levels(c), s);
     if (c->profiling && (st = record(c, 2, s)) != PANO_OK) return st;
     HIP_TRY(c, hipGetLastError());
     return PANO_OK;
@@ -1985,7 +1949,7 @@ pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b, const uint8_t* const* fa
     for (int i = 0; i < B.n; i++) pp.cam[A.n + i] = b->pyr.cam[i];
     pp.ncam = A.n + B.n;
     const unsigned all = (1u << pp.ncam) - 1u;
-    launch_pyr_chain(pp, all, pyr_levels(a), a->pyr_tail, s);
+    launch_pyr_chain(pp, all, pyr_levels(a), s);
     if (prof && (st = record(a, 2, s)) != PANO_OK) return st;
     // K3: both canvases per launch
     CanvasSet cs{};
@@ -2082,6 +2046,13 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
     hipStream_t up = c->host_h2d[0], down = c->host_h2d[1];
     const int prev_slot = c->cur_slot;
     if (c->nslots > 1 && prev_slot != 0) bind_slot(c, 0);
+    struct RestoreSlot {  // every return below - the HIP_TRY ones included - leaves the caller's frame slot selected
+        pano_ctx* c;
+        int prev;
+        ~RestoreSlot() {
+            if (c->nslots > 1 && prev != 0 && c->cur_slot != prev) bind_slot(c, prev);
+        }
+    } restore_slot{c, prev_slot};
     hipStream_t s = c->own_stream;
     CopyPool& pool = CopyPool::instance();
     // PANO_HOST_TRACE=1: mean host-clock ms of the phases, printed by pano_destroy (diagnostic)
@@ -2137,13 +2108,12 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
         HIP_TRY(c, hipEventSynchronize(c->host_in_ready[0]));
     turn.unlock();
     if (trace) tp[1] = now();
-    // a page-locked panorama buffer whose rows fit the staging buffer: the blend writes rows at the CALLER's stride (it takes
-    // any), and the way back is one linear DMA
-    const bool direct_out = out_stride * (size_t)(P.cut.h - 1) + row_out <= c->stage_out_bytes &&
-                            is_pinned_host(h_out, out_stride * (size_t)(P.cut.h - 1) + row_out);
+    // a page-locked panorama buffer with TIGHT rows (a continuous cv::Mat: step == 3 * width): the blend writes rows at that
+    // stride and the way back is one linear DMA.  Any other stride has bytes between the rows that are not the panorama's - a
+    // ROI view's belong to its parent image - and a linear copy would overwrite them: those take the staged 2-D copy below
+    const bool direct_out = out_stride == row_out && is_pinned_host(h_out, row_out * (size_t)P.cut.h);
     const size_t dev_pitch = direct_out ? out_stride : out_pitch;
     st = pano_compose(c, frames, pitches, c->stage_out, dev_pitch, s);
-    if (c->nslots > 1 && prev_slot != 0) bind_slot(c, prev_slot);
     if (st != PANO_OK) return st;
     if (trace) {
         tp[2] = now();
@@ -2280,11 +2250,19 @@ hipError_t shared_copy_streams(int device, hipStream_t* h2d, hipStream_t* d2h) {
     static hipStream_t up[64] = {}, down[64] = {};
     std::lock_guard<std::mutex> g(m);
     if (device < 0 || device >= 64) return hipErrorInvalidDevice;
-    if (!up[device]) {
-        hipError_t e = hipStreamCreateWithFlags(&up[device], hipStreamNonBlocking);
+    if (!up[device] || !down[device]) {
+        // both or neither: a half-made pair would hand out a null download stream - the legacy default stream, on which
+        // every copy back would serialise against everything, silently
+        hipStream_t u = nullptr, d = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&u, hipStreamNonBlocking);
         if (e != hipSuccess) return e;
-        e = hipStreamCreateWithFlags(&down[device], hipStreamNonBlocking);
-        if (e != hipSuccess) return e;
+        e = hipStreamCreateWithFlags(&d, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            (void)hipStreamDestroy(u);
+            return e;
+        }
+        up[device] = u;
+        down[device] = d;
     }
     *h2d = up[device];
     *d2h = down[device];
@@ -2708,10 +2686,17 @@ pano_status pano_save_camera_file(pano_ctx* c, const char* path) {
 
 pano_status pano_prepare(pano_ctx* c) {
     // a failure half way (an allocation, an upload) must not leave a ctx that claims to be prepared with null buffers
+    // a second pano_prepare on a prepared context is a harmless error (PANO_ESTATE): it must not tear down a context that may
+    // have frames in flight and a mask refresh running - only a prepare that failed half way is cleaned up
+    const bool was_prepared = c && c->prepared;
     pano_status st = guarded(c, [&]() { return prepare_impl(c); });
-    if (st != PANO_OK && c && c->prepared) {
+    if (st != PANO_OK && c && !was_prepared && c->prepared) {
         std::string why = c->err;
-        if (c->device >= 0) free_device(c);
+        if (c->device >= 0) {
+            drop_job(c);
+            (void)hipDeviceSynchronize();
+            free_device(c);
+        }
         c->prepared = false;
         c->err = why;
     }

@@ -1,4 +1,4 @@
-// pano_blend.hip - K3: one blend level per launch (generic, vector and strip forms), owner maps, launchers
+// pano_blend.hip - K3: one blend level per launch (generic and vector forms), owner maps, launchers
 // Device helpers: pano_dev.hpp; launch interface: pano_kernels.hpp.  Compile with -ffp-contract=off.
 
 #include "pano_dev.hpp"
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         bxi = tile % (unsigned)Cq.order_gx; byi = tile / (unsigned)Cq.order_gx; bzi = cvi;
         hint = (ent >> (16 + 4 * __builtin_amdgcn_readfirstlane(threadIdx.y))) & 0xfu;
     } else if (((lvl >> 8) & 15) == 3) {
-        // XCD bands (shape 3, the default): a 1-D grid of 8 * per workgroups; the hardware deals consecutive ids round-robin
+        // XCD bands (shape 3): a 1-D grid of 8 * per workgroups; the hardware deals consecutive ids round-robin
         // over the 8 XCDs, so XCD k is given the logical workgroups [k * per, (k + 1) * per) - a contiguous band of canvas
         // rows, whose neighbouring workgroups share their cache lines and pyrUp halos in ONE L2
         const unsigned gx = ((unsigned)lvl >> 12) & 0x3ffu, gy = ((unsigned)lvl >> 22) & 0x3ffu;
@@ -518,25 +518,11 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     // a wave is 16 x 4 blocks = 64 x 8 pixels (not a 256-pixel strip): four times fewer waves straddle a seam,
     // and a wave that does not straddle one takes the single-owner fast path below.
     // The four waves of a workgroup form a 2 x 2 patch (128 x 16 pixels).  Consecutive workgroups go to different XCDs,
-    // each with its own L2, so what a workgroup reads of a row should be whole 128-byte lines: stacked (64 x 32 pixels,
-    // shape 1) the 64 bytes a wave reads of a u8 plane row are half a line and the level-0 launch fetched 152 MB for the
-    // ~45 MB it uses; side by side (256 x 8, shape 0) it fetches 74 MB.  Measured per frame (levels 0-2, C2), stacked /
-    // side by side / 2 x 2: HBM bytes of these launches 247 / 145 / 182 MB, panoramas/s one frame at a time 7.18 / 7.35 /
-    // 7.27 k, with four frames in flight 11.77 / 11.64 / 11.83 k (same box, alternating): bytes are not what bounds the
-    // pipeline, and 2 x 2 is the fastest of the three.  On top of 2 x 2, XCD bands (above): blend stage 76.6 -> 72.8 us,
-    // 7.24 -> 7.46 k one frame at a time, 11.71 -> 11.92 k in flight.  PANO_K3_SHAPE=0|1|2|3.
-    int X0, Y0;
-    if (((lvl >> 8) & 15) == 1) {         // stacked
-        const int tid = threadIdx.y * 64 + threadIdx.x;
-        X0 = bx0 + (bxi * 16 + (tid & 15)) * 4;
-        Y0 = by0 + (byi * 16 + (tid >> 4)) * 2;
-    } else if (((lvl >> 8) & 15) == 0) {  // side by side
-        X0 = bx0 + ((bxi * 4 + threadIdx.y) * 16 + (threadIdx.x & 15)) * 4;
-        Y0 = by0 + (byi * 4 + (threadIdx.x >> 4)) * 2;
-    } else {                              // 2 x 2
-        X0 = bx0 + ((bxi * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
-        Y0 = by0 + ((byi * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * 2;
-    }
+    // each with its own L2, so what a workgroup reads of a row should be whole 128-byte lines (four waves stacked read
+    // half lines and fetched twice the bytes; four side by side straddle more seams: docs/EXPERIMENTS.md).  On top of
+    // that the XCD bands above: neighbouring tiles share their lines and pyrUp halos in one L2.
+    const int X0 = bx0 + ((bxi * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
+    const int Y0 = by0 + ((byi * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * 2;
     if (L0) {
         if (X0 >= C.cut_x + C.cut_w || Y0 >= C.cut_y + C.cut_h) return;
     } else if (X0 >= cw || Y0 >= ch) {
@@ -544,220 +530,6 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
     }
     blend_block<L0, NPL>(P, C, l, X0, Y0, pb, hint);
 }
-
-// ------------------------------------------------------------------------------------------------
-// K3 level 0, strip form.  blend_level_vec_kernel spends 700 vector instructions on a single-owner 4 x 2 block, most of them
-// on the two pyrUps (camera level 1 and canvas level 1): every block redoes the horizontal pass of THREE coarse rows of each,
-// although vertically adjacent blocks share two of them, and the whole chain runs one value per instruction.
-// Here a lane owns a strip of S blocks stacked vertically (4 x 2S pixels) and walks down it:
-//   * one new coarse row per step and source - the horizontal pass of a coarse row is done once, a sliding window of three
-//     rows feeds the vertical pass (S + 2 rows per S blocks instead of 3 S);
-//   * the camera side runs two values per instruction: horizontal sums <= 8 * 255 and vertical sums <= 64 * 255 + 32 fit
-//     uint16 (v_pk_add_u16, v_pk_mad_u16, v_pk_lshrrev_b16), with the rounding terms (+32 on even rows, +8 on odd rows) riding
-//     as +4 in every horizontal sum (1 + 6 + 1 = 8 = 32 / 4, 1 + 1 = 2 = 8 / 4);
-//   * Laplacian, n - sign(n), + canvas, saturate and byte packing on int16 pairs (v_pk_sub_i16, v_pk_min/max_i16, v_perm_b32).
-//   The canvas side stays 32-bit in the vertical pass (|out_1| <= 9 * 255 + 9 makes 64-fold sums that do not fit 16 bits).
-// A wave is 16 x 4 strips (64 x 8S pixels): as narrow as before, so no more waves straddle a seam than before.  Waves that
-// do (or that lie on no single owner) run blend_block on each of their blocks.
-// ------------------------------------------------------------------------------------------------
-
-// horizontal position of a lane's 4-sample coarse window (columns x-1 .. x+2 with pyrUp's border rule): what load_coarse
-// derives per block, derived once per strip
-struct CoarseX {
-    unsigned fetch;  // element offset of the aligned fetch inside a row
-    unsigned shift;  // byte shift of the window inside the fetched bytes
-    unsigned selA, selB;
-};
-template <typename T>
-__device__ __forceinline__ CoarseX coarse_x(int n, int x) {
-    const int xi[4] = {x > 0 ? x - 1 : (n > 1 ? 1 : 0), x, min(x + 1, n - 1), min(x + 2, n - 1)};
-    const int base = min(max(x - 1, 0), max(n - 4, 0));
-    const unsigned sh0 = xi[0] - base, sh1 = xi[1] - base, sh2 = xi[2] - base, sh3 = xi[3] - base;
-    CoarseX cx;
-    if (sizeof(T) == 1) {
-        const int ab = base & ~3;
-        cx.fetch = (unsigned)ab;
-        cx.shift = (unsigned)(base - ab);
-        cx.selA = sh0 | (sh1 << 8) | (sh2 << 16) | (sh3 << 24);
-        cx.selB = 0;
-    } else {
-        const int ab = base & ~1;
-        cx.fetch = (unsigned)ab;
-        cx.shift = (unsigned)(base - ab) * 2u;
-        cx.selA = (2 * sh0) | ((2 * sh0 + 1) << 8) | ((2 * sh1) << 16) | ((2 * sh1 + 1) << 24);
-        cx.selB = (2 * sh2) | ((2 * sh2 + 1) << 8) | ((2 * sh3) << 16) | ((2 * sh3 + 1) << 24);
-    }
-    return cx;
-}
-// coarse row j of the sliding window (j = -1 .. m): pyrUp's vertical border rule (top reflect-101, bottom replicate)
-__device__ __forceinline__ int coarse_row(int j, int m) { return j < 0 ? (m > 1 ? 1 : 0) : min(j, m - 1); }
-
-// camera level-1 row (u8): fetched 8 bytes -> the four horizontal sums as two uint16 pairs, each carrying +4
-__device__ __forceinline__ void cam_hrow(uint2 d, const CoarseX& cx, us2_t& h01, us2_t& h23) {
-    const unsigned w = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(d.y, d.x, cx.shift), cx.selA);
-    const unsigned h0 = __builtin_amdgcn_udot4(w, 0x00010601u, 4u, false), h1 = __builtin_amdgcn_udot4(w, 0x00040400u, 4u, false);
-    const unsigned h2 = __builtin_amdgcn_udot4(w, 0x01060100u, 4u, false), h3 = __builtin_amdgcn_udot4(w, 0x04040000u, 4u, false);
-    h01 = __builtin_bit_cast(us2_t, h0 | (h1 << 16));
-    h23 = __builtin_bit_cast(us2_t, h2 | (h3 << 16));
-}
-// canvas level-1 row (int16): fetched 12 bytes -> the four horizontal sums, 32-bit
-__device__ __forceinline__ void cv_hrow(uint3 d, const CoarseX& cx, int h[4]) {
-    const unsigned w0 = __builtin_amdgcn_alignbyte(d.y, d.x, cx.shift), w1 = __builtin_amdgcn_alignbyte(d.z, d.y, cx.shift);
-    const unsigned q0 = __builtin_amdgcn_perm(w1, w0, cx.selA), q1 = __builtin_amdgcn_perm(w1, w0, cx.selB);
-    const s2_t A = __builtin_bit_cast(s2_t, q0), B = __builtin_bit_cast(s2_t, q1);
-    const s2_t c16 = {1, 6}, c04 = {0, 4}, c01 = {0, 1};
-    h[0] = __builtin_amdgcn_sdot2(A, c16, (int)B.x, false);
-    h[1] = __builtin_amdgcn_sdot2(A, c04, sdot2_from_zero(q1, 0x00000004u), false);
-    h[2] = __builtin_amdgcn_sdot2(A, c01, sdot2_from_zero(q1, 0x00010006u), false);
-    h[3] = sdot2_from_zero(q1, 0x00040004u);
-}
-// one output row of level 0 (4 pixels) from the three planes' bytes: dst_mask is all set here (single owner), so
-// convertTo(8U) + the cut is all that is left
-__device__ __forceinline__ void store_row_l0(const CanvasParams& C, int X0, int Y, uint3 pk) {
-    if (Y < C.cut_y || Y >= C.cut_y + C.cut_h) return;
-    uint8_t* d = C.out + (int)(__mul24(Y - C.cut_y, C.out_stride) + 3 * (X0 - C.cut_x));
-    const bool whole = X0 >= C.cut_x && X0 + 4 <= C.cut_x + C.cut_w;
-    if (whole) {
-        *reinterpret_cast<Bgr4*>(d) = Bgr4{pk.x, pk.y, pk.z};  // any alignment: see store_block
-    } else {
-        const unsigned w[3] = {pk.x, pk.y, pk.z};
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (X0 + k >= C.cut_x && X0 + k < C.cut_x + C.cut_w) {
-#pragma unroll
-                for (int q = 0; q < 3; q++) d[3 * k + q] = (uint8_t)(w[(3 * k + q) >> 2] >> (8 * ((3 * k + q) & 3)));
-            }
-    }
-}
-
-template <int S>
-__global__ __launch_bounds__(256) void blend_level0_strip_kernel(PyrParams P, CanvasSet CS, int lvl) {
-    // XCD bands over workgroups of 2 x 2 waves (see blend_level_vec_kernel): gx, gy = logical grid, packed in lvl
-    const unsigned gx = ((unsigned)lvl >> 12) & 0x3ffu, gy = ((unsigned)lvl >> 22) & 0x3ffu;
-    const unsigned total = gx * gy * (unsigned)CS.n;
-    const unsigned per = (total + 7u) / 8u;
-    const unsigned logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per || logical >= total) return;
-    const unsigned bxi = logical % gx, byi = (logical / gx) % gy, bzi = logical / (gx * gy);
-    const CanvasParams& C = CS.c[bzi];
-    const int cw = C.w0, ch = C.h0;
-    const int bx0 = C.cut_x & ~3, by0 = C.cut_y & ~1;
-    const int X0 = bx0 + ((bxi * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
-    const int Yb = by0 + ((byi * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * (2 * S);
-    const int y_end = min(C.cut_y + C.cut_h, ch);
-    if (X0 >= C.cut_x + C.cut_w || Yb >= y_end) return;
-    // the strip's owner entries: single owner for the whole wave?
-    unsigned entry[S];
-#pragma unroll
-    for (int s = 0; s < S; s++)
-        entry[s] = C.owner[0][(unsigned)(__mul24(min(Yb + 2 * s, ch - 2) >> 1, C.opitch[0]) + (X0 >> 2))];
-    const unsigned ucode = __builtin_amdgcn_readfirstlane(entry[0] & 0xffu);
-    bool same = true;
-#pragma unroll
-    for (int s = 0; s < S; s++) same &= (entry[s] & 0xffu) == ucode;
-    if (ucode == 0xffu || __builtin_amdgcn_ballot_w64(!same) != 0) {
-        for (int s = 0; s < S; s++) {
-            const int Y0 = Yb + 2 * s;
-            if (Y0 < y_end) blend_block<true, 3>(P, C, 0, X0, Y0, 0);
-        }
-        return;
-    }
-    if (ucode >= 8u) {  // no camera carries weight here: dst_mask clear, black
-#pragma unroll
-        for (int r = 0; r < 2 * S; r++)
-            if (Yb + r < y_end) store_row_l0(C, X0, Yb + r, make_uint3(0u, 0u, 0u));
-        return;
-    }
-    // ---- the whole wave lies on camera `ucode` with weight 1: acc = lap, W = 1, norm = lap - sign(lap)
-    const PyrCam& c = P.cam[C.cam_lo + ucode];
-    const int x = X0 - c.tx, y = Yb - c.ty;      // tile coordinates (y even: tile origins are multiples of 2^bands)
-    const int n1 = c.w0 >> 1, m1 = c.h0 >> 1;    // camera level 1
-    const int cn = cw >> 1, cm = ch >> 1;        // canvas level 1
-    const CoarseX kx = coarse_x<uint8_t>(n1, x >> 1), vx = coarse_x<int16_t>(cn, X0 >> 1);
-    const int kr0 = (y >> 1) - 1, vr0 = (Yb >> 1) - 1;  // first row of the two sliding windows
-    // plane by plane: the loads of a plane - 2S fine rows, S + 2 coarse rows of the camera and of the canvas - are issued
-    // together and consumed before the next plane's are issued (all three planes at once: 183 VGPRs at S = 4, two waves
-    // per SIMD)
-    // The plane loop is a real loop: unrolled, the compiler overlaps the planes and allocates 179 VGPRs at S = 4 (two waves per
-    // SIMD).  A plane's four bytes per row are inserted into the row's three interleaved BGR dwords (B0 G0 R0 B1 | G1 R1 B2 G2
-    // | R2 B3 G3 R3) by v_perm_b32 with per-plane selectors (0-3 = old bytes, 4-7 = the plane's pixels 0-3)
-    uint3 out[2 * S];
-#pragma unroll
-    for (int r = 0; r < 2 * S; r++) out[r] = make_uint3(0u, 0u, 0u);
-#pragma unroll 1
-    for (int pl = 0; pl < 3; pl++) {
-        const unsigned ins0 = pl == 0 ? 0x05020104u : (pl == 1 ? 0x03020400u : 0x03040100u);
-        const unsigned ins1 = pl == 0 ? 0x03060100u : (pl == 1 ? 0x06020105u : 0x03020500u);
-        const unsigned ins2 = pl == 0 ? 0x03020700u : (pl == 1 ? 0x03070100u : 0x07020106u);
-        unsigned g[2 * S];
-        uint2 kq[S + 2];
-        uint3 vq[S + 2];
-        {
-            const uint8_t* g0 = c.lvl[0] + (size_t)pl * c.plane[0] + (unsigned)(__mul24(y, c.pitch[0]) + x);
-#pragma unroll
-            for (int r = 0; r < 2 * S; r++) g[r] = *reinterpret_cast<const unsigned*>(g0 + __mul24(min(r, c.h0 - 1 - y), c.pitch[0]));
-            const uint8_t* k1 = c.lvl[1] + (size_t)pl * c.plane[1] + kx.fetch;
-#pragma unroll
-            for (int r = 0; r < S + 2; r++) kq[r] = *reinterpret_cast<const uint2*>(k1 + (unsigned)__mul24(coarse_row(kr0 + r, m1), c.pitch[1]));
-            const int16_t* v1 = C.img[1] + (size_t)pl * C.cplane[1] + vx.fetch;
-#pragma unroll
-            for (int r = 0; r < S + 2; r++) vq[r] = *reinterpret_cast<const uint3*>(v1 + (unsigned)__mul24(coarse_row(vr0 + r, cm), C.cpitch[1]));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        us2_t ka01, ka23, kb01, kb23, kc01, kc23;
-        int va[4], vb[4], vc[4];
-        cam_hrow(kq[0], kx, ka01, ka23);
-        cam_hrow(kq[1], kx, kb01, kb23);
-        cv_hrow(vq[0], vx, va);
-        cv_hrow(vq[1], vx, vb);
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-            cam_hrow(kq[s + 2], kx, kc01, kc23);
-            cv_hrow(vq[s + 2], vx, vc);
-            // pyrUp of the camera's level 1: rows 2k (1 6 1) and 2k + 1 (4 4); the +4 in every sum is the rounding term
-            const us2_t e01 = (us2_t)(ka01 + kc01 + kb01 * (us2_t)6) >> (us2_t)6, e23 = (us2_t)(ka23 + kc23 + kb23 * (us2_t)6) >> (us2_t)6;
-            const us2_t o01 = (us2_t)(kb01 + kc01) >> (us2_t)4, o23 = (us2_t)(kb23 + kc23) >> (us2_t)4;
-            // pyrUp of the canvas' level 1, packed to int16 pairs (|out_1| <= 9 * 255 + 9)
-            int ve[4], vo[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                ve[k] = (va[k] + vc[k] + 32 + vb[k] * 6) >> 6;
-                vo[k] = (vb[k] + vc[k] + 8) >> 4;
-            }
-            const s2_t ce01 = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm((unsigned)ve[1], (unsigned)ve[0], 0x05040100u));
-            const s2_t ce23 = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm((unsigned)ve[3], (unsigned)ve[2], 0x05040100u));
-            const s2_t co01 = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm((unsigned)vo[1], (unsigned)vo[0], 0x05040100u));
-            const s2_t co23 = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm((unsigned)vo[3], (unsigned)vo[2], 0x05040100u));
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const unsigned gw = g[2 * s + r];
-                const s2_t g01 = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm(0u, gw, 0x0c010c00u));
-                const s2_t g23 = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm(0u, gw, 0x0c030c02u));
-                const s2_t u01 = __builtin_bit_cast(s2_t, r == 0 ? e01 : o01), u23 = __builtin_bit_cast(s2_t, r == 0 ? e23 : o23);
-                const s2_t one = {1, 1}, mone = {-1, -1}, zero = {0, 0}, top = {255, 255};
-                s2_t l01 = g01 - u01, l23 = g23 - u23;                                // |lap| <= 255
-                l01 -= __builtin_elementwise_max(__builtin_elementwise_min(l01, one), mone);   // n - sign(n)
-                l23 -= __builtin_elementwise_max(__builtin_elementwise_min(l23, one), mone);
-                l01 += r == 0 ? ce01 : co01;
-                l23 += r == 0 ? ce23 : co23;
-                l01 = __builtin_elementwise_min(__builtin_elementwise_max(l01, zero), top);    // convertTo(CV_8U)
-                l23 = __builtin_elementwise_min(__builtin_elementwise_max(l23, zero), top);
-                const unsigned px = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, l23), __builtin_bit_cast(unsigned, l01), 0x06040200u);
-                out[2 * s + r].x = __builtin_amdgcn_perm(px, out[2 * s + r].x, ins0);
-                out[2 * s + r].y = __builtin_amdgcn_perm(px, out[2 * s + r].y, ins1);
-                out[2 * s + r].z = __builtin_amdgcn_perm(px, out[2 * s + r].z, ins2);
-            }
-            ka01 = kb01; ka23 = kb23; kb01 = kc01; kb23 = kc23;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { va[k] = vb[k]; vb[k] = vc[k]; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int r = 0; r < 2 * S; r++)
-        if (Yb + r < y_end) store_row_l0(C, X0, Yb + r, out[r]);
-}
-
 
 // owner map of a vector level: one byte per 4 x 2 block (see CanvasParams::owner)
 __global__ __launch_bounds__(256) void build_owner_kernel(PyrParams P, CanvasParams C, int l, uint16_t* owner) {
@@ -844,37 +616,18 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
                 h = max(h, cg.h0 >> l);
             }
         }
-        // workgroup shape (see the kernel): 3 = 2 x 2 waves in XCD bands (default), 2 = 2 x 2 waves, 0 = side by side, 1 = stacked
-        const int shape_env = c.k3_shape & 3;
-        // one plane per lane on the canvas levels >= 1 (measured: levels 1 + 2 29 -> 23 us, in flight no worse);
-        // PANO_BLEND_PLANES=0 keeps three planes per lane
-        const bool split = c.blend_split != 0;
-        int shape = shape_env;
-        if (shape == 3 && ((w + 127) / 128 > 1023 || (h + 15) / 16 > 1023)) shape = 2;  // the band form packs the extents in 10 bits each
+        // workgroups of 2 x 2 waves (128 x 16 pixels) dealt to the XCDs in bands (shape 3); extents beyond the 10 bits the band
+        // form packs them in fall back to a plain 3-D grid (shape 2).  Canvas levels >= 1 run one colour plane per lane
+        // (grid.z = canvas * 3 + plane): those launches are one round of waves whose seam waves set the duration
+        int shape = 3;
+        if ((w + 127) / 128 > 1023 || (h + 15) / 16 > 1023) shape = 2;
         dim3 block(64, 4, 1), grid((w + 127) / 128, (h + 15) / 16, cs.n);
-        if (shape == 0) grid = dim3((w + 255) / 256, (h + 7) / 8, cs.n);
-        if (shape == 1) grid = dim3((w + 63) / 64, (h + 31) / 32, cs.n);
         int larg = l | (shape << 8);
         const dim3 grid3 = grid;  // the logical extents
-        if (shape == 3) {       // XCD bands over the 2 x 2 shape: a 1-D grid of 8 * ceil(workgroups / 8)
+        if (shape == 3) {       // a 1-D grid of 8 * ceil(workgroups / 8)
             larg |= (int)((grid3.x & 0x3ffu) << 12) | (int)((grid3.y & 0x3ffu) << 22);
-            const unsigned zext = (l == 0 || !split) ? cs.n : cs.n * 3;
+            const unsigned zext = l == 0 ? cs.n : cs.n * 3;
             grid = dim3(8u * ((grid3.x * grid3.y * zext + 7u) / 8u), 1, 1);
-        }
-        // level 0 in strips of S blocks per lane (blend_level0_strip_kernel): opt-in, PANO_L0_STRIPS=2 / 4 / 8 pick S.  Measured on
-        // config 2: half the vector instructions per pixel, yet 36.7 / 49.4 / 72.5 us against 31.4 us
-        // for one block per lane alone and the same panoramas/s with frames in flight
-        const int strips = c.l0_strips;
-        if (l == 0 && c.bands >= 1 && (strips == 2 || strips == 4 || strips == 8)) {
-            const unsigned sgx = (w + 127) / 128, sgy = (h + 16 * strips - 1) / (16 * strips);
-            if (sgx <= 1023 && sgy <= 1023) {
-                const int karg = (int)(sgx << 12) | (int)(sgy << 22);
-                const dim3 sgrid(8u * ((sgx * sgy * cs.n + 7u) / 8u), 1, 1);
-                if (strips == 2) PANO_LAUNCH_L0(blend_level0_strip_kernel<2>, sgrid);
-                else if (strips == 4) PANO_LAUNCH_L0(blend_level0_strip_kernel<4>, sgrid);
-                else PANO_LAUNCH_L0(blend_level0_strip_kernel<8>, sgrid);
-                return;
-            }
         }
         if (l == 0) {
             bool ordered = shape == 3;
@@ -891,8 +644,7 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
                 PANO_LAUNCH_L0((blend_level_vec_kernel<true, 3>), grid);
             }
         } else {
-            if (split) hipLaunchKernelGGL((blend_level_vec_kernel<false, 1>), shape == 3 ? grid : dim3(grid.x, grid.y, cs.n * 3), block, 0, s, p, cs, larg);
-            else hipLaunchKernelGGL((blend_level_vec_kernel<false, 3>), grid, block, 0, s, p, cs, larg);
+            hipLaunchKernelGGL((blend_level_vec_kernel<false, 1>), shape == 3 ? grid : dim3(grid.x, grid.y, cs.n * 3), block, 0, s, p, cs, larg);
         }
         return;
     }

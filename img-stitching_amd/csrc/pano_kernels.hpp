@@ -91,19 +91,11 @@ struct CanvasParams {
     const uint16_t* owner[kLevels]; // vector levels, per 4x2 block: low byte = the single unit-weight camera (0..7), 0xFE none,
                                // 0xFF mixed; high byte = bit i set when camera i carries weight anywhere on the block
     int opitch[kLevels];       // owner entries per block row
-    // launch shape knobs, read from the environment ONCE per context (pano_prepare), never inside a launcher:
-    int k3_shape;              // PANO_K3_SHAPE: 3 = 2 x 2 waves in XCD bands (default), 2 = 2 x 2, 0 = side by side, 1 = stacked
-    int blend_split;           // PANO_BLEND_PLANES != 0: one colour plane per lane on the canvas levels >= 1 (default)
-    int l0_strips;             // PANO_L0_STRIPS = 2 / 4 / 8: level 0 by blend_level0_strip_kernel<S>; 0 (default): one block per lane
     int small_base;            // >0: levels small_base..bands run as one normalise launch + one LDS collapse launch
-    int small_merged;          // 1: the normalise and the collapse launch are ONE launch (collapse_small_kernel<true>)
-    int small_fused;           // 1: ... and as ONE launch (small_fused_kernel) that also builds the camera levels above
-                               // small_base itself: the per-frame pyrDown chain stops at level small_base
     const uint32_t* order0;    // level 0, or nullptr: per XCD band (order_per entries each, low half 0xffff = none) the 128 x 16-pixel
     int order_per, order_gx;   // workgroup tiles in the order they are dispatched - seam tiles first; tile = by * order_gx + bx;
                                // high half: what the tile's four waves will find in the owner map, a nibble each (wave = threadIdx.y):
                                // 0..7 the single owner of every block of the wave, 0xE no owner anywhere, 0xF look it up
-    const uint8_t* small_live; // small_fused: per 64 x 16 tile of level small_base, the cameras with weight on its footprint
     int cam_lo, cam_n;         // this canvas blends cameras [cam_lo, cam_lo + cam_n) of the PyrParams it is launched with
     int w0, h0;                // padded canvas size
     int bands;
@@ -137,47 +129,28 @@ void launch_warp_mask(const WarpCam& c, uint8_t* dst, int dst_stride, hipStream_
 
 // K2: one pyrDown level (16S x3) for the selected cameras: level `l` -> level `l+1`
 void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s);
-// K2 tail: levels b -> b+1 -> ... -> t (1 <= t - b <= 4) in ONE launch, tiled through LDS with the halo recomputed;
-// ts = 32 | 64: the tile of level b + 1 a workgroup owns
-void launch_pyr_tail(const PyrParams& p, unsigned cam_bits, int b, int t, int ts, hipStream_t s);
+// K2 tail: levels b -> b+1 -> ... -> t (1 <= t - b <= 4) in ONE launch, tiled through LDS with the halo recomputed
+constexpr int kPyrTailTile = 32;  // the tile of level b + 1 a workgroup owns
+constexpr int kPyrTailBase = 2;   // the per-frame chain runs plain launches up to this level and the tail above it
+void launch_pyr_tail(const PyrParams& p, unsigned cam_bits, int b, int t, hipStream_t s);
 bool pyr_tail_ok(const PyrParams& p, unsigned cam_bits, int t);  // every source level of the tail at least 4 x 4
-// how the per-frame pyrDown chain 0 -> levels is cut into launches: levels 0 .. head as one pyr_tail launch (head <= 1: plain
-// launches), plain launches up to level base, levels base .. top as one pyr_tail launch (base = 0 or fewer than two levels
-// left: plain launches)
-struct PyrTailCfg {
-    int head, head_ts;  // PANO_PYR_HEAD, PANO_PYR_HEAD_TS
-    int base, ts;       // PANO_PYR_TAIL, PANO_PYR_TAIL_TS
-};
-inline void launch_pyr_chain(const PyrParams& p, unsigned cam_bits, int levels, PyrTailCfg cfg, hipStream_t s) {
-    int l = 0;
-    const int head = cfg.head < levels ? cfg.head : levels;
-    if (head >= 1 && head <= 4 && ((cfg.head_ts == 64 ? 64 : 32) >> (head - 1)) >= 4 && pyr_tail_ok(p, cam_bits, head)) {
-        launch_pyr_tail(p, cam_bits, 0, head, cfg.head_ts, s);
-        l = head;
-    }
+// the per-frame pyrDown chain 0 -> levels: plain launches up to level base = max(kPyrTailBase, levels - 4), levels base ..
+// top as one pyr_tail launch (fewer than two levels left, or levels too small for it: plain launches)
+inline void launch_pyr_chain(const PyrParams& p, unsigned cam_bits, int levels, hipStream_t s) {
     int plain = levels;
-    if (cfg.base > 0) {
-        int b = cfg.base > levels - 4 ? cfg.base : levels - 4;
-        if (b < l) b = l;
-        const int T = (cfg.ts == 64 ? 64 : 32) >> (levels - b - 1);
-        if (levels - b >= 2 && levels - b <= 4 && T >= 4 && pyr_tail_ok(p, cam_bits, levels)) plain = b;
-    }
+    const int b = kPyrTailBase > levels - 4 ? kPyrTailBase : levels - 4;
+    if (levels - b >= 2 && (kPyrTailTile >> (levels - b - 1)) >= 4 && pyr_tail_ok(p, cam_bits, levels)) plain = b;
+    int l = 0;
     for (; l < plain; l++) launch_pyr_down(p, cam_bits, l, s);
-    if (l < levels) launch_pyr_tail(p, cam_bits, l, levels, cfg.ts, s);
+    if (l < levels) launch_pyr_tail(p, cam_bits, l, levels, s);
 }
 // K3: one blend level for the whole canvas (Laplacian, weight, accumulate, normalise, collapse);
 // level 0 writes the cut 8U panorama
 // ev_start / ev_stop (optional, level 0): the dispatch's own begin / end timestamps
 void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStream_t s, hipEvent_t ev_start = nullptr,
                         hipEvent_t ev_stop = nullptr);
-// the small levels small_base..bands in two launches (one when CanvasParams::small_fused)
-constexpr int kSmallFusedMaxLevels = 4;   // small_fused_kernel handles bands - small_base + 1 <= 4 levels
+// the small levels small_base..bands in two launches: normalise, then the collapse chain through LDS
 void launch_blend_small(const PyrParams& p, const CanvasSet& cs, hipStream_t s);
-// the live-camera table of small_fused_kernel (run when masks change): one byte per 64 x 16 tile of level small_base
-void launch_small_live(const PyrParams& p, const CanvasParams& c, uint8_t* table, hipStream_t s);
-inline size_t small_live_bytes(const CanvasParams& c) {
-    return (size_t)(((c.w0 >> c.small_base) + 63) / 64) * (((c.h0 >> c.small_base) + 15) / 16);  // 64 x 16 tiles
-}
 // per 128 x 16-pixel tile of level 0 (gx x gy of them over the hull of the cut): the owner nibbles of its four waves (0xF: no single owner)
 void launch_tile_mixed(const CanvasParams& c, int gx, int gy, uint16_t* flags, hipStream_t s);
 // owner map of a vector level (run when masks change)

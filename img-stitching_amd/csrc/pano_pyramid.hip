@@ -122,7 +122,7 @@ __host__ __device__ constexpr int tail_cap(int TS, int MJ, int j) {
 __host__ __device__ constexpr int tail_lds_bytes(int TS, int MJ) {
     return tail_cap(TS, MJ, 0) + tail_cap(TS, MJ, 1) + tail_cap(TS, MJ, 2) + tail_cap(TS, MJ, 3) + tail_cap(TS, MJ, 4);
 }
-static_assert(tail_lds_bytes(64, 4) <= 64 * 1024 && tail_pitch(64, 4, 0) == 224 && tail_pitch(64, 4, 1) == 128 && tail_pitch(64, 4, 3) == 64, "static LDS");
+static_assert(tail_lds_bytes(kPyrTailTile, 4) <= 64 * 1024, "static LDS");
 struct TailBox {
     int x0, y0, x1, y1;  // inclusive; x1 < x0: empty
 };
@@ -313,8 +313,8 @@ bool pyr_tail_ok(const PyrParams& p, unsigned cam_bits, int t) {
     return true;
 }
 
-// ts: tile of level b + 1 per workgroup (64: 512 lanes, 32: 256 lanes)
-void launch_pyr_tail(const PyrParams& p, unsigned cam_bits, int b, int t, int ts, hipStream_t s) {
+// one workgroup of 256 lanes owns a 32 x 32 tile of level b + 1 (64 x 64 tiles on 512 lanes measured slower)
+void launch_pyr_tail(const PyrParams& p, unsigned cam_bits, int b, int t, hipStream_t s) {
     int mw = 0, mh = 0;
     for (int i = 0; i < p.ncam; i++)
         if ((cam_bits >> i) & 1u) {
@@ -323,20 +323,13 @@ void launch_pyr_tail(const PyrParams& p, unsigned cam_bits, int b, int t, int ts
         }
     const int J = t - b;
     if (mw == 0 || mh == 0 || J < 1 || J > kTailMaxJ) return;
-    ts = ts == 64 ? 64 : 32;
-    const int T = ts >> (J - 1);  // tile of the top level
+    const int T = kPyrTailTile >> (J - 1);  // tile of the top level
     if (T < 1) return;
     dim3 grid((mw + T - 1) / T, (mh + T - 1) / T, p.ncam * 3);
-#define PANO_TAIL(TS_, TH_, MJ_) hipLaunchKernelGGL((pyr_tail_kernel<TS_, TH_, MJ_>), grid, dim3(64, TH_ / 64, 1), 0, s, p, cam_bits, b, t)
-    if (ts == 64) {
-        if (J == 1) PANO_TAIL(64, 512, 1);
-        else if (J == 2) PANO_TAIL(64, 512, 2);
-        else PANO_TAIL(64, 512, 4);
-    } else {
-        if (J <= 2) PANO_TAIL(32, 256, 2);
-        else if (J == 3) PANO_TAIL(32, 256, 3);
-        else PANO_TAIL(32, 256, 4);
-    }
+#define PANO_TAIL(MJ_) hipLaunchKernelGGL((pyr_tail_kernel<kPyrTailTile, 256, MJ_>), grid, dim3(64, 4, 1), 0, s, p, cam_bits, b, t)
+    if (J <= 2) PANO_TAIL(2);
+    else if (J == 3) PANO_TAIL(3);
+    else PANO_TAIL(4);
 #undef PANO_TAIL
 }
 

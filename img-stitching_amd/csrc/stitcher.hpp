@@ -250,6 +250,7 @@ class Stitcher {
             }
         }
         frame_ = 0;
+        refreshing_ = false;  // a refresh that was under way died with the old context
         return RET_OK;
     }
 

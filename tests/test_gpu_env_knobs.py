@@ -36,10 +36,8 @@ print("knob ok")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knob", ["PANO_K3_SHAPE=0", "PANO_K3_SHAPE=1", "PANO_K3_SHAPE=2", "PANO_BLEND_PLANES=0", "PANO_GRAPH=1",
-                                  "PANO_VEC_MIN_PIXELS=20000", "PANO_VEC_MIN_PIXELS=100000000", "PANO_FULL_TILES=1",
-                                  "PANO_WARP_ON_THE_FLY=1", "PANO_SMALL_FUSED=1", "PANO_SMALL_FUSED=2", "PANO_SMALL_MERGED=1", "PANO_L0_STRIPS=2", "PANO_L0_STRIPS=4", "PANO_L0_ORDER=0", "PANO_HOST_THREADS=1", "PANO_PYR_TAIL=0", "PANO_PYR_TAIL=1 PANO_PYR_TAIL_TS=64", "PANO_PYR_HEAD=2",
-                                  "PANO_PYR_HEAD=1 PANO_PYR_HEAD_TS=32 PANO_PYR_TAIL=3", "PANO_L0_HINTS=0"])
+@pytest.mark.parametrize("knob", ["PANO_GRAPH=1", "PANO_FULL_TILES=1", "PANO_WARP_ON_THE_FLY=1", "PANO_L0_ORDER=0",
+                                  "PANO_HOST_THREADS=1", "PANO_HOST_TRACE=1", "PANO_WRAP_IS_ERROR=1"])
 def test_environment_switch_keeps_the_result(knob):
     env = dict(os.environ)
     for kv in knob.split():
