@@ -223,8 +223,9 @@ def main():
             ok, why = False, repr(exc)[:200]
         if not agree(ok):
             raise SystemExit("bench.py: a rank cannot run its local part of the sharded step (%s)" % (why or "another rank"))
-        # (2) the communicator of the C-ABI exchange (collective; not in the gloo rehearsal, where ranks share one GPU)
-        if not rehearsal and not os.environ.get("PANO_BENCH_EXCHANGE") == "torch":
+        # (2) the communicator of the C-ABI exchange (collective; in the gloo rehearsal, where the ranks share one GPU, only when
+        # PANO_RCCL_LIB names a library that accepts that - the test double of tests/src/fake_rccl.cpp; RCCL itself does not)
+        if (not rehearsal or os.environ.get("PANO_RCCL_LIB")) and not os.environ.get("PANO_BENCH_EXCHANGE") == "torch":
             ok = True
             try:
                 uid = [pano.Context.rccl_unique_id() if rank == 0 else None]
@@ -512,7 +513,7 @@ def main():
                                    "multi-band blend, Voronoi seams, pano 2 x %dx%d" % (args.bands, ow, oh),
                        "parallelism": ("single GPU, %d frames in flight" % F) if world == 1 else
                                       ("cameras sharded %d/rank, %s" % (per_rank, "gloo rehearsal on one GPU, slots staged through the host"
-                                                                          if rehearsal else
+                                                                          if rehearsal and exchange["kind"] != "cabi" else
                                                                           ("RCCL gather to rank 0 through the C-ABI (pano_gather_slots)" if exchange["kind"] == "cabi"
                                                                            else "RCCL gather to rank 0 (torch.distributed batch_isend_irecv)")))},
             "roofline": roofline,
@@ -525,6 +526,13 @@ def main():
         }
         if world > 1:
             mg = {"exchange": exchange["kind"] if any(pl["moves"] for pl in plans) else "none (a rank owns whole stitchers; finished half panoramas move)"}
+            if exchange.get("comm") is not None:
+                # what RCCL itself says about the communicator the exchange ran on (ncclCommCount), and the library behind it
+                try:
+                    mg["rccl_ranks"] = ctxs[0].rccl_comm_count(exchange["comm"])
+                    mg["rccl_library"] = pano.Context.rccl_library()
+                except Exception:  # noqa: BLE001
+                    mg["rccl_ranks"] = None
             if gather_events:
                 us = [a.elapsed_time(b) * 1e3 for a, b in gather_events]
                 recv_bytes = sum(cnt for pl, (_, slot) in zip(plans, slot_views) for (_, _, n_) in pl["moves"] for cnt in [n_ * slot])

@@ -7,6 +7,8 @@
 //   g++ -O2 -std=c++17 examples/sharded_replay.cpp -o sharded_replay -Iinclude -Limg-stitching_amd -lpano_hip -Wl,-rpath,$PWD/img-stitching_amd
 //   ./sharded_replay 0 2 /tmp/pano.id &  ./sharded_replay 1 2 /tmp/pano.id        (rank r uses GPU r)
 //   ./sharded_replay --single          the same panorama on one GPU, for comparison of the checksum
+//   ... <frames> --device D            every rank on GPU D: a rehearsal on one GPU (RCCL itself refuses that; PANO_RCCL_LIB
+//                                      can name a library that does not, e.g. the test double of tests/src/fake_rccl.cpp)
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -53,13 +55,16 @@ static unsigned checksum(const std::vector<uint8_t>& v) {  // position-weighted 
 int main(int argc, char** argv) {
     const bool single = argc > 1 && std::string(argv[1]) == "--single";
     if (!single && argc < 4) {
-        fprintf(stderr, "usage: sharded_replay <rank> <world> <id-file> [frames]   |   sharded_replay --single [frames]\n");
+        fprintf(stderr, "usage: sharded_replay <rank> <world> <id-file> [frames] [--device D]   |   sharded_replay --single [frames]\n");
         return 2;
     }
     const int rank = single ? 0 : atoi(argv[1]), world = single ? 1 : atoi(argv[2]);
     const int frames = argc > (single ? 2 : 4) ? atoi(argv[single ? 2 : 4]) : 3;
+    int device = rank;
+    for (int a = 1; a + 1 < argc; a++)
+        if (std::string(argv[a]) == "--device") device = atoi(argv[a + 1]);
     if (world < 1 || N % world || rank < 0 || rank >= world) { fprintf(stderr, "world must divide %d cameras\n", N); return 2; }
-    pano_ctx* ctx = make_ctx(rank);
+    pano_ctx* ctx = make_ctx(device);
     if (!ctx) return 1;
     // camera c belongs to rank c / (N / world)
     int owner[N];

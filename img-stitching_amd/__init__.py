@@ -88,7 +88,7 @@ EXPORTS = [
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_get_camera", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
     "pano_build_masks_voronoi", "pano_build_masks_graphcut", "pano_refresh_masks_begin", "pano_refresh_masks_poll", "pano_refresh_masks_wait", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
-    "pano_compose_host", "pano_host_alloc", "pano_host_free", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_feed_cameras_host", "pano_blend_host", "pano_rccl_unique_id", "pano_rccl_comm_create", "pano_rccl_comm_destroy", "pano_gather_slots", "pano_stack_master", "pano_stack_finalcut", "pano_stack_master_host", "pano_stack_finalcut_host", "pano_stream_input", "pano_stream_output",
+    "pano_compose_host", "pano_host_alloc", "pano_host_free", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_feed_cameras_host", "pano_blend_host", "pano_rccl_unique_id", "pano_rccl_comm_create", "pano_rccl_comm_destroy", "pano_gather_slots", "pano_rccl_comm_count", "pano_rccl_library", "pano_stack_master", "pano_stack_finalcut", "pano_stack_master_host", "pano_stack_finalcut_host", "pano_stream_input", "pano_stream_output",
     "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
     "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_get_live_rect", "pano_get_live_gap", "pano_get_warp_table_stats", "pano_debug_get_level", "pano_debug_get_weights",
     "pano_debug_get_canvas_weights", "pano_debug_get_canvas",
@@ -389,7 +389,21 @@ class Context:
         return comm
 
     def rccl_comm_destroy(self, comm):
-        self.lib.pano_rccl_comm_destroy(comm)
+        """returns the status (a test double reports sends that never met their receive here)"""
+        return int(self.lib.pano_rccl_comm_destroy(comm))
+
+    def rccl_comm_count(self, comm):
+        """ncclCommCount: the ranks RCCL itself says the communicator spans"""
+        n = C.c_int(0)
+        self._ck(self.lib.pano_rccl_comm_count(comm, C.byref(n)))
+        return n.value
+
+    @staticmethod
+    def rccl_library():
+        """the name the RCCL library was opened by (PANO_RCCL_LIB, or the system's librccl.so); '' when none loads"""
+        lib = load_library()
+        lib.pano_rccl_library.restype = C.c_char_p
+        return (lib.pano_rccl_library() or b"").decode()
 
     def gather_slots(self, comm, rank, root, owner_rank, stream=0):
         arr = (C.c_int * self.n)(*[int(r) for r in owner_rank])

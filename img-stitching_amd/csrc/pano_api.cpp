@@ -2459,6 +2459,18 @@ pano_status pano_rccl_comm_destroy(void* comm) {
     return R.CommDestroy((ncclComm_t)comm) == ncclSuccess ? PANO_OK : PANO_EHIP;
 }
 
+pano_status pano_rccl_comm_count(void* comm, int* ranks) {
+    if (!comm || !ranks) return PANO_EINVAL;
+    Rccl& R = Rccl::get();
+    if (!R.ok) return PANO_ENODEVICE;
+    return R.CommCount((ncclComm_t)comm, ranks) == ncclSuccess ? PANO_OK : PANO_EHIP;
+}
+
+const char* pano_rccl_library(void) {
+    Rccl& R = Rccl::get();
+    return R.ok ? R.path.c_str() : "";
+}
+
 pano_status pano_gather_slots(pano_ctx* c, void* comm, int rank, int root, const int* owner_rank, void* stream) {
     pano_status st = check_compute(c);
     if (st != PANO_OK) return st;

@@ -263,6 +263,11 @@ pano_status pano_rccl_unique_id(char id[PANO_RCCL_ID_BYTES]);
 pano_status pano_rccl_comm_create(pano_ctx* ctx, const char id[PANO_RCCL_ID_BYTES], int world, int rank, void** rccl_comm);
 pano_status pano_rccl_comm_destroy(void* rccl_comm);
 pano_status pano_gather_slots(pano_ctx* ctx, void* rccl_comm, int rank, int root, const int* owner_rank, void* hip_stream);
+/* ncclCommCount of a communicator (how many ranks RCCL itself says it spans), and the name the RCCL library was opened by
+ * ("" when none could be).  Environment PANO_RCCL_LIB=<path>, read once at first use, names the library to open instead of the
+ * system's librccl.so - a site build, or a test double that lets several ranks share one GPU (tests/src/fake_rccl.cpp). */
+pano_status pano_rccl_comm_count(void* rccl_comm, int* ranks);
+const char* pano_rccl_library(void);
 
 /* ---- caller-side assembly of the two half panoramas (device buffers, BGR8) ------------------------------ */
 /* src/master.cpp:321-326: cv::resize(up, up, down.size()) [INTER_LINEAR], cv::vconcat(up, down), black 10-row

@@ -1,0 +1,145 @@
+"""The C-ABI's one exchange, pano_gather_slots, between REAL peers on the box's one GPU: libpano_hip.so opens the RCCL test
+double (PANO_RCCL_LIB -> tests/src/fake_rccl.cpp, which moves the bytes between ranks through shared memory and checks
+send / recv pairing, counts and group nesting) instead of librccl.so, which refuses two ranks on one device.  Walked: world 2
+(one group, two cameras per rank), world 4 (two groups, the bench's N = 4 plan) and world 8 - the C3 partition of BASELINE.json:
+8 ranks, ONE camera each, both groups' slots landing on rank 0.  Rank 0's panoramas are compared with the ORACLE's, and the
+double's counters prove that the bytes came from the peers (replaces the reference's inter-device path,
+src/slave.cpp:88-145 / src/panocamimpl.cpp:11-56).
+Ranks are processes; at world 8 four processes carry two ranks each on a thread (a GPU box admits six processes on its card)."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, BANDS, NC = 960, 540, 4, 4
+
+
+def _rank_main(rank, world, total_cams, uid, res):
+    from helpers import c2_group, synth_frame
+    pano = importlib.import_module("img-stitching_amd")
+    sh = importlib.import_module("img-stitching_amd.sharding")
+    d = c2_group(w=W, h=H, f=501.2)
+    ngroups = total_cams // NC
+    shards = sh.camera_shards(total_cams, world)
+    ctxs = []
+    for g in range(ngroups):
+        ctx = pano.Context(NC, W, H, scale=d["scale"], num_bands=BANDS, device=0)
+        for i in range(NC):
+            ctx.set_camera(i, d["K"][i], d["R"][i])
+        ctx.prepare(); ctx.build_masks_voronoi()
+        ctxs.append(ctx)
+    assert "fake_rccl" in pano.Context.rccl_library(), pano.Context.rccl_library()
+    comm = ctxs[0].rccl_comm_create(uid, world, rank)      # collective: returns when all `world` ranks have joined
+    assert ctxs[0].rccl_comm_count(comm) == world
+    out = {"rank": rank, "ok": True, "why": ""}
+    try:
+        for rep in range(2):
+            for g, ctx in enumerate(ctxs):
+                # a rank only ever sees the frames of ITS cameras
+                mine = [c - g * NC for c in shards[rank] if g * NC <= c < (g + 1) * NC]
+                frames = [synth_frame(W, H, 700 + 31 * rep + NC * g + i) if i in mine else None for i in range(NC)]
+                bits = sum(1 << i for i in mine)
+                if bits:
+                    ctx.feed_cameras_host(bits, frames)
+                # every rank of the communicator walks the same owner runs; the ranks of the other group's cameras no-op
+                ctx.gather_slots(comm, rank, 0, sh.owner_ranks(total_cams, NC, world, g))
+                if rank == 0:
+                    import pano_oracle as po
+                    got = ctx.blend_host()
+                    allf = [synth_frame(W, H, 700 + 31 * rep + NC * g + i) for i in range(NC)]
+                    want, _ = po.compose(allf, d["K"], d["R"], d["scale"], [ctx.get_mask(i) for i in range(NC)], BANDS)
+                    if not np.array_equal(got, want):
+                        out["ok"] = False
+                        out["why"] += f" group {g} rep {rep}: panorama differs from the oracle's;"
+        _, slot = ctxs[0].pyramid_slots()
+        out["slot_bytes"] = int(slot)
+        fk = C.CDLL(os.environ["PANO_RCCL_LIB"])
+        fk.fake_rccl_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
+        st = (C.c_ulonglong * 5)()
+        assert fk.fake_rccl_stats(comm, rank, st) == 0
+        out["stats"] = [int(x) for x in st]
+    except Exception as e:  # noqa: BLE001 - reported to the parent
+        out["ok"] = False
+        out["why"] += f" {type(e).__name__}: {e}"
+    finally:
+        out["destroy"] = ctxs[0].rccl_comm_destroy(comm)
+    res.append(out)
+
+
+def _child(ranks, world, total_cams, uid_hex):
+    import json
+    import threading
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    res = []
+    th = [threading.Thread(target=_rank_main, args=(r, world, total_cams, bytes.fromhex(uid_hex), res)) for r in ranks]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=240)
+    print("RESULT " + json.dumps(res))
+
+
+@pytest.mark.parametrize("world,total_cams,per_proc", [(2, 4, 1), (4, 8, 1), (8, 8, 2)])
+def test_gather_slots_between_real_peers(world, total_cams, per_proc, fake_rccl_lib):
+    import json
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert C.CDLL(fake_rccl_lib).ncclGetUniqueId(C.byref(uid)) == 0     # the id needs no GPU
+    env = dict(os.environ, PANO_RCCL_LIB=fake_rccl_lib, FAKE_RCCL_TIMEOUT_S="120")
+    procs = []
+    for p0 in range(0, world, per_proc):
+        ranks = list(range(p0, p0 + per_proc))
+        code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); "
+                f"import test_gpu_rccl_double as t; t._child({ranks}, {world}, {total_cams}, {bytes(uid)[:128].hex()!r})")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-3000:]
+        line = [l for l in so.splitlines() if l.startswith("RESULT ")]
+        assert line, so[-2000:] + se[-2000:]
+        res += json.loads(line[-1][7:])
+    assert sorted(r["rank"] for r in res) == list(range(world))
+    assert all(r["ok"] and r["destroy"] == 0 for r in res), [(r["rank"], r["why"], r["destroy"]) for r in res]
+    sh = importlib.import_module("img-stitching_amd.sharding")
+    slot = res[0]["slot_bytes"]
+    per = total_cams // world
+    reps, ngroups = 2, total_cams // NC
+    for r in res:
+        groups, sends, recvs, b_out, b_in = r["stats"]
+        if r["rank"] == 0:
+            # everything rank 0 did not feed itself arrived from a peer: one message per rank and group it shares with
+            assert sends == 0 and b_out == 0 and b_in == reps * (total_cams - per) * slot
+            assert recvs == reps * sum(len({o for o in sh.owner_ranks(total_cams, NC, world, g) if o != 0}) for g in range(ngroups))
+            # one ncclGroupStart / End per gather that moves anything
+            assert groups == reps * sum(1 for g in range(ngroups) if any(o != 0 for o in sh.owner_ranks(total_cams, NC, world, g)))
+        else:
+            assert recvs == 0 and b_in == 0 and sends == reps and b_out == reps * per * slot and groups == reps
+
+
+def test_sharded_replay_world_2_through_the_double(fake_rccl_lib, tmp_path):
+    """examples/sharded_replay.cpp - the C++ caller of the sharded flow - as two processes on the one GPU: rank 0's panorama
+    checksums equal the single-rank run's"""
+    lib_dir = os.path.join(ROOT, "img-stitching_amd")
+    exe = tmp_path / "sharded_replay"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", os.path.join(ROOT, "examples", "sharded_replay.cpp"), "-o", str(exe),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + lib_dir, "-lpano_hip", "-Wl,-rpath," + lib_dir, "-lpthread"])
+    single = subprocess.run([str(exe), "--single", "2"], capture_output=True, text=True, cwd=tmp_path)
+    assert single.returncode == 0, single.stderr
+    want = [l.split("checksum ")[1].split(",")[0] for l in single.stdout.splitlines() if l.startswith("frame ")]
+    env = dict(os.environ, PANO_RCCL_LIB=fake_rccl_lib)
+    idf = str(tmp_path / "pano.id")
+    ps = [subprocess.Popen([str(exe), str(r), "2", idf, "2", "--device", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, cwd=tmp_path) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in ps]
+    assert all(p.returncode == 0 for p in ps), [o[1][-1500:] for o in outs]
+    got = [l.split("checksum ")[1].split(",")[0] for l in outs[0][0].splitlines() if l.startswith("frame ")]
+    assert len(want) == 2 and got == want and "(2 ranks)" in outs[0][0]

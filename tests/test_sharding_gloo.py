@@ -45,7 +45,7 @@ def _worker(rank, world, port, total_cams, cams_per_group, slot_bytes, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])   # 8 = the C3 partition: one camera per rank
 def test_slot_exchange(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -53,7 +53,7 @@ def test_slot_exchange(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, 8, 4, 4096, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert sorted(r for r, _ in res) == list(range(world))
