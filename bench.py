@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--cold-only", action="store_true",
                     help="N=1: ONLY K steps one frame at a time over six rotating frame sets (the roofline.cold measurement), for a "
                          "rocprofv3 --kernel-trace --stats summary of exactly that loop; prints the cold object alone")
+    ap.add_argument("--no-c4", action="store_true", help="N=1: skip the config-4 leg (4 x 4K, cylindrical, gain maps, 7 bands: the `c4` object)")
     ap.add_argument("--no-isolated-pass", action="store_true",
                     help="N=1: skip the K steps composed one frame at a time (kernel durations without overlap)")
     args = ap.parse_args()
@@ -610,12 +611,78 @@ def main():
             # compose and D2H of consecutive panoramas overlapped); PCIe-inclusive, so never `value`
             result["h2d_inclusive_panoramas_per_s"] = rate
             result["host_streaming_panoramas_per_s"] = rate
+        if world == 1 and not args.no_c4:
+            try:
+                result["c4"] = config4_leg(pano, torch, max(60, min(args.steps, 200)))
+            except Exception as exc:  # noqa: BLE001 - a side measurement never breaks the contract line
+                result["c4"] = {"error": repr(exc)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(ctxs, g, args.bands)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def config4_leg(pano, torch, steps):
+    """BASELINE.json configs[3] on the same GPU, through the same machinery: 4 x 3840x2160 BGR8 frames resident in HBM, cylindrical
+    warp, exposure gain maps applied in K1 (the compensator apply of src/stitching_detailed.cpp:841), 7-band blend.  Panoramas/s
+    with four frames in flight, then `steps` frames one at a time with the dispatch events on: K1 with the gain maps and the
+    level-0 blend against the HBM roofline (the kernels run three to four times longer here than on config 2)."""
+    from helpers import c4_gain_map, c4_rig, synth_frame
+    g = c4_rig()
+    W, H, NC, F = g["w"], g["h"], 4, 4
+    ctx = pano.Context(NC, W, H, scale=g["scale"], projector=pano.CYLINDRICAL, num_bands=7, device=torch.cuda.current_device())
+    for i in range(NC):
+        ctx.set_camera(i, g["K"][i], g["R"][i])
+    ctx.prepare()
+    ctx.build_masks_voronoi()
+    for i in range(NC):
+        r = ctx.roi(i)
+        ctx.set_gain_map(i, c4_gain_map((r[2] + 31) // 32, (r[3] + 31) // 32, 7 + i))
+    ctx.set_frame_slots(F)
+    frames = [torch.from_numpy(synth_frame(W, H, 900 + i)).cuda() for i in range(NC)]
+    fp, strides = [t.data_ptr() for t in frames], [W * 3] * NC
+    ow, oh = ctx.output_size()
+    outs = [torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in range(F)]
+    streams = [torch.cuda.Stream() for _ in range(F)]
+
+    def step(k):
+        f = k % F
+        ctx.select_frame_slot(f)
+        ctx.compose(fp, strides, outs[f].data_ptr(), ow * 3, streams[f].cuda_stream)
+    for k in range(12):
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ctx.set_profiling(True)
+    ctx.select_frame_slot(0)
+    torch.cuda.synchronize()
+    ctx.stage_stats(True)
+    for k in range(steps):
+        ctx.compose(fp, strides, outs[0].data_ptr(), ow * 3, streams[0].cuda_stream)
+    torch.cuda.synchronize()
+    ms, n = ctx.stage_stats(True)
+    sb, db = ctx.warp_bytes()
+
+    def roof(kernel, nbytes, ms_total, launches):
+        us = ms_total / max(launches, 1) * 1e3
+        gbs = nbytes / (us * 1e-6) / 1e9
+        return {"kernel": kernel, "bound": "hbm", "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_us": round(us, 2),
+                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    out = {"workload": "C4: 4x3840x2160 BGR8, cylindrical warp + exposure gain maps (32x32-pixel blocks, smooth field in [0.8, 1.25]) + "
+                       "7-band blend, Voronoi seams, pano %dx%d" % (ow, oh),
+           "panoramas_per_s": round(1.0 / dt, 1), "frames_in_flight": F, "steps": steps,
+           "one_frame_at_a_time_stage_us": {k: round(ms[i] / max(n[i], 1) * 1e3, 2) for i, k in enumerate(("warp", "pyramid", "blend", "blend_level0"))},
+           "roofline": {"warp_with_gains": roof("warp_tiles_lut_kernel<true>", sb + db, ms[0], n[0]),
+                        "blend_level0": roof("blend_level_vec_kernel<true,3>", 8.5 * ow * oh, ms[3], n[3]),
+                        "measured": "%d frames one at a time, dispatch events of the kernels" % steps}}
+    del ctx
+    return out
 
 
 def cpu_baseline(ctxs, g, bands):

@@ -67,6 +67,8 @@ struct pano_ctx {
     int2 *grow[kMaxCams] = {}, *grow_roi[kMaxCams] = {};
     float2 *groww[kMaxCams] = {}, *groww_roi[kMaxCams] = {};
     float *ghrow[kMaxCams] = {}, *ghrow_roi[kMaxCams] = {};  // horizontally resized gain map rows (tile / ROI columns)
+    int* grow_base[kMaxCams] = {};                           // WarpCam::grow_base
+    int4* grow4[kMaxCams] = {};                              // WarpCam::grow4
     int ghrow_pitch[kMaxCams] = {}, ghrow_roi_pitch[kMaxCams] = {};
 
     // pyramid slots (one allocation), weights, canvas
@@ -245,7 +247,7 @@ void free_device(pano_ctx* c) {
         dfree(c->colA[i]); dfree(c->rowB[i]); dfree(c->colA_roi[i]); dfree(c->rowB_roi[i]);
         dfree(c->mask[i]); dfree(c->gain[i]); dfree(c->mask0[i]); dfree(c->lut[i]); dfree(c->lutc[i]); dfree(c->box[i]); dfree(c->k1_flags[i]); dfree(c->d_fe[i]);
         dfree(c->grow[i]); dfree(c->grow_roi[i]); dfree(c->groww[i]); dfree(c->groww_roi[i]);
-        dfree(c->ghrow[i]); dfree(c->ghrow_roi[i]);
+        dfree(c->ghrow[i]); dfree(c->ghrow_roi[i]); dfree(c->grow_base[i]); dfree(c->grow4[i]);
         dfree(c->stage_in[i]);
         for (int l = 0; l < kMaxLevels; l++) dfree(c->wgt[i][l]);
     }
@@ -324,9 +326,12 @@ WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t strid
         w.box = c->use_lut ? c->box[i] : nullptr;
         w.lutc_pitch = c->lut_pitch[i] / 4;
         w.ghrow = c->ghrow[i]; w.ghrow_pitch = c->ghrow_pitch[i]; w.grow = c->grow[i]; w.groww = c->groww[i];
+        w.grow_base = c->grow_base[i];
+        w.grow4 = c->grow4[i];
     }
     w.gain = c->gain[i];
     w.gw = c->gain_w[i];
+    w.gh = c->gain_h[i];
     w.live_bx0 = 0; w.live_bx1 = INT_MAX; w.live_by0_gap = 0; w.live_by1 = INT_MAX;
     if (!roi_only) {  // the bordered feed() tile: only the 64 x 16 blocks that overlap the live rect of level 0
         const int* L = c->live[i][0];
@@ -513,6 +518,25 @@ pano_status upload_gain_tables(pano_ctx* c, int i, const float* h_gain) {
     build(t.rect.h, t.top, roi.h, gh, ix, wx, true);
     if ((s = upload(c, &c->grow[i], ix.data(), ix.size() * sizeof(int2)))) return s;
     if ((s = upload(c, &c->groww[i], wx.data(), wx.size() * sizeof(float2)))) return s;
+    {   // per 16-row block row of K1: do its rows read at most kGainRows consecutive rows of ghrow?  (WarpCam::grow_base)
+        std::vector<int> base((t.rect.h + 15) / 16);
+        for (size_t b = 0; b < base.size(); b++) {
+            int lo = INT_MAX, hi = -1;
+            for (int y = (int)b * 16; y < std::min((int)b * 16 + 16, t.rect.h); y++) {
+                lo = std::min(lo, std::min(ix[y].x, ix[y].y));
+                hi = std::max(hi, std::max(ix[y].x, ix[y].y));
+            }
+            base[b] = hi - lo < kGainRows ? lo : -1;
+        }
+        if ((s = upload(c, &c->grow_base[i], base.data(), base.size() * sizeof(int)))) return s;
+        std::vector<int4> both(ix.size());
+        for (size_t y = 0; y < ix.size(); y++) {
+            int wb[2];
+            std::memcpy(wb, &wx[y], sizeof(wb));
+            both[y] = make_int4(ix[y].x, ix[y].y, wb[0], wb[1]);
+        }
+        if ((s = upload(c, &c->grow4[i], both.data(), both.size() * sizeof(int4)))) return s;
+    }
     build(roi.w, 0, roi.w, gw, ix, wx, false);
     hresize(ix, wx, roi.w, hr, c->ghrow_roi_pitch[i]);
     if ((s = upload(c, &c->ghrow_roi[i], hr.data(), hr.size() * sizeof(float)))) return s;

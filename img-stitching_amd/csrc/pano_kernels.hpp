@@ -39,25 +39,32 @@ struct alignas(64) WarpCam {
     // --- the next 16 bytes ride on a second scalar load
     int live_bx1, live_by1;
     int src_w, src_h;
+    // --- 40 bytes the gain-applying instantiation of K1 fetches with two more scalar loads, together with the first
+    const float* gain;    // [gh][gw] block gains (BlocksGainCompensator::apply) or nullptr
+    // per 16-row block row of K1: the first of the (at most kGainRows) consecutive rows of ghrow that its 16 tile rows read, or -1
+    // when they span more (a map finer than the blocks): K1 stages those rows' 64 columns in LDS once per workgroup
+    const int* grow_base;
+    // optional exposure gain: cv::resize(INTER_LINEAR) of the block map on the fly.  The horizontal pass is a table -
+    // ghrow[gy][x] = S[gy][sx] * (1 - fx) + S[gy][sx1] * fx for every map row gy and tile column x (REFLECT folded like
+    // colA) - so a pixel needs two coalesced reads and the vertical pass h0 * (1 - fy) + h1 * fy
+    const float* ghrow;   // [gh][ghrow_pitch]
+    const int4* grow4;    // [th] {sy0, sy1, bits of 1-fy, bits of fy}: grow and groww in one 16-byte entry per tile row
+    int ghrow_pitch;      // floats per row, a multiple of 4; columns past tw repeat the last one
+    int gh;               // rows of ghrow
     // --- everything else
-    // static remap table (frames up to 2048 x 2048): one dword per tile pixel, see build_warp_lut_kernel
+    // static remap table: one dword per tile pixel, see build_warp_table_kernel
     const uint32_t* lut;  // dense form, read where the packed form escapes; nullptr -> project on the fly
     int lut_pitch;        // dwords per row of lut (multiple of 8)
-    const float* gain;    // [gh][gw] block gains (BlocksGainCompensator::apply) or nullptr
     float m[9];           // k_rinv = K * R^-1 (Projector::k_rinv)
     const float2* colA;   // [tw] {sin(u/s), cos(u/s)} with the REFLECT border of feed() folded in
     const float2* rowB;   // [th] {sin(pi - v/s) | 1, cos(pi - v/s) | v/s}
     const FrontEndDev* fe; // nullptr, or the undistort front end: src is then the RAW frame (src_w x src_h raw)
     int out_w, out_h;     // the stitcher's frame size (mask warp inside test); == src_w x src_h without a front end
-    // optional exposure gain: cv::resize(INTER_LINEAR) of the block map on the fly.  The horizontal pass is a table -
-    // ghrow[gy][x] = S[gy][sx] * (1 - fx) + S[gy][sx1] * fx for every map row gy and tile column x (REFLECT folded like
-    // colA) - so a pixel needs two coalesced reads and the vertical pass h0 * (1 - fy) + h1 * fy
-    const float* ghrow;   // [gain_h][ghrow_pitch]
-    int ghrow_pitch;      // floats per row, a multiple of 4; columns past tw repeat the last one
     const int2* grow;     // [th] {sy0, sy1}
     const float2* groww;  // [th] {1-fy, fy}
     int gw;
 };
+constexpr int kGainRows = 4;
 inline int warp_pack_live(int live_by0, int gap_bx0, int gap_len) { return live_by0 | gap_bx0 << 12 | (int)((unsigned)gap_len << 22); }
 struct WarpParams {
     WarpCam cam[kCams];

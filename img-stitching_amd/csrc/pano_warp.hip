@@ -485,6 +485,9 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_checked_kernel(WarpParams 
 template <bool GAIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void warp_tiles_lut_kernel(WarpParams P) {
     __shared__ uint4 sbox[kBoxBytes / 16];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    // GAIN: the workgroup's 64 columns of up to kGainRows rows of ghrow, then its 16 row entries {sy0, sy1, 1 - fy, fy} (as bits)
+    __shared__ f32x4 sgain[GAIN ? kGainRows * 16 + 16 : 1];
     // grid = (ncam, ceil(tw/64), ceil(th/16)): the camera is the FASTEST workgroup coordinate.  Linear workgroup ids
     // are dealt round-robin over the 8 XCDs (each with its own L2), so with 8 (or 4, 2) cameras an XCD's L2 only ever
     // holds one camera's frame, and every camera still advances top to bottom with all XCDs busy.  Measured on the
@@ -507,7 +510,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // WarpParams is the only kernel argument: P.cam[i] sits at kernarg + i * sizeof(WarpCam)
     const char __attribute__((address_space(4)))* ka =
         (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.x * sizeof(WarpCam);
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hot.v) : "s"(ka) : "memory");
+    // GAIN: the camera's gain block {gain, grow_base, ghrow, grow4 | ghrow_pitch, gh} rides along (two more scalar loads in
+    // flight with the first), so that the workgroup's gain rows can be requested together with its source box
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    struct GainBlk {
+        const float* gain; const int* grow_base; const float* ghrow; const void* grow4;
+    };
+    union { i32x8 v; GainBlk g; } gq;
+    i32x2 gq2 = {0, 0};  // {ghrow_pitch, gh}
+    gq.v = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (GAIN) {
+        static_assert(sizeof(GainBlk) == 32 && offsetof(WarpCam, gain) == 80 && offsetof(WarpCam, grow_base) == 88 && offsetof(WarpCam, ghrow) == 96 &&
+                          offsetof(WarpCam, grow4) == 104 && offsetof(WarpCam, ghrow_pitch) == 112 && offsetof(WarpCam, gh) == 116, "gain block layout");
+        asm volatile("s_load_dwordx8 %0, %2, 0x50\n\ts_load_dwordx2 %1, %2, 0x70" : "=s"(gq.v), "=s"(gq2) : "s"(ka) : "memory");
+        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hot.v), "+s"(gq.v), "+s"(gq2) : "s"(ka) : "memory");
+    } else {
+        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hot.v) : "s"(ka) : "memory");
+    }
     // the camera block as a plain pointer for the rare out-of-line paths (a reference to the by-value kernel argument
     // would make the compiler copy all of WarpParams to scratch)
     const WarpCam* const cg = (const WarpCam*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.x * sizeof(WarpCam));
@@ -549,7 +569,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     u32x2 e = u32x2{0u, 0u};
     if (active)  // 32-bit byte offset: scalar base + vector offset addressing, no 64-bit multiply
         e = *reinterpret_cast<const u32x2 PANO_GLOBAL*>((const uint8_t PANO_GLOBAL*)lutc + (((unsigned)y * lutc_pitch + (unsigned)(x0 >> 2)) << 3));
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bb), "+s"(live) : : "memory");  // bb, live are only valid past this point
+    // Exposure gains (GAIN instantiation; per camera, workgroup-uniform).  BlocksGainCompensator::apply resizes the block map to
+    // the tile (cv::resize INTER_LINEAR, f32): the horizontal pass is a table (ghrow: map rows x tile columns), the vertical pass
+    // g = h0 * (1 - fy) + h1 * fy is done here.  Fetched per lane that was four more vector loads per wave (two per-row entries,
+    // two 16-byte map reads: 8 bytes of L2 traffic per pixel for 3 bytes of output) in a kernel whose waves issue six - config
+    // 4 ran 76 us with gains against 59 without.  A 16-row patch reads the same two or three rows of ghrow in every one of its
+    // rows (a block is 32 pixels high), so the workgroup copies its 64 columns of those rows (1 KB) and its 16 row entries
+    // (256 B) into LDS with ONE vector load in each of two waves, and every lane reads its row entry and four gains from there.
+    const bool gains = GAIN && gq.g.gain != nullptr;
+    int gbase = -1;
+    if (gains) {
+        // workgroup-uniform: a scalar load, spelled out (left to the compiler it became a vector load with a wait behind it),
+        // in flight together with the loads of `live` and the source box above
+        const char __attribute__((address_space(4)))* gbp = (const char __attribute__((address_space(4)))*)gq.g.grow_base + (unsigned)by * 4u;
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(gbase) : "s"(gbp) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bb), "+s"(live), "+s"(gbase) : : "memory");  // bb, live, gbase are only valid past this point
     if (bx > live.x || by > live.y) return;  // beyond this camera's live blocks (workgroup-uniform)
     const int src_w = live.z, src_h = live.w;
     const int bh = bb.z >> 8, cpr = bb.z & 255;
@@ -558,6 +593,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     const unsigned lo16 = (unsigned)(size_t)hot.h.src & 15u;
     const unsigned og = (unsigned)bb.y * stride + 3u * (unsigned)bb.x + lo16;  // from the 16-byte boundary below src
     const unsigned ph = og & 15u;
+    // the workgroup's gain rows and row entries: requested BEFORE the box copy so that one wait covers both (behind it they
+    // were a second round trip in front of the barrier: 9 us of a 75 us launch)
+    f32x4 gstage = {0.f, 0.f, 0.f, 0.f};
+    if (GAIN && gbase >= 0 && tid < kGainRows * 16 + 16) {
+        // lane t < 64: row gbase + t / 16 of ghrow, columns 64 bx + 4 (t % 16) .. + 3 (the table's rows end on a multiple of
+        // four columns: a chunk past the end repeats the last one - only inactive lanes would read it); lanes 64 .. 79: the row
+        // entries of tile rows 16 by .. 16 by + 15.  One load instruction for both
+        const unsigned gp = (unsigned)gq2.x;
+        const unsigned row = (unsigned)min(gbase + (tid >> 4), gq2.y - 1), c4 = min((unsigned)(bx * 16 + (tid & 15)), (gp >> 2) - 1u);
+        const unsigned ry = (unsigned)min(by * 16 + tid - kGainRows * 16, th - 1);
+        const char PANO_GLOBAL* a = tid < kGainRows * 16 ? (const char PANO_GLOBAL*)gq.g.ghrow + ((row * gp + c4 * 4u) << 2)
+                                                         : (const char PANO_GLOBAL*)gq.g.grow4 + (ry << 4);
+        gstage = *reinterpret_cast<const f32x4 PANO_GLOBAL*>(a);
+    }
     if (bh) {
         // chunk k = tid + 256 * it -> (row r = k / cpr, column ci = k % cpr), copied by global_load_lds_dwordx4: the 64
         // lanes of a wave write 64 consecutive 16-byte chunks at M0 - no staging registers, no ds_write.  Whole
@@ -578,9 +627,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
+    if (GAIN && gbase >= 0 && tid < kGainRows * 16 + 16) sgain[tid] = gstage;
+    if (bh || (GAIN && gbase >= 0)) __syncthreads();  // workgroup-uniform
     if (!active) return;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x4 gh0 = {0.f, 0.f, 0.f, 0.f}, gh1 = gh0;
+    float2 gby = make_float2(0.f, 0.f);
+    if (gains) {
+        if (gbase >= 0) {  // the lane's row entry and the four columns of its two map rows, from the workgroup's copy
+            const f32x4 re = sgain[kGainRows * 16 + threadIdx.y * 4 + (threadIdx.x >> 4)];
+            gby = make_float2(re.z, re.w);
+            gh0 = sgain[(__float_as_int(re.x) - gbase) * 16 + (int)(threadIdx.x & 15)];
+            gh1 = sgain[(__float_as_int(re.y) - gbase) * 16 + (int)(threadIdx.x & 15)];
+        } else {           // a map too fine for that (more than kGainRows rows per patch): everything per lane from global memory
+            const int2 gy = cg->grow[y];
+            gby = cg->groww[y];
+            const float PANO_GLOBAL* gr = (const float PANO_GLOBAL*)gq.g.ghrow;
+            const unsigned gp = (unsigned)gq2.x;
+            gh0 = *reinterpret_cast<const f32x4 PANO_GLOBAL*>(gr + ((unsigned)gy.x * gp + (unsigned)x0));
+            gh1 = *reinterpret_cast<const f32x4 PANO_GLOBAL*>(gr + ((unsigned)gy.y * gp + (unsigned)x0));
+        }
+    }
     uint8_t PANO_GLOBAL* d = dst + ((unsigned)y * dst_pitch + (unsigned)x0);  // 32-bit offsets: a tile is far below 4 GB
     unsigned X[4], Y[4];
     {
@@ -644,22 +712,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 #pragma unroll
     for (int j = 0; j < 4; j++) bilinear_b2(t[j], u[j], X[j] & 31u, Y[j] & 31u, r[j]);
     unsigned pk[3];
-    if (GAIN && cg->gain != nullptr) {  // per camera: workgroup-uniform
-        // the gains of the lane's four pixels: two 16-byte reads of the horizontally resized map rows, then the vertical pass
-        const int2 gy = cg->grow[y];
-        const float2 by = cg->groww[y];
-        const int gp = cg->ghrow_pitch;
-        const float4 h0 = *reinterpret_cast<const float4*>(cg->ghrow + (unsigned)(gy.x * gp + x0));
-        const float4 h1 = *reinterpret_cast<const float4*>(cg->ghrow + (unsigned)(gy.y * gp + x0));
-        const float g[4] = {h0.x * by.x + h1.x * by.y, h0.y * by.x + h1.y * by.y, h0.z * by.x + h1.z * by.y, h0.w * by.x + h1.w * by.y};
+    if (gains) {
+        // VResizeLinear: g = h0 * (1 - fy) + h1 * fy, two pixels per instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE per half, no
+        // contraction - the same three roundings as the scalar expression)
+        const f32x2 b0 = {gby.x, gby.x}, b1 = {gby.y, gby.y};
+        const f32x2 g01 = f32x2{gh0.x, gh0.y} * b0 + f32x2{gh1.x, gh1.y} * b1;
+        const f32x2 g23 = f32x2{gh0.z, gh0.w} * b0 + f32x2{gh1.z, gh1.w} * b1;
         // saturate_cast<uchar>(px * gain) = round-half-even + clamp is what v_cvt_pk_u8_f32 does, and it drops the byte
-        // where the plane dword wants it: three instructions per value (v_cvt_f32_ubyte2, v_mul_f32, v_cvt_pk_u8_f32)
+        // where the plane dword wants it: v_cvt_f32_ubyte2 per value, one v_pk_mul_f32 per two, v_cvt_pk_u8_f32 per value
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            pk[ch] = 0u;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                pk[ch] = __builtin_amdgcn_cvt_pk_u8_f32((float)((r[j][ch] >> 16) & 0xffu) * g[j], (unsigned)j, pk[ch]);
+            const f32x2 p01 = f32x2{(float)((r[0][ch] >> 16) & 0xffu), (float)((r[1][ch] >> 16) & 0xffu)} * g01;
+            const f32x2 p23 = f32x2{(float)((r[2][ch] >> 16) & 0xffu), (float)((r[3][ch] >> 16) & 0xffu)} * g23;
+            pk[ch] = __builtin_amdgcn_cvt_pk_u8_f32(p01.x, 0u, 0u);
+            pk[ch] = __builtin_amdgcn_cvt_pk_u8_f32(p01.y, 1u, pk[ch]);
+            pk[ch] = __builtin_amdgcn_cvt_pk_u8_f32(p23.x, 2u, pk[ch]);
+            pk[ch] = __builtin_amdgcn_cvt_pk_u8_f32(p23.y, 3u, pk[ch]);
         }
     } else {
 #pragma unroll

@@ -33,3 +33,16 @@ def c4_rig(w=3840, h=2160, f=3534.0):
     """config 4: 4 x 4K, cylindrical, same yaws"""
     d = c2_group(w, h, f)
     return d
+
+
+def c4_gain_map(gw, gh, seed):
+    """a smooth field of block gains in [0.8, 1.25] - a 5 x 4 grid of seeded values, bilinearly
+    interpolated to the gw x gh blocks of BlocksGainCompensator (32 x 32-pixel blocks of the warped tile)"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    coarse = rng.random((4, 5))
+    ys = np.linspace(0, 3, gh)[:, None]; xs = np.linspace(0, 4, gw)[None, :]
+    y0 = np.minimum(ys.astype(int), 2); x0 = np.minimum(xs.astype(int), 3)
+    fy = ys - y0; fx = xs - x0
+    f = (coarse[y0, x0] * (1 - fy) * (1 - fx) + coarse[y0, x0 + 1] * (1 - fy) * fx
+         + coarse[y0 + 1, x0] * fy * (1 - fx) + coarse[y0 + 1, x0 + 1] * fy * fx)
+    return (0.8 + 0.45 * f).astype(np.float32)

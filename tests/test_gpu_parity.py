@@ -278,8 +278,8 @@ def test_c4_cylindrical_7_bands_properties(pano, po):
 
 
 def test_c4_full_size_bit_exact(pano, po):
-    """config 4 at full size (4 x 3840x2160, cylindrical, 7 bands, block gains; the projecting K1 variant because
-    the frames exceed the remap table's 2048 limit) against the oracle"""
+    """config 4 at full size (4 x 3840x2160, cylindrical, 7 bands, block gains: the table form of K1 with box-relative codes,
+    gain-applying instantiation) against the oracle"""
     d = c4_rig()
     rng = np.random.default_rng(11)
     frames = [synth_frame(3840, 2160, 7 + i) for i in range(4)]
