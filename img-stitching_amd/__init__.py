@@ -90,7 +90,7 @@ EXPORTS = [
     "pano_build_masks_voronoi", "pano_build_masks_graphcut", "pano_refresh_masks_begin", "pano_refresh_masks_poll", "pano_refresh_masks_wait", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
     "pano_compose_host", "pano_host_alloc", "pano_host_free", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_feed_cameras_host", "pano_blend_host", "pano_rccl_unique_id", "pano_rccl_comm_create", "pano_rccl_comm_destroy", "pano_gather_slots", "pano_rccl_comm_count", "pano_rccl_library", "pano_stack_master", "pano_stack_finalcut", "pano_stack_master_host", "pano_stack_finalcut_host", "pano_stream_input", "pano_stream_output",
     "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
-    "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_get_live_rect", "pano_get_live_gap", "pano_get_warp_table_stats", "pano_debug_get_level", "pano_debug_get_weights",
+    "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_get_live_rect", "pano_get_source_rect", "pano_get_live_gap", "pano_get_warp_table_stats", "pano_debug_get_level", "pano_debug_get_weights",
     "pano_debug_get_canvas_weights", "pano_debug_get_canvas",
 ]
 
@@ -442,6 +442,12 @@ class Context:
     def warp_bytes(self):
         a = C.c_uint64(); b = C.c_uint64()
         self._ck(self.lib.pano_get_warp_bytes(self.h, C.byref(a), C.byref(b))); return a.value, b.value
+
+    def source_rect(self, i):
+        """(byte x0, row y0, byte width, rows) of camera i's frame that the warp reads with the present masks: what the host
+        entries upload"""
+        r = (C.c_int * 4)()
+        self._ck(self.lib.pano_get_source_rect(self.h, int(i), r)); return tuple(r)
 
     def live_rect(self, i, level):
         r = (C.c_int * 4)()

@@ -91,6 +91,11 @@ struct pano_ctx {
     uint2* lutc[kMaxCams] = {};         // packed form of lut (8 bytes per 4 pixels), read by unflagged workgroups
     int4* box[kMaxCams] = {};           // source box of every 64x16-pixel workgroup of K1
     long long box_global[kMaxCams] = {}; // workgroups whose box does not fit LDS (global taps)
+    std::vector<int4> h_box[kMaxCams];   // host copy of box[]: which frame bytes each K1 workgroup reads (static)
+    // The frame bytes K1 reads with the present masks: byte columns [x0, x0 + w) of rows [y0, y0 + rows), x0 and w multiples of
+    // 64 (a rectangular DMA runs at the link rate only when aligned: 50 GB/s against 5).  The host entries upload nothing else
+    struct SrcRect { int x0, y0, w, rows; };
+    SrcRect src_rect[kMaxCams] = {};
     uint32_t* k1_flags[kMaxCams] = {};  // per K1 workgroup: the table holds marked pixels there
     long long k1_blocks[kMaxCams] = {}, k1_flagged[kMaxCams] = {};
     bool use_lut = true;
@@ -359,6 +364,7 @@ WarpCam make_warp_cam(const pano_ctx* c, int i, const uint8_t* src, size_t strid
 // of u) whose mask lives at the two ends.  The need sets are unions over the mask's support (w_l is linear in the mask),
 // so the mask is cut at its widest run of empty columns (>= kMinDeadColumns) into two pieces, each piece gets its own
 // chain of rectangles, and per level the columns between the two are recorded as the dead gap K1 / K2 step over.
+static void live_source_rects(pano_ctx* c);
 static void live_rects(pano_ctx* c, const std::vector<std::vector<uint8_t>>& masks) {
     constexpr int kMinDeadColumns = 256;
     const Plan& P = c->plan;
@@ -449,8 +455,54 @@ static void live_rects(pano_ctx* c, const std::vector<std::vector<uint8_t>>& mas
             for (int k = 0; k < 4; k++) c->pyr.cam[i].live[l][k] = c->live[i][l][k];
             for (int k = 0; k < 2; k++) c->pyr.cam[i].gap[l][k] = c->gap[i][l][k];
         }
+    live_source_rects(c);
 }
 
+
+// Which bytes of camera i's frame does K1 read?  The table is static, so every 64 x 16 workgroup's source box is (h_box), and the
+// masks say which workgroups run (make_warp_cam: the live blocks of level 0 minus the dead middle of a +-pi straddler).  The
+// union of the live boxes, widened to the bytes the copies and taps really touch: an LDS box copies `chunks` 16-byte pieces per
+// row from the 16-byte boundary at or below its first byte; a patch on global taps fetches the aligned 12 bytes around each tap
+// (3 bytes before it at most) in rows ys and ys + 1.  The staging buffers are 64-byte aligned with 64-byte pitches, so byte
+// columns are frame columns.  No table (projecting kernel): the whole frame.
+static void live_source_rects(pano_ctx* c) {
+    const Plan& P = c->plan;
+    const int row_bytes = c->frame_w * 3;
+    for (int i = 0; i < P.n; i++) {
+        pano_ctx::SrcRect& r = c->src_rect[i];
+        r = {0, 0, (int)align_up((size_t)row_bytes, 64), c->frame_h};
+        if (!c->use_lut || c->h_box[i].empty()) continue;
+        const WarpCam w = make_warp_cam(c, i, nullptr, (size_t)row_bytes, false);
+        const int nbx = (P.tile[i].rect.w + 63) / 64, nby = (P.tile[i].rect.h + 15) / 16;
+        const unsigned lg = (unsigned)w.live_by0_gap;
+        const int by0 = (int)(lg & 0xfffu), g0 = (int)((lg >> 12) & 0x3ffu), glen = (int)(lg >> 22);
+        int x0 = INT_MAX, x1 = -1, y0 = INT_MAX, y1 = -1;
+        for (int by = by0; by <= std::min(w.live_by1, nby - 1); by++)
+            for (int bx = w.live_bx0; bx <= std::min(w.live_bx1, nbx - 1); bx++) {
+                if (bx >= g0 && bx < g0 + glen) continue;
+                const int4 b = c->h_box[i][(size_t)by * nbx + bx];
+                int bx0, bx1, by1;
+                if (b.z >> 8) {
+                    bx0 = (3 * b.x) & ~15;
+                    bx1 = bx0 + (b.z & 255) * 16 + 16;  // + a fetch of the general kernel's global taps on the box's last pixel
+                    by1 = b.y + (b.z >> 8);
+                } else {
+                    bx0 = std::max(3 * b.x - 3, 0);
+                    bx1 = 3 * (b.x + (b.w >> 16)) + 12;
+                    by1 = std::min(b.y + (b.w & 0xffff) + 2, c->frame_h);
+                }
+                x0 = std::min(x0, bx0); x1 = std::max(x1, bx1);
+                y0 = std::min(y0, b.y); y1 = std::max(y1, by1);
+            }
+        if (x1 < 0) { r = {0, 0, 0, 0}; continue; }  // nothing live: nothing to upload
+        // a fetch near the end of a row may run into the first bytes of the next one: then whole rows
+        y0 = std::max(y0, 0); y1 = std::min(y1, c->frame_h);
+        x0 &= ~63;
+        x1 = (int)align_up((size_t)x1, 64);
+        if (x1 > row_bytes) { x0 = 0; x1 = (int)align_up((size_t)row_bytes, 64); }
+        r = {x0, y0, x1 - x0, y1 - y0};
+    }
+}
 
 // cv::resize INTER_LINEAR (f32) coefficients of dst index d for ssize -> dsize
 inline void linear_coef(int d, int ssize, int dsize, int& s0, int& s1, float& a0, float& a1) {
@@ -1223,6 +1275,8 @@ static pano_status prepare_impl(pano_ctx* c) {
             HIP_TRY(c, ce);
             c->box_global[i] = h_cnt[0];
             too_wide |= h_cnt[1] != 0;
+            c->h_box[i].resize(nb);
+            HIP_TRY(c, hipMemcpy(c->h_box[i].data(), c->box[i], nb * sizeof(int4), hipMemcpyDeviceToHost));
             const int gp = c->lut_pitch[i] / 4;
             HIP_TRY(c, hipMalloc((void**)&c->k1_flags[i], nb * sizeof(uint32_t)));
             HIP_TRY(c, hipMemset(c->k1_flags[i], 0, nb * sizeof(uint32_t)));
@@ -1236,7 +1290,7 @@ static pano_status prepare_impl(pano_ctx* c) {
         }
         if (too_wide) {
             // a 64 x 16 patch that spans 2048 source pixels (a projection that magnifies 32 x): no table for this rig
-            for (int i = 0; i < n; i++) { dfree(c->lut[i]); dfree(c->lutc[i]); dfree(c->box[i]); dfree(c->k1_flags[i]); }
+            for (int i = 0; i < n; i++) { dfree(c->lut[i]); dfree(c->lutc[i]); dfree(c->box[i]); dfree(c->k1_flags[i]); c->h_box[i].clear(); }
             c->use_lut = false;
         }
         HIP_TRY(c, hipDeviceSynchronize());
@@ -2038,8 +2092,9 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
     if (!h_frames || !strides || !h_out) return PANO_EINVAL;
     const Plan& P = c->plan;
     const size_t row_in = (size_t)c->frame_w * 3, row_out = (size_t)P.cut.w * 3;
-    // tight pitches (K1 wants strides % 16 == 0): a caller stride of width*3 makes every copy one linear transfer
-    const size_t in_pitch = align_up(row_in, 16), out_pitch = align_up(row_out, 16);
+    // staging pitches: multiples of 64 bytes (K1 wants strides % 16 == 0; a rectangular DMA runs at the link rate only on
+    // 64-byte boundaries), equal to width * 3 for the usual frame widths: a caller stride of width*3 then needs no staging
+    const size_t in_pitch = align_up(row_in, 64), out_pitch = align_up(row_out, 16);
     for (int i = 0; i < P.n; i++)
         if (!h_frames[i] || strides[i] < row_in) return PANO_EINVAL;
     if (out_stride < row_out) return PANO_EINVAL;
@@ -2103,25 +2158,39 @@ static pano_status compose_host_impl(pano_ctx* c, const uint8_t* const* h_frames
     } wait_all{pool, staged};
     const uint8_t* dma_src[kMaxCams];
     bool any_staged = false;
+    // Only the bytes K1 reads cross the link (src_rect: with the masks of config 2, 70 % of a frame): byte columns [x0, x0 + w) of
+    // rows [y0, y0 + rows), one rectangular DMA per camera - at the link rate, because x0, w and both pitches are multiples of 64
+    // (misaligned rectangles run at a tenth of it, tools/pcie_2d.py).  The rest of the device frame keeps whatever it held.
     for (int i = 0; i < P.n; i++) {
         dma_src[i] = h_frames[i];
-        // direct DMA only when it is ONE linear transfer: rectangular copies with odd row lengths run at a fraction of the
-        // link rate (1.3 GB/s measured for 11679-byte rows), slower than staging them
-        if (strides[i] != in_pitch || !is_pinned_host(h_frames[i], strides[i] * (size_t)(c->frame_h - 1) + row_in)) {
+        const pano_ctx::SrcRect& r = c->src_rect[i];
+        const size_t wcopy = std::min((size_t)r.w, row_in - (size_t)r.x0);  // the frame's own bytes of those columns
+        // direct DMA from page-locked caller memory whose rows sit on the staging grid; anything else is staged
+        if (strides[i] != in_pitch || ((size_t)h_frames[i] & 63) || !is_pinned_host(h_frames[i], strides[i] * (size_t)(c->frame_h - 1) + row_in)) {
             if (!c->pin_in[i] || c->pin_in_pitch != in_pitch) {
                 HIP_TRY(c, hipStreamSynchronize(up));
                 if (c->pin_in[i]) (void)hipHostFree(c->pin_in[i]);
                 c->pin_in[i] = nullptr;
                 HIP_TRY(c, hipHostMalloc((void**)&c->pin_in[i], in_pitch * c->frame_h, hipHostMallocDefault));
             }
-            pool.submit(staged[i], c->pin_in[i], in_pitch, h_frames[i], strides[i], row_in, c->frame_h);
+            if (r.rows > 0)
+                pool.submit(staged[i], c->pin_in[i] + (size_t)r.y0 * in_pitch + r.x0, in_pitch, h_frames[i] + (size_t)r.y0 * strides[i] + r.x0,
+                            strides[i], wcopy, r.rows);
             dma_src[i] = c->pin_in[i];
             any_staged = true;
         }
     }
     for (int i = 0; i < P.n; i++) {
         pool.wait(staged[i]);
-        HIP_TRY(c, hipMemcpyAsync(c->stage_in[i], dma_src[i], in_pitch * (size_t)(c->frame_h - 1) + row_in, hipMemcpyHostToDevice, up));
+        const pano_ctx::SrcRect& r = c->src_rect[i];
+        if (r.rows > 0) {
+            const size_t off = (size_t)r.y0 * in_pitch + r.x0;
+            if ((size_t)r.w >= in_pitch)  // whole rows: one linear transfer
+                HIP_TRY(c, hipMemcpyAsync(c->stage_in[i] + off, dma_src[i] + off, in_pitch * (size_t)(r.rows - 1) + row_in, hipMemcpyHostToDevice, up));
+            else
+                HIP_TRY(c, hipMemcpy2DAsync(c->stage_in[i] + off, in_pitch, dma_src[i] + off, in_pitch, (size_t)r.w, (size_t)r.rows,
+                                            hipMemcpyHostToDevice, up));
+        }
         frames[i] = c->stage_in[i];
         pitches[i] = in_pitch;
     }
@@ -2350,7 +2419,17 @@ pano_status pano_stream_submit(pano_ctx* c, int slot) {
     const uint8_t* frames[kMaxCams];
     size_t pitches[kMaxCams];
     for (int i = 0; i < P.n; i++) {
-        HIP_TRY(c, hipMemcpyAsync(sl.d_in[i], sl.h_in[i], c->slot_in_pitch * c->frame_h, hipMemcpyHostToDevice, sl.h2d));
+        // only the bytes K1 reads with the present masks cross the link: one aligned rectangular DMA (see pano_compose_host)
+        const pano_ctx::SrcRect& r = c->src_rect[i];
+        if (r.rows > 0) {
+            const size_t off = (size_t)r.y0 * c->slot_in_pitch + r.x0;
+            if ((size_t)r.w >= c->slot_in_pitch || (size_t)r.w >= align_up((size_t)c->frame_w * 3, 64))
+                HIP_TRY(c, hipMemcpyAsync(sl.d_in[i] + (size_t)r.y0 * c->slot_in_pitch, sl.h_in[i] + (size_t)r.y0 * c->slot_in_pitch,
+                                          c->slot_in_pitch * (size_t)r.rows, hipMemcpyHostToDevice, sl.h2d));
+            else
+                HIP_TRY(c, hipMemcpy2DAsync(sl.d_in[i] + off, c->slot_in_pitch, sl.h_in[i] + off, c->slot_in_pitch, (size_t)r.w, (size_t)r.rows,
+                                            hipMemcpyHostToDevice, sl.h2d));
+        }
         frames[i] = sl.d_in[i];
         pitches[i] = c->slot_in_pitch;
     }
@@ -2407,7 +2486,7 @@ static pano_status feed_cameras_host_impl(pano_ctx* c, unsigned cam_bits, const 
     if (!h_frames || !strides) return PANO_EINVAL;
     const Plan& P = c->plan;
     cam_bits &= (1u << P.n) - 1u;
-    const size_t row_in = (size_t)c->frame_w * 3, in_pitch = align_up(row_in, 16);
+    const size_t row_in = (size_t)c->frame_w * 3, in_pitch = align_up(row_in, 64);  // the staging grid of pano_compose_host
     if (!c->stage_in[0] || c->stage_in_pitch != in_pitch) {
         HIP_TRY(c, hipDeviceSynchronize());
         for (int i = 0; i < P.n; i++) {
@@ -2421,8 +2500,10 @@ static pano_status feed_cameras_host_impl(pano_ctx* c, unsigned cam_bits, const 
     for (int i = 0; i < P.n; i++) {
         if (!((cam_bits >> i) & 1u)) continue;
         if (!h_frames[i] || strides[i] < row_in) return PANO_EINVAL;
-        HIP_TRY(c, hipMemcpy2DAsync(c->stage_in[i], in_pitch, h_frames[i], strides[i], row_in, c->frame_h, hipMemcpyHostToDevice,
-                                    c->own_stream));
+        const pano_ctx::SrcRect& r = c->src_rect[i];  // only the bytes K1 reads (see pano_compose_host)
+        if (r.rows > 0)
+            HIP_TRY(c, hipMemcpy2DAsync(c->stage_in[i] + (size_t)r.y0 * in_pitch + r.x0, in_pitch, h_frames[i] + (size_t)r.y0 * strides[i] + r.x0,
+                                        strides[i], std::min((size_t)r.w, row_in - (size_t)r.x0), (size_t)r.rows, hipMemcpyHostToDevice, c->own_stream));
         frames[i] = c->stage_in[i];
         pitches[i] = in_pitch;
     }
@@ -2606,6 +2687,13 @@ pano_status pano_get_warp_table_stats(const pano_ctx* c, uint64_t* table_bytes, 
     *table_bytes = g;
     *blocks = nb;
     *blocks_checked = nf;
+    return PANO_OK;
+}
+
+pano_status pano_get_source_rect(const pano_ctx* c, int i, int rect[4]) {
+    if (!c || !c->prepared || !rect || i < 0 || i >= c->plan.n) return PANO_EINVAL;
+    const pano_ctx::SrcRect& r = c->src_rect[i];
+    rect[0] = r.x0; rect[1] = r.y0; rect[2] = r.w; rect[3] = r.rows;
     return PANO_OK;
 }
 

@@ -280,7 +280,7 @@ __device__ __forceinline__ void lut_axis(int i0, int n, int frac, int& base, int
 //   * K1 copies the box into LDS and reads the taps there (see warp_tiles_lut_kernel).
 // Box entry: {xmin, ymin, rows << 8 | 16-byte chunks per row, ceil(2^16 / chunks)}.  Boxes that do not fit kBoxBytes (far
 // outside the frame, where BORDER_REFLECT folds pile up) or that would read past the last bytes of the frame get
-// rows == 0 and tap global memory instead; the origin is valid either way.
+// rows == 0 (and their extent in the fourth word) and tap global memory instead; the origin is valid either way.
 constexpr int kBoxBytes = 16 * 1024;             // LDS per workgroup, one spare row included
 constexpr int kBoxIters = kBoxBytes / 16 / 256;  // 16-byte chunk loads per lane, at most
 __global__ __launch_bounds__(256) void build_warp_table_kernel(WarpCam c, uint32_t* lut, int lut_pitch, int4* boxes, int gx,
@@ -335,7 +335,10 @@ __global__ __launch_bounds__(256) void build_warp_table_kernel(WarpCam c, uint32
     // the chunks of the last frame row must end inside the frame
     ok &= !(ymin + h - 1 == sh - 1 && 3 * xmin + cpr * 16 > 3 * sw);
     if (!ok) atomicAdd(&counters[0], 1u);
-    boxes[blockIdx.y * gx + blockIdx.x] = ok ? make_int4(xmin, ymin, (h << 8) | cpr, (65536 + cpr - 1) / cpr) : make_int4(xmin, ymin, 0, 0);
+    // a box without LDS carries its extent instead (x span << 16 | y span): what the host needs to know which frame bytes
+    // the patch's global taps can touch (live_source_rects in pano_api.cpp)
+    boxes[blockIdx.y * gx + blockIdx.x] = ok ? make_int4(xmin, ymin, (h << 8) | cpr, (65536 + cpr - 1) / cpr)
+                                             : make_int4(xmin, ymin, 0, (min(lim[1] - xmin, 32767) << 16) | min(lim[3] - ymin, 65535));
 }
 void launch_build_warp_table(const WarpCam& c, uint32_t* lut, int lut_pitch, int4* boxes, unsigned* counters, hipStream_t s) {
     dim3 block(64, 4, 1), grid((lut_pitch + 63) / 64, (c.th + 15) / 16, 1);

@@ -315,6 +315,13 @@ pano_status pano_get_warp_table_stats(const pano_ctx* ctx, uint64_t* table_bytes
 
 /* ---- stage inspection (parity tests) ------------------------------------------------------- */
 /* Gaussian level `level` of camera i's bordered tile, int16 x3 interleaved, tight rows */
+/* The bytes of camera i's frame that the warp reads with the present masks: byte columns [rect[0], rect[0] + rect[2]) of rows
+ * [rect[1], rect[1] + rect[3]), columns on 64-byte boundaries.  The remap table is static (fixed K / R), so every 64 x 16 patch of
+ * the warp taps a fixed box of the frame, and the masks say which patches anything downstream reads: pano_compose_host,
+ * pano_feed_cameras_host and pano_stream_submit upload this rectangle and nothing else (config 2: 70 % of a frame); a capture
+ * pipeline that fills pano_stream_input buffers need not write the rest either.  Recomputed whenever the masks change.
+ * Replaces nothing in the reference, which uploads whole frames inside every warp call (include/ocvstitcher.hpp:1171). */
+pano_status pano_get_source_rect(const pano_ctx* ctx, int i, int rect[4]);
 /* The part {x, y, w, h} of camera i's bordered tile at pyramid `level` that the library produces.
  * MultiBandBlender::feed (ocvstitcher.hpp:1202) weighs every Laplacian with the camera's weight pyramid, which is zero
  * away from the camera's blend mask; pixels of the tile that neither carry weight nor feed - through pyrDown / pyrUp -

@@ -1144,3 +1144,48 @@ def test_paced_60fps_stream(pano, po):
     assert r["dropped"] == 0 and r["frames_composed"] == 60, r
     assert r["sampled_frames_equal_oracle"] is True, r
     assert r["achieved_fps"] > 55.0, r
+
+
+def test_host_entries_upload_only_what_the_warp_reads(pano, po):
+    """pano_get_source_rect: with masks set, the host entries (pano_compose_host, pano_stream_submit) upload only the frame bytes
+    the warp's live patches tap.  Proof that nothing outside that rectangle is ever read: frames whose bytes OUTSIDE it are
+    garbage give the oracle's panorama of the clean frames, through both entries; and the rectangle really is smaller than the
+    frame (config 2 geometry: each camera keeps about 70 % of its columns)"""
+    d = c2_group(w=960, h=540, f=501.2)
+    clean = [synth_frame(960, 540, 300 + i) for i in range(4)]
+    ctx = make_ctx(pano, d, 0, num_bands=4)
+    full = [ctx.source_rect(i) for i in range(4)]
+    assert all(r == (0, 0, 2880, 540) for r in full)            # no masks yet: every patch is live, whole frames
+    ctx.build_masks_voronoi()
+    masks = [ctx.get_mask(i) for i in range(4)]
+    want, _ = po.compose(clean, d["K"], d["R"], d["scale"], masks, 4)
+    assert np.array_equal(ctx.compose_host(clean), want)        # the first frame after new masks: weights rebuilt, rects shrink
+    rects = [ctx.source_rect(i) for i in range(4)]
+    share = sum(r[2] * r[3] for r in rects) / (4 * 2880 * 540)
+    assert all(r[0] % 64 == 0 and r[2] % 64 == 0 and r[2] > 0 for r in rects) and 0.4 < share < 0.9, (rects, share)
+    rng = np.random.default_rng(5)
+    dirty = []
+    for f, (x0, y0, w, rows) in zip(clean, rects):
+        g = rng.integers(0, 256, f.shape, dtype=np.uint8)
+        flat, gflat = f.reshape(540, 2880), g.reshape(540, 2880)
+        gflat[y0:y0 + rows, x0:x0 + w] = flat[y0:y0 + rows, x0:x0 + w]
+        dirty.append(g)
+    assert np.array_equal(ctx.compose_host(dirty), want)
+    pin = [pano.HostBuffer((540, 960, 3)) for _ in range(4)]   # page-locked caller frames: the direct DMA path
+    for b, f in zip(pin, dirty):
+        b.array[:] = f
+    assert np.array_equal(ctx.compose_host([b.array for b in pin]), want)
+    for s in range(2):
+        for i in range(4):
+            ctx.stream_input(s, i)[:] = dirty[i]
+        ctx.stream_submit(s)
+        ctx.stream_wait(s)
+        assert np.array_equal(ctx.stream_output(s), want)
+    # new masks (one camera dropped): the rectangles follow, the first frame behind them is uploaded whole
+    ctx.set_mask(1, np.zeros_like(masks[1]))
+    m2 = [masks[0], np.zeros_like(masks[1]), masks[2], masks[3]]
+    want2, _ = po.compose(clean, d["K"], d["R"], d["scale"], m2, 4)
+    assert np.array_equal(ctx.compose_host(clean), want2)
+    assert ctx.source_rect(1)[3] == 0                            # nothing of camera 1 is read any more
+    for b in pin:
+        b.close()
