@@ -1189,3 +1189,23 @@ def test_host_entries_upload_only_what_the_warp_reads(pano, po):
     assert ctx.source_rect(1)[3] == 0                            # nothing of camera 1 is read any more
     for b in pin:
         b.close()
+
+
+def test_paced_60fps_stream_at_full_size_with_mask_refresh(pano, po):
+    """BASELINE config 5 at its stated size: 8 x 1920x1080 frames offered at 60 fps for ten seconds (600 ticks) through
+    pano_stream_*, with the reference's mask refresh every 200 frames (include/ocvstitcher.hpp:1152-1159) running BESIDE the loop
+    (pano_refresh_masks_begin / _poll: graph cuts on a thread of the library).  The capture loop it stands for is
+    src/master.cpp:302-411.  No tick may be lost to a refresh (one is ~110 ms of host max-flow: inline it costs 6 ticks each); a
+    wall-clock loop on a shared box is allowed two late ticks in 600.  Panoramas sampled before, between and after the refreshes
+    are the oracle's for the masks in force at their tick"""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("stream_60fps", os.path.join(ROOT, "tools", "stream_60fps.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run(fps=60.0, frames=600, width=1920, height=1080, bands=5, check=True, refresh_every=200, refresh_async=True)
+    print(r)
+    assert r["dropped"] <= 2 and r["frames_composed"] + r["dropped"] == 600, r
+    assert r["mask_refresh"]["masks_installed"] >= 2, r            # both stitchers' refreshes came through
+    assert r["sampled_frames_equal_oracle"] is True and r["sampled_frames"] == [0, 300, 599], r
+    assert r["achieved_fps"] > 58.0, r

@@ -50,7 +50,8 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
     ins = [[[ctxs[grp].stream_input(s, i) for i in range(NC)] for grp in range(NG)] for s in range(2)]
     period = 1.0 / fps
     tick_t, done_t = {}, {}
-    sample = {}
+    sample, sample_masks = {}, {}
+    sample_ticks = (0, frames // 2, frames - 1) if check else ()
     dropped = 0
     pending = None   # (frame index, slot)
     refreshed = [0]
@@ -60,7 +61,7 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
         for grp in range(NG):
             ctxs[grp].stream_wait(s)
         done_t[k] = time.perf_counter()
-        if check and k in (0, frames // 2):
+        if k in sample_ticks:
             sample[k] = [ctxs[grp].stream_output(s).copy() for grp in range(NG)]
 
     # two untimed frames: page-locked slots, device buffers and weights come into being here
@@ -90,6 +91,8 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
                 if k and k % refresh_every == 0:     # inside the tick, in front of the frame, like ocvStitcher::process
                     ctxs[grp].build_masks_graphcut(fs[grp])
                     refreshed[0] += 1
+        if k in sample_ticks:   # the masks this tick's panoramas are composed with (a refresh may have installed new ones since the last sample)
+            sample_masks[k] = [[ctxs[grp].get_mask(i) for i in range(NC)] for grp in range(NG)]
         for grp in range(NG):
             for i in range(NC):
                 ins[slot][grp][i][:] = fs[grp][i]          # the capture thread's write into the slot
@@ -133,11 +136,10 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pano_oracle as po
         po.set_threads(min(16, os.cpu_count() or 1))
-        masks = [ctxs[0].get_mask(i) for i in range(NC)]
         ok = True
         for k, got in sample.items():
             for grp in range(NG):
-                want, _ = po.compose(sets[k % nsets][grp], g["K"], g["R"], g["scale"], masks, bands)
+                want, _ = po.compose(sets[k % nsets][grp], g["K"], g["R"], g["scale"], sample_masks[k][grp], bands)
                 ok &= bool(np.array_equal(got[grp], want))
         po.set_threads(1)
         out["sampled_frames_equal_oracle"] = ok
