@@ -51,17 +51,27 @@ def c1b():
     return {"frames": frames, "K": [d["K"]] * 4, "R": d["R"], "scale": d["scale"], "w": 480, "h": 270, "n": 4}
 
 
+def _rig_real(rig, prefix):
+    out = []
+    for s, st in enumerate(rig["stitchers"]):
+        v = st["cams"]
+        out.append({"n": 2, "w": rig["width"], "h": rig["height"], "scale": v[-1], "K": [v[0:9], v[18:27]], "R": [v[9:18], v[27:36]],
+                    "cut": st["cut"], "cams": v, "prefix": prefix,
+                    "frames": [load_png_bgr(os.path.join(GOLDEN, f"{prefix}_cam{2 * s + i}.png")) for i in range(2)]})
+    return out
+
+
 @pytest.fixture(scope="session")
 def rig_r_real(rig_r):
     """rig R with its REAL frames 2222/4cam/0..3.png (960x540): replay.cpp:211-215 gives 0,1 to the "up" stitcher and 2,3
     to the "down" one.  Returns the two stitchers as dicts like c1 (+ "cut")"""
-    out = []
-    for s, st in enumerate(rig_r["stitchers"]):
-        v = st["cams"]
-        out.append({"n": 2, "w": 960, "h": 540, "scale": v[-1], "K": [v[0:9], v[18:27]], "R": [v[9:18], v[27:36]],
-                    "cut": st["cut"], "cams": v,
-                    "frames": [load_png_bgr(os.path.join(GOLDEN, f"r_cam{2 * s + i}.png")) for i in range(2)]})
-    return out
+    return _rig_real(rig_r, "r")
+
+
+@pytest.fixture(scope="session")
+def rig_s_real():
+    """rig S: cfg/cameras.yaml 4cam-silver/640 (:212-228) with ITS frames 2222/4cam/1/0..3.png (640x360), like rig_r_real"""
+    return _rig_real(json.load(open(os.path.join(GOLDEN, "s_cams.json"))), "s")
 
 
 @pytest.fixture(scope="session")

@@ -13,6 +13,7 @@ cannot be built here).
   r_golden.json    rig R (cfg/cameras.yaml 4cam-black/960) on the REAL frames 2222/4cam/0..3.png: per stitcher the
                    ROIs, graph-cut masks, band count from strength 1, the cut panorama (what ocvStitcher::process returns),
                    and master.cpp's stacked output of the two halves
+  s_golden.json    rig S (cfg/cameras.yaml 4cam-silver/640, :212-228) on ITS frames 2222/4cam/1/0..3.png: the same keys
 """
 import hashlib
 import json
@@ -70,12 +71,14 @@ def group_480(prefix, all_bands):
     json.dump(out, open(os.path.join(HERE, f"{prefix}_golden.json"), "w"), indent=1)
 
 
-def rig_r():
+def rig(prefix="r"):
     """what replay.cpp does with 2222/4cam: frames 0,1 -> stitcher 0 ("up"), 2,3 -> stitcher 1 ("down"), each
     init(yaml) + calibration (graph-cut masks from those frames, bands from strength 1) + process; then master.cpp's
-    resize + vconcat + divider"""
-    r = json.load(open(os.path.join(HERE, "r_cams.json")))
-    frames = [load_bgr(f"r_cam{i}.png") for i in range(4)]
+    resize + vconcat + divider.  prefix "r": rig R (4cam-black/960, 2222/4cam/0..3.png); "s": rig S (4cam-silver/640,
+    2222/4cam/1/0..3.png)"""
+    r = json.load(open(os.path.join(HERE, f"{prefix}_cams.json")))
+    W, H = r["width"], r["height"]
+    frames = [load_bgr(f"{prefix}_cam{i}.png") for i in range(4)]
     out = {"stitchers": []}
     halves = []
     for s, st in enumerate(r["stitchers"]):
@@ -84,7 +87,7 @@ def rig_r():
         R = [v[9:18], v[27:36]]
         scale = v[-1]
         fr = frames[2 * s:2 * s + 2]
-        rois = [list(po.warp_roi(po.projector(po.SPHERICAL, scale, K[i], R[i]), 960, 540)) for i in range(2)]
+        rois = [list(po.warp_roi(po.projector(po.SPHERICAL, scale, K[i], R[i]), W, H)) for i in range(2)]
         full = po.result_roi([q[:2] for q in rois], [q[2:] for q in rois])
         bands = po.bands_from_strength(full[2], full[3], 1.0)
         gc = po.prepare_masks_graphcut(fr, K, R, scale)
@@ -96,14 +99,15 @@ def rig_r():
     stacked = po.stack_master(halves[0], halves[1])
     out["stack_master_sha256"] = sha(stacked)
     out["stack_master_size"] = [stacked.shape[1], stacked.shape[0]]
-    Image.fromarray(np.ascontiguousarray(stacked[:, :, ::-1])).save(os.path.join(HERE, "r_stacked.png"), optimize=True)
-    json.dump(out, open(os.path.join(HERE, "r_golden.json"), "w"), indent=1)
+    Image.fromarray(np.ascontiguousarray(stacked[:, :, ::-1])).save(os.path.join(HERE, f"{prefix}_stacked.png"), optimize=True)
+    json.dump(out, open(os.path.join(HERE, f"{prefix}_golden.json"), "w"), indent=1)
 
 
 def main():
     group_480("c1", True)
     group_480("c1b", False)
-    rig_r()
+    rig("r")
+    rig("s")
 
 
 if __name__ == "__main__":

@@ -18,6 +18,8 @@ executed on the GPU box; the outputs are committed:
   r_cam{0..3}.png    /root/reference/2222/4cam/{0..3}.png (960x540, pixels unchanged,
                      re-encoded): the real rig-R frames; replay.cpp:211-215 gives 0,1 to the
                      "up" stitcher and 2,3 to the "down" one.
+  s_cams.json        cfg/cameras.yaml `4cam-silver / inputsz 640` structure (:212-228; rig S)
+  s_cam{0..3}.png    /root/reference/2222/4cam/1/{0..3}.png (640x360, pixels unchanged)
 
 These are data (inputs), not reference source.
 """
@@ -57,12 +59,12 @@ def last_record_old_format(path, source="2222/cameraparaout_1.txt (last record)"
             "width": 480, "height": 270, "source": source}
 
 
-def structure_4cam_black_960(path):
+def structure(path, sttype="4cam-black", inputsz=960, height=540):
     txt = open(path).read()
-    # locate the structure block: sttype 4cam-black ... inputsz: 960
+    # locate the structure block: sttype <sttype> ... inputsz: <inputsz>
     blocks = txt.split("\n -\n")
     for b in blocks:
-        if "sttype: 4cam-black" in b and "inputsz: 960" in b:
+        if f"sttype: {sttype}" in b and f"inputsz: {inputsz}" in b:
             cams = re.findall(r"cams:\s*\[([^\]]*)\]", b, flags=re.S)
             cuts = re.findall(r"^\s*cut:\s*\[([^\]]*)\]", b, flags=re.M)
             out = []
@@ -70,8 +72,8 @@ def structure_4cam_black_960(path):
                 vals = [float(v) for v in c.replace("\n", " ").split(",") if v.strip()]
                 assert len(vals) == 18 * 2 + 1
                 out.append({"cams": vals, "cut": [int(v) for v in cut.split(",")]})
-            return {"width": 960, "height": 540, "num_images": 2, "stitchers": out,
-                    "source": "cfg/cameras.yaml structure lijing/imx390/4cam-black/undistor/120/960"}
+            return {"width": inputsz, "height": height, "num_images": 2, "stitchers": out,
+                    "source": f"cfg/cameras.yaml structure lijing/imx390/{sttype}/undistor/120/{inputsz}"}
     raise SystemExit("structure not found")
 
 
@@ -81,8 +83,13 @@ def main():
         Image.fromarray(im, "RGB").save(f"{OUT}/c1_cam{i}.png", optimize=True)
     json.dump(last_record_old_format(f"{REF}/2222/cameraparaout_1.txt"),
               open(f"{OUT}/c1_cams.json", "w"), indent=1)
-    json.dump(structure_4cam_black_960(f"{REF}/cfg/cameras.yaml"),
-              open(f"{OUT}/r_cams.json", "w"), indent=1)
+    json.dump(structure(f"{REF}/cfg/cameras.yaml"), open(f"{OUT}/r_cams.json", "w"), indent=1)
+    # rig S: the 4cam-silver / inputsz 640 structure (cfg/cameras.yaml:212-228) and ITS frames 2222/4cam/1/0..3.png (640x360)
+    json.dump(structure(f"{REF}/cfg/cameras.yaml", "4cam-silver", 640, 360), open(f"{OUT}/s_cams.json", "w"), indent=1)
+    for i in range(4):
+        im = Image.open(f"{REF}/2222/4cam/1/{i}.png").convert("RGB")
+        assert im.size == (640, 360)
+        im.save(f"{OUT}/s_cam{i}.png", optimize=True)
     for i in range(4):
         im = box4(f"{REF}/2222/{i + 5}.png")
         Image.fromarray(im, "RGB").save(f"{OUT}/c1b_cam{i}.png", optimize=True)

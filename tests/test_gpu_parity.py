@@ -847,7 +847,7 @@ def test_single_ring_of_eight_cameras(pano, po, monkeypatch, w, h, f, bands, fir
     assert two_ended or first != 180.0
 
 
-@pytest.mark.parametrize("case", ["c1", "c1_cylindrical", "rig_r", "c2_1080p", "ties"])
+@pytest.mark.parametrize("case", ["c1", "c1_cylindrical", "rig_r", "c2_1080p", "ties", "half_scale"])
 def test_graphcut_masks_bit_exact(pano, po, c1, rig_r, case):
     """the reference's own seam finder: ocvStitcher::updateMask with GraphCutSeamFinder(COST_COLOR)
     (ocvstitcher.hpp:1218-1261, :1033-1035) - seam-scale warps, graph weights and mask update on the GPU, OpenCV's
@@ -864,6 +864,11 @@ def test_graphcut_masks_bit_exact(pano, po, c1, rig_r, case):
     elif case == "c2_1080p":
         d = c2_group()
         frames = [synth_frame(1920, 1080, 80 + i) for i in range(4)]
+    elif case == "half_scale":
+        # 800 x 500 = 4e5 pixels: seam_work_aspect = sqrt(1e5 / 4e5) is EXACTLY 0.5, where cv::resize(INTER_LINEAR_EXACT) hands the
+        # frame to INTER_AREA's 2 x 2 box (which OpenCV documents as equal to the bit-exact bilinear there: tests/test_oracle.py)
+        d = c2_group(w=800, h=500, f=417.7)
+        frames = [synth_frame(800, 500, 170 + i) for i in range(4)]
     else:   # flat frames: every edge costs the same and the labels of the vertices no tree holds decide
         d = c2_group(w=640, h=360, f=334.0)
         frames = [np.full((360, 640, 3), 90 + 20 * i, np.uint8) for i in range(4)]
@@ -1030,28 +1035,31 @@ def test_bundled_set_second_half_c1b(pano, po, c1b):
     assert sha(ctx.compose_host(d["frames"])) == g["gain_pano_b4_sha256"]
 
 
-def test_rig_r_on_its_real_frames(pano, po, torch, rig_r_real):
-    """rig R (cfg/cameras.yaml 4cam-black/960) on the REAL frames 2222/4cam/0..3.png, driven like replay.cpp:206-290: two
-    2-camera stitchers from the 18N+1 lists, graph-cut masks from the frames (calibration), bands from strength 1, yaml
-    cut, process, then master.cpp:321-326's resize + vconcat + divider - against the oracle and the committed vectors"""
+@pytest.mark.parametrize("which", ["r", "s"])
+def test_rig_r_on_its_real_frames(pano, po, torch, rig_r_real, rig_s_real, which):
+    """rig R (cfg/cameras.yaml 4cam-black/960) on the REAL frames 2222/4cam/0..3.png, and rig S (4cam-silver/640, :212-228) on
+    2222/4cam/1/0..3.png, driven like replay.cpp:206-290: two 2-camera stitchers from the 18N+1 lists, graph-cut masks from the
+    frames (calibration), bands from strength 1, yaml cut, process, then master.cpp:321-326's resize + vconcat + divider -
+    against the oracle and the committed vectors"""
     import hashlib
     import json
     from conftest import GOLDEN, load_png_bgr
-    g = json.load(open(os.path.join(GOLDEN, "r_golden.json")))
+    rig = rig_r_real if which == "r" else rig_s_real
+    g = json.load(open(os.path.join(GOLDEN, f"{which}_golden.json")))
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
     halves, halves_d = [], []
-    for st, gs in zip(rig_r_real, g["stitchers"]):
-        ctx = pano.Context(2, 960, 540, scale=1.0, num_bands=pano.BANDS_FROM_STRENGTH, blend_strength=1.0, cut=st["cut"], device=0)
+    for st, gs in zip(rig, g["stitchers"]):
+        ctx = pano.Context(2, st["w"], st["h"], scale=1.0, num_bands=pano.BANDS_FROM_STRENGTH, blend_strength=1.0, cut=st["cut"], device=0)
         ctx.set_cameras_from_list(",".join(repr(float(x)) for x in st["cams"]))   # the yaml's `cams: [...]` text
         ctx.prepare()
-        assert [list(ctx.roi(i)) for i in range(2)] == gs["rois"] and ctx.num_bands() == gs["bands"] == 3
+        assert [list(ctx.roi(i)) for i in range(2)] == gs["rois"] and ctx.num_bands() == gs["bands"] == (3 if which == "r" else 2)
         ctx.build_masks_graphcut(st["frames"])
         gc = po.prepare_masks_graphcut(st["frames"], st["K"], st["R"], st["scale"])
         for i in range(2):
             assert np.array_equal(ctx.get_mask(i), gc[i])
         assert [sha(ctx.get_mask(i)) for i in range(2)] == gs["graphcut_mask_sha256"]
         got = ctx.compose_host(st["frames"])
-        want, _ = po.compose(st["frames"], st["K"], st["R"], st["scale"], gc, 3, cut=tuple(st["cut"]))
+        want, _ = po.compose(st["frames"], st["K"], st["R"], st["scale"], gc, gs["bands"], cut=tuple(st["cut"]))
         assert [got.shape[1], got.shape[0]] == gs["pano_cut_size"]
         assert np.array_equal(got, want) and sha(got) == gs["pano_cut_sha256"]
         halves.append(got)
@@ -1063,7 +1071,7 @@ def test_rig_r_on_its_real_frames(pano, po, torch, rig_r_real):
     torch.cuda.synchronize()
     stacked = out.cpu().numpy()
     assert np.array_equal(stacked, po.stack_master(halves[0], halves[1]))
-    assert sha(stacked) == g["stack_master_sha256"] and np.array_equal(stacked, load_png_bgr(os.path.join(GOLDEN, "r_stacked.png")))
+    assert sha(stacked) == g["stack_master_sha256"] and np.array_equal(stacked, load_png_bgr(os.path.join(GOLDEN, f"{which}_stacked.png")))
 
 
 def test_host_entry_pageable_pinned_and_strided(pano, po, torch, c1):

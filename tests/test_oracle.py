@@ -251,7 +251,7 @@ def test_oracle_reproduces_committed_golden(po, c1):
     assert [list(x.shape) for x in gains] == g["gain_map_shape"] and [sha(x) for x in gains] == g["gain_map_sha256"]
 
 
-def test_oracle_reproduces_committed_golden_c1b_and_rig_r(po, c1b, rig_r_real):
+def test_oracle_reproduces_committed_golden_c1b_and_rig_r(po, c1b, rig_r_real, rig_s_real):
     """the rest of the bundled set: 2222/5..8.png under cameraparaout_2.txt, and rig R on its real 2222/4cam frames the way
     replay.cpp drives it (two 2-camera stitchers, graph-cut masks, bands from strength 1, yaml cut, master.cpp stacking)"""
     import hashlib
@@ -273,23 +273,24 @@ def test_oracle_reproduces_committed_golden_c1b_and_rig_r(po, c1b, rig_r_real):
     assert [sha(m) for m in gc] == g["graphcut_mask_sha256"]
     gains, _ = po.estimate_gains(d["frames"], d["K"], d["R"], d["scale"])
     assert [sha(x) for x in gains] == g["gain_map_sha256"]
-    g = json.load(open(os.path.join(GOLDEN, "r_golden.json")))
-    halves = []
-    for st, gs in zip(rig_r_real, g["stitchers"]):
-        rois = [list(po.warp_roi(po.projector(0, st["scale"], st["K"][i], st["R"][i]), 960, 540)) for i in range(2)]
-        assert rois == gs["rois"]
-        full = po.result_roi([q[:2] for q in rois], [q[2:] for q in rois])
-        assert list(full) == gs["pano_roi"] and po.bands_from_strength(full[2], full[3], 1.0) == gs["bands"] == 3
-        gc = po.prepare_masks_graphcut(st["frames"], st["K"], st["R"], st["scale"])
-        assert [sha(m) for m in gc] == gs["graphcut_mask_sha256"]
-        pano, _ = po.compose(st["frames"], st["K"], st["R"], st["scale"], gc, 3, cut=tuple(st["cut"]))
-        assert sha(pano) == gs["pano_cut_sha256"]
-        halves.append(pano)
-    # SURVEY appendix C pins of rig R, stitcher 0
-    assert g["stitchers"][0]["rois"] == [[-721, 525, 773, 495], [-59, 497, 790, 496]] and g["stitchers"][0]["pano_roi"][2:] == [1452, 523]
-    stacked = po.stack_master(halves[0], halves[1])
-    assert sha(stacked) == g["stack_master_sha256"]
-    assert np.array_equal(stacked, load_png_bgr(os.path.join(GOLDEN, "r_stacked.png")))
+    for which, rig in (("r", rig_r_real), ("s", rig_s_real)):   # rig S: 4cam-silver/640 on 2222/4cam/1/0..3.png
+        g = json.load(open(os.path.join(GOLDEN, f"{which}_golden.json")))
+        halves = []
+        for st, gs in zip(rig, g["stitchers"]):
+            rois = [list(po.warp_roi(po.projector(0, st["scale"], st["K"][i], st["R"][i]), st["w"], st["h"])) for i in range(2)]
+            assert rois == gs["rois"]
+            full = po.result_roi([q[:2] for q in rois], [q[2:] for q in rois])
+            assert list(full) == gs["pano_roi"] and po.bands_from_strength(full[2], full[3], 1.0) == gs["bands"] == (3 if which == "r" else 2)
+            gc = po.prepare_masks_graphcut(st["frames"], st["K"], st["R"], st["scale"])
+            assert [sha(m) for m in gc] == gs["graphcut_mask_sha256"]
+            pano, _ = po.compose(st["frames"], st["K"], st["R"], st["scale"], gc, gs["bands"], cut=tuple(st["cut"]))
+            assert sha(pano) == gs["pano_cut_sha256"]
+            halves.append(pano)
+        if which == "r":   # SURVEY appendix C pins of rig R, stitcher 0
+            assert g["stitchers"][0]["rois"] == [[-721, 525, 773, 495], [-59, 497, 790, 496]] and g["stitchers"][0]["pano_roi"][2:] == [1452, 523]
+        stacked = po.stack_master(halves[0], halves[1])
+        assert sha(stacked) == g["stack_master_sha256"]
+        assert np.array_equal(stacked, load_png_bgr(os.path.join(GOLDEN, f"{which}_stacked.png")))
 
 
 def test_caller_side_assembly_known_answers(po):
@@ -481,3 +482,26 @@ def test_graphcut_find_properties(po, c1):
         assert m.shape == v.shape and 0.5 < (m != 0).sum() / (v != 0).sum() < 1.5
     pano, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 3)
     assert (pano.reshape(-1, 3).max(1) > 0).mean() > 0.9
+
+
+def test_linear_exact_at_half_scale_is_the_2x2_box(po):
+    """cv::resize(..., Size(), 0.5, 0.5, INTER_LINEAR_EXACT) does not run resize_bitExact: with both scales exactly 2 it switches to
+    INTER_AREA's fast path (imgproc resize.cpp: "in case of inv_scale_x && inv_scale_y is equal to 0.5 INTER_AREA (fast) is equal to
+    bit exact INTER_LINEAR") - the 2 x 2 box (a + b + c + d + 2) >> 2.  initSeam / updateMask meet it when seam_work_aspect =
+    sqrt(1e5 / (W H)) is exactly 0.5, i.e. W H = 4e5 (800 x 500).  The restatement has no such branch because it needs none: the
+    fixed-point bilinear at scale 2 IS that box - every tap pair weighs 128/256 + 128/256 and the 16.16 rounding of
+    (a + b + c + d) << 14 is (sum + 2) >> 2; an odd last column / row averages what exists.  Shown here on random data,
+    even and odd sizes, 1 and 3 channels; a hand-computed corner first"""
+    a = np.array([[10, 20, 7], [31, 42, 9], [5, 6, 200]], np.uint8)            # 3 x 3 -> cvRound(1.5) = 2 x 2
+    got = po.resize_linear_exact_fxy(a, 0.5, 0.5)
+    assert got.tolist() == [[(10 + 20 + 31 + 42 + 2) >> 2, (7 + 9 + 1) >> 1], [(5 + 6 + 1) >> 1, 200]]
+    rng = np.random.default_rng(12)
+    for (h, w, cn) in ((500, 800, 3), (37, 53, 1), (36, 54, 3), (9, 7, 3)):
+        src = rng.integers(0, 256, (h, w, cn) if cn > 1 else (h, w), dtype=np.uint8)
+        got = po.resize_linear_exact_fxy(src, 0.5, 0.5)
+        dh, dw = int(np.rint(h * 0.5)), int(np.rint(w * 0.5))                  # cvRound: half to even
+        assert got.shape[:2] == (dh, dw)
+        s = src.astype(np.int64).reshape(h, w, -1)
+        pad = np.pad(s, ((0, 2 * dh - h if 2 * dh > h else 0), (0, 2 * dw - w if 2 * dw > w else 0), (0, 0)), mode="edge")[:2 * dh, :2 * dw]
+        box = (pad[0::2, 0::2] + pad[0::2, 1::2] + pad[1::2, 0::2] + pad[1::2, 1::2] + 2) >> 2
+        assert np.array_equal(got.reshape(dh, dw, -1), box)
