@@ -722,12 +722,31 @@ def cpu_baseline(ctxs, g, bands):
                 "ms_per_panorama": round(el / reps * 1e3, 1),
                 "stage_ms_per_panorama": {"warp": round(stage[0] / reps, 1), "feed": round(stage[1] / reps, 1), "blend": round(stage[2] / reps, 1)}}
 
+    # the timed leg runs the build BASELINE.md states (-O3 -march=native, same source, same -ffp-contract=off): a second library,
+    # compiled on this host, and only after it has reproduced the checker build's panorama byte for byte
+    build_flags = "-O2 (checker build)"
+    try:
+        po.set_threads(min(usable, 16))
+        want, _ = po.compose(frames, g["K"], g["R"], g["scale"], masks, bands)
+        po.select_build("timed")
+        po.set_threads(min(usable, 16))
+        got, _ = po.compose(frames, g["K"], g["R"], g["scale"], masks, bands)
+        if np.array_equal(got, want):
+            build_flags = "-O3 -march=native -ffp-contract=off -fopenmp (reproduces the checker build's bytes)"
+        else:
+            po.select_build("check")
+            build_flags = "-O2 (checker build; the -O3 -march=native build did NOT reproduce its bytes and was not timed)"
+    except Exception as exc:  # noqa: BLE001 - no compiler on the box: time the checker build
+        po.select_build("check")
+        build_flags = "-O2 (checker build; the timed build failed: %s)" % repr(exc)[:80]
     one = run(1, 8.0, 3)
     share = run(min(usable, 16), 7.0, 20)
     allc = run(min(usable, 64), 7.0, 20) if usable > 16 else share   # beyond 64 threads the row-parallel loops run out of rows
     po.set_threads(1)
+    po.select_build("check")
     best = max((share, allc), key=lambda r: r["value"])
     return {"value": best["value"], "unit": "panoramas/s", "cores": best["cores"], "kind": "port", "host_cpus": ncpu, "cpu_quota": quota,
+            "build": build_flags,
             "sample": "%d panoramas of the same C2 workload (8x1080p, 2 groups, %d bands), OpenMP over rows; the best of the "
                       "16-thread and all-core runs is `value`" % (best["panoramas"], bands),
             "one_thread": one, "threads_16": share, "all_cores": allc}

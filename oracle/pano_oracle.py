@@ -58,18 +58,46 @@ class ComposeArgs(C.Structure):
 
 
 _lib = None
+_libs = {}
+
+
+def _load(path):
+    L = C.CDLL(path)
+    L.po_blender_create.restype = C.c_void_p
+    L.po_blender_level_laplace.restype = C.c_void_p
+    L.po_blender_level_weights.restype = C.c_void_p
+    L.po_bands_from_strength.argtypes = [C.c_int, C.c_int, C.c_float]
+    return L
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_SO)
-        _lib.po_blender_create.restype = C.c_void_p
-        _lib.po_blender_level_laplace.restype = C.c_void_p
-        _lib.po_blender_level_weights.restype = C.c_void_p
-        _lib.po_bands_from_strength.argtypes = [C.c_int, C.c_int, C.c_float]
+        _lib = _libs["check"] = _load(_SO)
     return _lib
+
+
+def build_timed(out_dir=None):
+    """the SAME source built the way BASELINE.md states the timed CPU leg: -O3 -march=native (still -ffp-contract=off, no fast
+    math: the arithmetic is unchanged), OpenMP.  A second library, so that the checker build (-O2, portable) is untouched; built
+    on the host it is timed on (-march=native), into a scratch directory."""
+    import tempfile
+    out = os.path.join(out_dir or tempfile.gettempdir(), "libpano_oracle_timed_%d.so" % os.getuid())
+    src = os.path.join(_HERE, "pano_oracle.c")
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-std=gnu99", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+                           "-shared", "-o", out, src, "-lm"])
+    return out
+
+
+def select_build(which, path=None):
+    """which = "check" (the checker build every test uses) or "timed" (build_timed(): bench.py's cpu_baseline leg only, after it has
+    shown that build to reproduce the checker's bytes)"""
+    global _lib
+    lib()
+    if which == "timed" and "timed" not in _libs:
+        _libs["timed"] = _load(path or build_timed())
+    _lib = _libs[which]
 
 
 def _p(a):
