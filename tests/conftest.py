@@ -98,3 +98,16 @@ def build_fake_rccl():
 def fake_rccl_lib():
     """the RCCL test double: libpano_hip.so opens it instead of librccl.so when PANO_RCCL_LIB names it"""
     return build_fake_rccl()
+
+
+@pytest.fixture(scope="session")
+def st258():
+    """the remaining bundled frames, 2222/258st/1..8.png (2x2 box to 320x180), as two groups of four under the config-1 / config-1b
+    parameters scaled by 2/3 (tests/golden/make_inputs.py: a pairing of this repo's own - the tree holds no parameters for them)"""
+    g = json.load(open(os.path.join(GOLDEN, "st258_golden.json")))
+    out = []
+    for k, (grp, prefix) in enumerate(zip(g["groups"], ("c1", "c1b"))):
+        d = json.load(open(os.path.join(GOLDEN, f"{prefix}_cams.json")))
+        out.append({"n": 4, "w": 320, "h": 180, "K": [grp["K"]] * 4, "R": d["R"], "scale": grp["scale"], "golden": grp,
+                    "frames": [load_png_bgr(os.path.join(GOLDEN, f"st258_cam{4 * k + i}.png")) for i in range(4)]})
+    return out

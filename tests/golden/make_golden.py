@@ -13,6 +13,7 @@ cannot be built here).
   r_golden.json    rig R (cfg/cameras.yaml 4cam-black/960) on the REAL frames 2222/4cam/0..3.png: per stitcher the
                    ROIs, graph-cut masks, band count from strength 1, the cut panorama (what ocvStitcher::process returns),
                    and master.cpp's stacked output of the two halves
+  st258_golden.json the 2222/258st frames (see make_inputs.py) under the scaled config-1 / 1b parameters: masks and 4-band panoramas
   s_golden.json    rig S (cfg/cameras.yaml 4cam-silver/640, :212-228) on ITS frames 2222/4cam/1/0..3.png: the same keys
 """
 import hashlib
@@ -103,7 +104,24 @@ def rig(prefix="r"):
     json.dump(out, open(os.path.join(HERE, f"{prefix}_golden.json"), "w"), indent=1)
 
 
+def st258():
+    """the 2222/258st frames (320x180 after the 2x2 box) under the config-1 / config-1b parameters scaled by 2/3: Voronoi masks,
+    4-band panorama of each group of four"""
+    out = {"groups": []}
+    for g, prefix in enumerate(("c1", "c1b")):
+        d = json.load(open(os.path.join(HERE, f"{prefix}_cams.json")))
+        K = [v * (2.0 / 3.0) if i in (0, 2, 4, 5) else v for i, v in enumerate(d["K"])]
+        scale = float(np.float32(d["scale"]) * np.float32(2.0 / 3.0))
+        frames = [load_bgr(f"st258_cam{4 * g + i}.png") for i in range(4)]
+        masks = po.prepare_masks_voronoi(po.SPHERICAL, 320, 180, [K] * 4, d["R"], scale)
+        pano, _ = po.compose(frames, [K] * 4, d["R"], scale, masks, 4)
+        out["groups"].append({"K": K, "scale": scale, "pano_size": [pano.shape[1], pano.shape[0]], "pano_b4_sha256": sha(pano),
+                              "mask_sha256": [sha(m) for m in masks]})
+    json.dump(out, open(os.path.join(HERE, "st258_golden.json"), "w"), indent=1)
+
+
 def main():
+    st258()
     group_480("c1", True)
     group_480("c1b", False)
     rig("r")

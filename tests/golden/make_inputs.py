@@ -18,6 +18,10 @@ executed on the GPU box; the outputs are committed:
   r_cam{0..3}.png    /root/reference/2222/4cam/{0..3}.png (960x540, pixels unchanged,
                      re-encoded): the real rig-R frames; replay.cpp:211-215 gives 0,1 to the
                      "up" stitcher and 2,3 to the "down" one.
+  st258_cam{0..7}.png /root/reference/2222/258st/{1..8}.png (640x360: another scene from an 8-camera rig of the same kind; the tree
+                     holds no parameters for it), 2x2 box-downsampled to 320x180.  The tests pair them with the config-1 /
+                     config-1b parameters scaled by 2/3 - a pairing of this repo's own, used for real image content at a third
+                     frame size, with no claim that those parameters belong to these frames.
   s_cams.json        cfg/cameras.yaml `4cam-silver / inputsz 640` structure (:212-228; rig S)
   s_cam{0..3}.png    /root/reference/2222/4cam/1/{0..3}.png (640x360, pixels unchanged)
 
@@ -84,6 +88,11 @@ def main():
     json.dump(last_record_old_format(f"{REF}/2222/cameraparaout_1.txt"),
               open(f"{OUT}/c1_cams.json", "w"), indent=1)
     json.dump(structure(f"{REF}/cfg/cameras.yaml"), open(f"{OUT}/r_cams.json", "w"), indent=1)
+    for i in range(8):
+        a = np.asarray(Image.open(f"{REF}/2222/258st/{i + 1}.png").convert("RGB"), dtype=np.uint32)
+        assert a.shape == (360, 640, 3)
+        a = a.reshape(180, 2, 320, 2, 3).sum(axis=(1, 3))
+        Image.fromarray(((a + 2) // 4).astype(np.uint8), "RGB").save(f"{OUT}/st258_cam{i}.png", optimize=True)
     # rig S: the 4cam-silver / inputsz 640 structure (cfg/cameras.yaml:212-228) and ITS frames 2222/4cam/1/0..3.png (640x360)
     json.dump(structure(f"{REF}/cfg/cameras.yaml", "4cam-silver", 640, 360), open(f"{OUT}/s_cams.json", "w"), indent=1)
     for i in range(4):

@@ -1217,3 +1217,22 @@ def test_paced_60fps_stream_at_full_size_with_mask_refresh(pano, po):
     assert r["mask_refresh"]["masks_installed"] >= 2, r            # both stitchers' refreshes came through
     assert r["sampled_frames_equal_oracle"] is True and r["sampled_frames"] == [0, 300, 599], r
     assert r["achieved_fps"] > 58.0, r
+
+
+def test_258st_frames_bit_exact(pano, po, st258):
+    """the last of the bundled inputs, 2222/258st/1..8.png (320x180 after a 2x2 box), as two 4-camera groups: Voronoi masks and the
+    4-band panorama equal the oracle's and the committed hashes; graph-cut masks from these frames equal the oracle's too"""
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    for d in st258:
+        ctx = make_ctx(pano, d, 0, num_bands=4)
+        ctx.build_masks_voronoi()
+        masks = [ctx.get_mask(i) for i in range(4)]
+        assert [sha(m) for m in masks] == d["golden"]["mask_sha256"]
+        got = ctx.compose_host(d["frames"])
+        assert sha(got) == d["golden"]["pano_b4_sha256"]
+        ctx.build_masks_graphcut(d["frames"])
+        gc = po.prepare_masks_graphcut(d["frames"], d["K"], d["R"], d["scale"])
+        assert all(np.array_equal(ctx.get_mask(i), gc[i]) for i in range(4))
+        want, _ = po.compose(d["frames"], d["K"], d["R"], d["scale"], gc, 4)
+        assert np.array_equal(ctx.compose_host(d["frames"]), want)

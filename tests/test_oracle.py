@@ -505,3 +505,14 @@ def test_linear_exact_at_half_scale_is_the_2x2_box(po):
         pad = np.pad(s, ((0, 2 * dh - h if 2 * dh > h else 0), (0, 2 * dw - w if 2 * dw > w else 0), (0, 0)), mode="edge")[:2 * dh, :2 * dw]
         box = (pad[0::2, 0::2] + pad[0::2, 1::2] + pad[1::2, 0::2] + pad[1::2, 1::2] + 2) >> 2
         assert np.array_equal(got.reshape(dh, dw, -1), box)
+
+
+def test_oracle_reproduces_committed_golden_258st(po, st258):
+    """the 2222/258st frames (another scene, a third frame size) through the oracle: masks and 4-band panoramas as committed"""
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    for d in st258:
+        masks = po.prepare_masks_voronoi(0, 320, 180, d["K"], d["R"], d["scale"])
+        assert [sha(m) for m in masks] == d["golden"]["mask_sha256"]
+        pano, _ = po.compose(d["frames"], d["K"], d["R"], d["scale"], masks, 4)
+        assert [pano.shape[1], pano.shape[0]] == d["golden"]["pano_size"] and sha(pano) == d["golden"]["pano_b4_sha256"]
