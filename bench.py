@@ -513,7 +513,10 @@ def main():
             "config": {"workload": "C2: 8x1920x1080 BGR8 -> 2 groups x 4 cameras, spherical warp + %d-band "
                                    "multi-band blend, Voronoi seams, pano 2 x %dx%d" % (args.bands, ow, oh),
                        "parallelism": ("single GPU, %d frames in flight" % F) if world == 1 else
-                                      ("cameras sharded %d/rank, %s" % (per_rank, "gloo rehearsal on one GPU, slots staged through the host"
+                                      ("cameras sharded %d/rank, %s" % (per_rank,
+                                                                          "every rank composes whole stitchers; the finished half panoramas move to rank 0 (torch.distributed send / recv)"
+                                                                          if not any(pl["moves"] for pl in plans) else
+                                                                          "gloo rehearsal on one GPU, slots staged through the host"
                                                                           if rehearsal and exchange["kind"] != "cabi" else
                                                                           ("RCCL gather to rank 0 through the C-ABI (pano_gather_slots)" if exchange["kind"] == "cabi"
                                                                            else "RCCL gather to rank 0 (torch.distributed batch_isend_irecv)")))},
