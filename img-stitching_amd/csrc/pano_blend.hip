@@ -144,15 +144,22 @@ __device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int 
         }
     }
 }
-// a . w for two packed int16 pairs, v_dot2_i32_i16 with an inline-constant 0 accumulator (w is a compile-time constant)
-__device__ __forceinline__ int sdot2_from_zero(unsigned a, unsigned w) {
+// a . w + R for two packed int16 pairs, v_dot2_i32_i16 with an INLINE-CONSTANT accumulator R (w is a compile-time constant; R = 0, 8
+// or 24: inline constants are free, the builtin would spend a v_mov on them)
+template <int R>
+__device__ __forceinline__ int sdot2_from(unsigned a, unsigned w) {
     int d;
-    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "s"(w));
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(w), "n"(R));
     return d;
 }
 // pyrUp of a 4 x 2 block from the packed 4 x 3 neighbourhood: up[0][..] = fine row Y0 (even), up[1][..] = row Y0+1.
 // Horizontal pass per coarse row: (p0 + 6 p1 + p2, 4 (p1 + p2), p1 + 6 p2 + p3, 4 (p2 + p3)) as dot products
-// (v_dot4_u32_u8 on the byte window / v_dot2_i32_i16 on the short pairs); vertical pass in 32-bit ints.
+// (v_dot4_u32_u8 on the byte window / v_dot2_i32_i16 on the short pairs); vertical pass in 32-bit ints:
+//   even row (h0 + 6 h1 + h2 + 32) >> 6,   odd row (h1 + h2 + 8) >> 4.
+// The rounding terms ride in the dot products' accumulators - +24 in h0, +8 in h2 (24 + 8 = 32 for the even row, 8 for the odd) -
+// and the 6 h1 is one v_mad_*24: add, mad, shift | add, shift per sample.  On gfx950 an add or a right shift issues at twice the
+// rate of a v_mad / v_add3 / v_mul_lo (profiles/r03_valu_instruction_rates.txt); the compiler's own v_mul_lo_u32 + v_add3_u32 chain
+// for the plain expression cost half again as many issue cycles.
 template <typename T>
 __device__ __forceinline__ void up_block(const unsigned q[3][2], int up[2][4]) {
     int h[3][4];
@@ -160,29 +167,45 @@ __device__ __forceinline__ void up_block(const unsigned q[3][2], int up[2][4]) {
     for (int r = 0; r < 3; r++) {
         if (sizeof(T) == 1) {
             const unsigned w = q[r][0];
-            h[r][0] = (int)__builtin_amdgcn_udot4(w, 0x00010601u, 0u, false);
-            h[r][1] = (int)__builtin_amdgcn_udot4(w, 0x00040400u, 0u, false);
-            h[r][2] = (int)__builtin_amdgcn_udot4(w, 0x01060100u, 0u, false);
-            h[r][3] = (int)__builtin_amdgcn_udot4(w, 0x04040000u, 0u, false);
+            const unsigned R = r == 0 ? 24u : (r == 2 ? 8u : 0u);
+            h[r][0] = (int)__builtin_amdgcn_udot4(w, 0x00010601u, R, false);
+            h[r][1] = (int)__builtin_amdgcn_udot4(w, 0x00040400u, R, false);
+            h[r][2] = (int)__builtin_amdgcn_udot4(w, 0x01060100u, R, false);
+            h[r][3] = (int)__builtin_amdgcn_udot4(w, 0x04040000u, R, false);
         } else {
             const s2_t A = __builtin_bit_cast(s2_t, q[r][0]), B = __builtin_bit_cast(s2_t, q[r][1]);
             const s2_t c16 = {1, 6}, c04 = {0, 4}, c01 = {0, 1};
-            // the products that start a sum use the three-operand form with an inline 0: the builtin becomes v_dot2c,
-            // whose accumulator is the destination, and costs a v_mov to zero it first
-            h[r][0] = __builtin_amdgcn_sdot2(A, c16, (int)B.x, false);
-            h[r][1] = __builtin_amdgcn_sdot2(A, c04, sdot2_from_zero(q[r][1], 0x00000004u), false);  // B . (4, 0)
-            h[r][2] = __builtin_amdgcn_sdot2(A, c01, sdot2_from_zero(q[r][1], 0x00010006u), false);  // B . (6, 1)
-            h[r][3] = sdot2_from_zero(q[r][1], 0x00040004u);                                         // B . (4, 4)
+            if (r == 0) {
+                h[r][0] = __builtin_amdgcn_sdot2(A, c16, (int)B.x + 24, false);
+                h[r][1] = __builtin_amdgcn_sdot2(A, c04, sdot2_from<24>(q[r][1], 0x00000004u), false);  // B . (4, 0)
+                h[r][2] = __builtin_amdgcn_sdot2(A, c01, sdot2_from<24>(q[r][1], 0x00010006u), false);  // B . (6, 1)
+                h[r][3] = sdot2_from<24>(q[r][1], 0x00040004u);                                         // B . (4, 4)
+            } else if (r == 2) {
+                h[r][0] = __builtin_amdgcn_sdot2(A, c16, (int)B.x + 8, false);
+                h[r][1] = __builtin_amdgcn_sdot2(A, c04, sdot2_from<8>(q[r][1], 0x00000004u), false);
+                h[r][2] = __builtin_amdgcn_sdot2(A, c01, sdot2_from<8>(q[r][1], 0x00010006u), false);
+                h[r][3] = sdot2_from<8>(q[r][1], 0x00040004u);
+            } else {
+                h[r][0] = __builtin_amdgcn_sdot2(A, c16, (int)B.x, false);
+                h[r][1] = __builtin_amdgcn_sdot2(A, c04, sdot2_from<0>(q[r][1], 0x00000004u), false);
+                h[r][2] = __builtin_amdgcn_sdot2(A, c01, sdot2_from<0>(q[r][1], 0x00010006u), false);
+                h[r][3] = sdot2_from<0>(q[r][1], 0x00040004u);
+            }
         }
     }
     // No saturate_cast here: it cannot trigger.  Camera planes are 8-bit (h <= 8*255), and a collapsed canvas level
     // is bounded by 255 per remaining level (|norm_l| <= 255, pyrUp is a convex combination + rounding), i.e.
-    // |out_l| <= 9*255 + 9 for the maximum of 8 bands - far inside int16.
+    // |out_l| <= 9*255 + 9 for the maximum of 8 bands - far inside int16 (and every h inside 24 bits).
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int h1 = h[1][k];
-        up[0][k] = (h[0][k] + h[2][k] + (h1 << 2) + (h1 << 1) + 32) >> 6;
-        up[1][k] = (h1 + h[2][k] + 8) >> 4;
+        if (sizeof(T) == 1) {
+            up[0][k] = (int)((unsigned)(__mul24(h1, 6) + (h[0][k] + h[2][k])) >> 6);  // signed spelling: one v_mad_i32_i24; sums are non-negative
+            up[1][k] = (int)((unsigned)(h1 + h[2][k]) >> 4);
+        } else {
+            up[0][k] = (__mul24(h1, 6) + (h[0][k] + h[2][k])) >> 6;
+            up[1][k] = (h1 + h[2][k]) >> 4;
+        }
     }
 }
 
