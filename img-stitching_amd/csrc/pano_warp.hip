@@ -629,6 +629,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                     16, 0, 0);
             }
         }
+    }
+    // Everything that needs the table entry but not the box - the four codes and the LDS byte offsets of their taps - is done
+    // HERE, in front of the barrier: a wave whose copies have landed waits for the slowest wave of its workgroup anyway (45 % of
+    // this kernel's wave cycles are spent parked), and a third of its vector instructions fit into that wait
+    unsigned X[4], Y[4];
+    {
+        const int Db = sbits(e.y, 0, 8), Eb = sbits(e.y, 8, 6);
+        X[0] = e.x & 0xffffu; Y[0] = e.x >> 16;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            X[j + 1] = X[j] + (unsigned)(Db + sbits(e.y, 14 + 6 * j, 3));
+            Y[j + 1] = Y[j] + (unsigned)(Eb + sbits(e.y, 17 + 6 * j, 3));
+        }
+    }
+    // an escaped group (a BORDER_REFLECT fold inside it) reads its four codes from the dense table: one more dependent
+    // load for the waves that hold one (about one in eight)
+    if (e.x == 0xffffffffu) {
+        const uint4 mm = *reinterpret_cast<const uint4*>(cg->lut + ((unsigned)y * (4u * lutc_pitch) + (unsigned)x0));
+        const unsigned code[4] = {mm.x, mm.y, mm.z, mm.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            X[j] = code[j] & 0xffffu;
+            Y[j] = code[j] >> 16;
+        }
+    }
+    unsigned loff[4] = {0u, 0u, 0u, 0u};
+    if (bh) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) loff[j] = __umul24(Y[j] >> 5, lpitch) + __umul24(X[j] >> 5, 3u) + ph;  // codes are box relative
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (GAIN && gbase >= 0 && tid < kGainRows * 16 + 16) sgain[tid] = gstage;
@@ -653,40 +682,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         }
     }
     uint8_t PANO_GLOBAL* d = dst + ((unsigned)y * dst_pitch + (unsigned)x0);  // 32-bit offsets: a tile is far below 4 GB
-    unsigned X[4], Y[4];
-    {
-        const int Db = sbits(e.y, 0, 8), Eb = sbits(e.y, 8, 6);
-        X[0] = e.x & 0xffffu; Y[0] = e.x >> 16;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            X[j + 1] = X[j] + (unsigned)(Db + sbits(e.y, 14 + 6 * j, 3));
-            Y[j + 1] = Y[j] + (unsigned)(Eb + sbits(e.y, 17 + 6 * j, 3));
-        }
-    }
-    // an escaped group (a BORDER_REFLECT fold inside it) reads its four codes from the dense table: one more dependent
-    // load for the waves that hold one (about one in eight)
-    if (e.x == 0xffffffffu) {
-        const uint4 mm = *reinterpret_cast<const uint4*>(cg->lut + ((unsigned)y * (4u * lutc_pitch) + (unsigned)x0));
-        const unsigned code[4] = {mm.x, mm.y, mm.z, mm.w};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            X[j] = code[j] & 0xffffu;
-            Y[j] = code[j] >> 16;
-        }
-    }
     uint2 t[4], u[4];
     if (bh) {
         // LDS byte offset of a pixel: (ys - ymin) * lpitch + 3 * (xs - xmin) + ph.  Three aligned dwords and
         // v_alignbyte, like the global taps: 8-byte ds reads at odd addresses work but run the kernel at half speed.
         const unsigned* sb = reinterpret_cast<const unsigned*>(sbox);
+        // all sixteen LDS reads of the lane's four pixels go out BEFORE the first is used (the scheduler, left alone, waits for
+        // each pixel's four reads before it issues the next pixel's: four LDS round trips per wave one after the other)
+        unsigned k[4], ra[4][3], rb[4][3];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const unsigned off = __umul24(Y[j] >> 5, lpitch) + __umul24(X[j] >> 5, 3u) + ph;  // codes are box relative
-            const unsigned k = off & 3u;
-            const unsigned* wt = sb + (off >> 2);
+            k[j] = loff[j] & 3u;
+            const unsigned* wt = sb + (loff[j] >> 2);
             const unsigned* wu = wt + (lpitch >> 2);  // row ys + 1; for ys == sh - 1 (weight 0) the spare row
-            t[j] = make_uint2(__builtin_amdgcn_alignbyte(wt[1], wt[0], k), __builtin_amdgcn_alignbyte(wt[2], wt[1], k));
-            u[j] = make_uint2(__builtin_amdgcn_alignbyte(wu[1], wu[0], k), __builtin_amdgcn_alignbyte(wu[2], wu[1], k));
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                ra[j][q] = wt[q];
+                rb[j][q] = wu[q];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            t[j] = make_uint2(__builtin_amdgcn_alignbyte(ra[j][1], ra[j][0], k[j]), __builtin_amdgcn_alignbyte(ra[j][2], ra[j][1], k[j]));
+            u[j] = make_uint2(__builtin_amdgcn_alignbyte(rb[j][1], rb[j][0], k[j]), __builtin_amdgcn_alignbyte(rb[j][2], rb[j][1], k[j]));
         }
     } else {
         // Global taps (the box of this patch does not fit LDS or touches the end of the frame).  `o_last` is the last
