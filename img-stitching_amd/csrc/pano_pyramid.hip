@@ -7,10 +7,22 @@ namespace pano {
 
 // ------------------------------------------------------------------------------------------------
 // K2: pyrDown (cv::pyrDown CV_16S semantics: 5x5 [1 4 6 4 1]^2, REFLECT_101, (v+128)>>8) on planar u8.
-// One thread = 4 x 2 output pixels of one plane: 7 input rows x one 16-byte load, the horizontal 5-tap as
+// One thread = 4 x R output pixels of one plane: 2R + 3 input rows x one 16-byte load, the horizontal 5-tap as
 // v_dot4_u32_u8 on byte windows, the vertical pass in registers.  grid.z = camera * 3 + plane.
+// R = 4 (eleven loads for sixteen outputs, 68 VGPRs, 7 waves / SIMD): against R = 2 a lane fetches 2.75 instead of 3.5 rows
+// per output row and does as many horizontal passes, and half as many waves pay the scalar prologue - the pyramid stage of
+// config 2 33.5 -> 31.7 us one frame at a time, +1.5 % panoramas/s with four in flight; R = 5, 6, 8 (92 / 116 VGPRs) measure the same.
 // ------------------------------------------------------------------------------------------------
+#ifndef PANO_PYR_ROWS
+#define PANO_PYR_ROWS 4
+#endif
+#ifndef PANO_PYR_ROWS_UP
+#define PANO_PYR_ROWS_UP 4
+#endif
+constexpr int kPyrRows0 = PANO_PYR_ROWS, kPyrRowsUp = PANO_PYR_ROWS_UP;  // output rows per lane: level 0 -> 1, the levels above
+template <int R>
 __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam_bits, int l) {
+    constexpr int NR = 2 * R + 3;  // source rows of R output rows
     const int ci = blockIdx.z / 3, pl = blockIdx.z - ci * 3;
     if (!((cam_bits >> ci) & 1u)) return;
     const PyrCam& c = P.cam[ci];
@@ -20,27 +32,26 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam
     // grid is laid over the live rect, so that whole waves - not lanes - fall off its far side.
     const int lx0 = c.live[l + 1][0], ly0 = c.live[l + 1][1], lx1 = c.live[l + 1][2], ly1 = c.live[l + 1][3];
     const int t = (lx0 >> 2) + blockIdx.x * 64 + threadIdx.x;  // group of 4 output columns
-    // a wave is one threadIdx.y: tell the compiler, and the row indices, the REFLECT_101 of the seven source rows and
+    // a wave is one threadIdx.y: tell the compiler, and the row indices, the REFLECT_101 of the source rows and
     // their addresses are scalar work (a quarter of this kernel's vector instructions otherwise)
-    const int y0 = ((ly0 >> 1) + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * 2;  // pair of output rows
+    const int y0 = ((int)((unsigned)ly0 / R) + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * R;  // first of R output rows
     if (y0 >= dh || y0 > ly1) return;
     if (t * 4 >= dw || t * 4 > lx1) return;
     if (t * 4 >= c.gap[l + 1][0] && t * 4 + 3 <= c.gap[l + 1][1]) return;  // the dead middle of a +-pi straddler's tile
     const uint8_t* __restrict__ src = c.lvl[l] + (size_t)pl * c.plane[l];
     const int sp = c.pitch[l];
-    // Every lane does seven 16-byte loads (columns 8t-4 .. 8t+11; lane 0 loads columns 0..15 and shifts).
+    // Every lane does NR 16-byte loads (columns 8t-4 .. 8t+11; lane 0 loads columns 0..15 and shifts).
     // REFLECT_101 at the two row ends touches at most three bytes, patched in registers:
     //   left  (t == 0): columns -2, -1 are columns 2, 1
     //   right (8t+8 == sw, the last group): column sw is column sw-2
-    int acc0[4] = {128, 128, 128, 128}, acc1[4] = {128, 128, 128, 128};  // the rounding term of (v + 128) >> 8
     const int off = t == 0 ? 0 : 8 * t - 4;
-    uint4 q[7];
+    uint4 q[NR];
 #pragma unroll
-    for (int r = 0; r < 7; r++)
+    for (int r = 0; r < NR; r++)
         q[r] = *reinterpret_cast<const uint4*>(src + ((unsigned)(reflect101_idx(2 * y0 - 2 + r, sh) * sp) + (unsigned)off));  // scalar row + lane offset
     if (t == 0) {
 #pragma unroll
-        for (int r = 0; r < 7; r++) {
+        for (int r = 0; r < NR; r++) {
             const unsigned a = q[r].x;
             q[r].w = q[r].z;
             q[r].z = q[r].y;
@@ -53,7 +64,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam
     if (ksw <= 12) {
         // ksw is even (sw and 8t-4 are even) and >= 6: the source byte ksw-2 sits in the same or the previous dword
 #pragma unroll
-        for (int r = 0; r < 7; r++) {
+        for (int r = 0; r < NR; r++) {
             unsigned d[4] = {q[r].x, q[r].y, q[r].z, q[r].w};
             const int ks = ksw - 2;
             unsigned v = 0;
@@ -66,28 +77,32 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam
             q[r] = make_uint4(d[0], d[1], d[2], d[3]);
         }
     }
+    int acc[R][4];
 #pragma unroll
-    for (int r = 0; r < 7; r++) {
+    for (int o = 0; o < R; o++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[o][j] = 128;  // the rounding term of (v + 128) >> 8
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
         int h[4];
         pyr_down_hrow(q[r], h);
-        const int wa = r == 0 ? 1 : (r == 1 ? 4 : (r == 2 ? 6 : (r == 3 ? 4 : (r == 4 ? 1 : 0))));
-        const int wb = r == 2 ? 1 : (r == 3 ? 4 : (r == 4 ? 6 : (r == 5 ? 4 : (r == 6 ? 1 : 0))));
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            acc0[j] += h[j] * wa;
-            acc1[j] += h[j] * wb;
+        for (int o = 0; o < R; o++) {
+            const int k = r - 2 * o;  // tap of output row o that source row r is
+            if (k < 0 || k > 4) continue;
+            const int wk = k == 0 || k == 4 ? 1 : (k == 2 ? 6 : 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[o][j] += h[j] * wk;
         }
     }
     uint8_t* d = c.lvl[l + 1] + (size_t)pl * c.plane[l + 1] + (size_t)y0 * c.pitch[l + 1] + 4 * t;
-    unsigned p0 = 0, p1 = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        // no saturate_cast: the taps sum to 256, so (256 * 255 + 128) >> 8 = 255 is the largest value there is
-        p0 |= (unsigned)(acc0[j] >> 8) << (8 * j);
-        p1 |= (unsigned)(acc1[j] >> 8) << (8 * j);
+    for (int o = 0; o < R; o++) {
+        unsigned px = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) px |= (unsigned)(acc[o][j] >> 8) << (8 * j);  // no saturate_cast: the taps sum to 256, so 255 is the largest value there is
+        if (o == 0 || y0 + o < dh) *reinterpret_cast<unsigned*>(d + (size_t)o * c.pitch[l + 1]) = px;  // rows are padded to 16 bytes
     }
-    *reinterpret_cast<unsigned*>(d) = p0;  // rows are padded to 16 bytes
-    if (y0 + 1 < dh) *reinterpret_cast<unsigned*>(d + c.pitch[l + 1]) = p1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -341,8 +356,10 @@ void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s
             mh = max(mh, p.cam[i].h0 >> (l + 1));
         }
     if (mw == 0 || mh == 0) return;
-    dim3 block(64, 4, 1), grid((mw + 255) / 256, (mh + 7) / 8, p.ncam * 3);
-    hipLaunchKernelGGL(pyr_down_kernel, grid, block, 0, s, p, cam_bits, l);
+    const int R = l == 0 ? kPyrRows0 : kPyrRowsUp;
+    dim3 block(64, 4, 1), grid((mw + 255) / 256, (mh + 4 * R - 1) / (4 * R), p.ncam * 3);
+    if (l == 0) hipLaunchKernelGGL(pyr_down_kernel<kPyrRows0>, grid, block, 0, s, p, cam_bits, l);
+    else hipLaunchKernelGGL(pyr_down_kernel<kPyrRowsUp>, grid, block, 0, s, p, cam_bits, l);
 }
 
 }  // namespace pano
