@@ -51,6 +51,9 @@ struct alignas(64) WarpCam {
     const int4* grow4;    // [th] {sy0, sy1, bits of 1-fy, bits of fy}: grow and groww in one 16-byte entry per tile row
     int ghrow_pitch;      // floats per row, a multiple of 4; columns past tw repeat the last one
     int gh;               // rows of ghrow
+    // --- set by launch_warp_tiles for the launch (WarpDeal): this camera's live block columns (its gap taken out) and the
+    // multiplier that divides by them (2^32 / cols + 1; 0: one column)
+    unsigned deal_cols, deal_mcols;
     // --- everything else
     // static remap table: one dword per tile pixel, see build_warp_table_kernel
     const uint32_t* lut;  // dense form, read where the packed form escapes; nullptr -> project on the fly
@@ -66,8 +69,19 @@ struct alignas(64) WarpCam {
 };
 constexpr int kGainRows = 4;
 inline int warp_pack_live(int live_by0, int gap_bx0, int gap_len) { return live_by0 | gap_bx0 << 12 | (int)((unsigned)gap_len << 22); }
+// How the table form of K1 deals its work: the live 64 x 16 blocks of every camera of the launch, camera after camera and row
+// after row, form one list; XCD k (= workgroup id mod 8: grid.x is 8) takes the k-th eighth of it.  With as many cameras as XCDs
+// that is "one camera per XCD" (an XCD's L2 holds one camera's frame) with the cameras' unequal live areas evened out at the
+// joints: dealt camera = XCD, the XCDs of config 2's largest cameras ran 23 % more waves than those of the smallest (5208 against
+// 4216) and finished 4 us after them (tools/wave_timeline.py).  Config 2: 18.2 -> 17.9 us warm, 21.8 -> 20.9 cold; config 4:
+// 60.1 -> 56.3 us (66.0 -> 63.2 with gains).
+struct WarpDeal {
+    unsigned end[kCams];  // end[c] = blocks of cameras 0..c (cameras past the last: the total)
+    unsigned per;         // blocks per XCD = ceil(total / 8)
+};
 struct WarpParams {
     WarpCam cam[kCams];
+    WarpDeal deal;
 };
 
 // one camera's pyramid slot.  Every Gaussian level of an 8-bit image stays in [0,255], so the levels are

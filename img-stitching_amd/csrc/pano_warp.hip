@@ -491,10 +491,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     // GAIN: the workgroup's 64 columns of up to kGainRows rows of ghrow, then its 16 row entries {sy0, sy1, 1 - fy, fy} (as bits)
     __shared__ f32x4 sgain[GAIN ? kGainRows * 16 + 16 : 1];
-    // grid = (ncam, ceil(tw/64), ceil(th/16)): the camera is the FASTEST workgroup coordinate.  Linear workgroup ids
-    // are dealt round-robin over the 8 XCDs (each with its own L2), so with 8 (or 4, 2) cameras an XCD's L2 only ever
-    // holds one camera's frame, and every camera still advances top to bottom with all XCDs busy.  Measured on the
-    // 8-camera launch against camera-major dispatch order: 33.1 vs 36.0 us, FETCH_SIZE 50.8 vs 77.8 MB.
+    // grid = (8, blocks per XCD): linear workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2), so
+    // blockIdx.x IS the XCD, and XCD k works through the k-th eighth of the list of live blocks (WarpDeal, pano_kernels.hpp):
+    // with 8 (or 4, 2) cameras an XCD's L2 holds one camera's frame (FETCH_SIZE 50.8 against 77.8 MB for camera-major
+    // dispatch, 33.1 against 36.0 us in round 1), every camera advances top to bottom with all XCDs busy, and no XCD has
+    // more blocks than another.
     // Tried and rejected: XCD-aware order of the blocks WITHIN a camera (fewer fetched bytes, 15 % slower).
     // Prologue: an empty body over this grid (53 K workgroups) costs 9.4 us when the camera block is read field by
     // field behind branches - a chain of dependent scalar loads per wave, which the compiler is free to build by
@@ -511,8 +512,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                       offsetof(WarpCam, box) == 24 && offsetof(WarpCam, live_bx0) == 40, "hot part layout");
     union { i32x16 v; Hot h; } hot;
     // WarpParams is the only kernel argument: P.cam[i] sits at kernarg + i * sizeof(WarpCam)
+    // Which block is this?  (WarpDeal)  blockIdx.x = XCD, blockIdx.y = position in the XCD's share of the list of live blocks
+    typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+    u32x8 dend;
+    unsigned dper;
+    {
+        static_assert(offsetof(WarpParams, deal) == sizeof(WarpCam) * kCams && offsetof(WarpDeal, per) == 32 && kCams == 8, "deal layout");
+        const char __attribute__((address_space(4)))* kd =
+            (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(WarpCam) * kCams;
+        // early clobber: the address is read again by the second load, after the first may have landed
+        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dend), "=&s"(dper) : "s"(kd) : "memory");
+    }
+    const unsigned lin = blockIdx.x * dper + blockIdx.y;
+    if (lin >= dend[kCams - 1]) return;  // past the end of the list (the whole workgroup leaves)
+    unsigned ci = 0, dstart = 0;
+#pragma unroll
+    for (int c = 0; c < kCams - 1; c++) {
+        if (lin >= dend[c]) {
+            ci = c + 1;
+            dstart = dend[c];
+        }
+    }
     const char __attribute__((address_space(4)))* ka =
-        (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.x * sizeof(WarpCam);
+        (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + ci * sizeof(WarpCam);
     // GAIN: the camera's gain block {gain, grow_base, ghrow, grow4 | ghrow_pitch, gh} rides along (two more scalar loads in
     // flight with the first), so that the workgroup's gain rows can be requested together with its source box
     typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -523,17 +545,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     union { i32x8 v; GainBlk g; } gq;
     i32x2 gq2 = {0, 0};  // {ghrow_pitch, gh}
     gq.v = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    u32x2 dcm;  // {deal_cols, deal_mcols}
+    static_assert(offsetof(WarpCam, deal_cols) == 0x78 && offsetof(WarpCam, deal_mcols) == 0x7c, "deal columns layout");
     if (GAIN) {
         static_assert(sizeof(GainBlk) == 32 && offsetof(WarpCam, gain) == 80 && offsetof(WarpCam, grow_base) == 88 && offsetof(WarpCam, ghrow) == 96 &&
                           offsetof(WarpCam, grow4) == 104 && offsetof(WarpCam, ghrow_pitch) == 112 && offsetof(WarpCam, gh) == 116, "gain block layout");
         asm volatile("s_load_dwordx8 %0, %2, 0x50\n\ts_load_dwordx2 %1, %2, 0x70" : "=s"(gq.v), "=s"(gq2) : "s"(ka) : "memory");
-        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hot.v), "+s"(gq.v), "+s"(gq2) : "s"(ka) : "memory");
+        asm volatile("s_load_dwordx2 %0, %1, 0x78" : "=&s"(dcm) : "s"(ka) : "memory");
+        asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hot.v), "+s"(gq.v), "+s"(gq2), "+s"(dcm) : "s"(ka) : "memory");
     } else {
-        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hot.v) : "s"(ka) : "memory");
+        asm volatile("s_load_dwordx2 %0, %1, 0x78" : "=&s"(dcm) : "s"(ka) : "memory");
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hot.v), "+s"(dcm) : "s"(ka) : "memory");
     }
     // the camera block as a plain pointer for the rare out-of-line paths (a reference to the by-value kernel argument
     // would make the compiler copy all of WarpParams to scratch)
-    const WarpCam* const cg = (const WarpCam*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.x * sizeof(WarpCam));
+    const WarpCam* const cg = (const WarpCam*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + ci * sizeof(WarpCam));
     // the pointers come out of the asm block without an address space: say "global", or every access is a flat_load
 #define PANO_GLOBAL __attribute__((address_space(1)))
     const uint8_t PANO_GLOBAL* const src = (const uint8_t PANO_GLOBAL*)hot.h.src;
@@ -543,8 +569,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // the grid is laid over the live blocks of the camera: workgroup (0, 0) is block (live_bx0, live_by0); the dead
     // block columns in the middle of a +-pi straddler (gap_len from gap_bx0 on, else 0) are stepped over
     const unsigned lg = (unsigned)hot.h.live_by0_gap;
-    int bx = hot.h.live_bx0 + (int)blockIdx.y;
-    const int by = (int)(lg & 0xfffu) + (int)blockIdx.z;
+    const unsigned dl = lin - dstart;                                   // position among this camera's live blocks, row after row
+    const unsigned drow = dcm.y ? __umulhi(dl, dcm.y) : dl;             // dl / deal_cols
+    int bx = hot.h.live_bx0 + (int)(dl - drow * dcm.x);
+    const int by = (int)(lg & 0xfffu) + (int)drow;
     if (bx >= (int)((lg >> 12) & 0x3ffu)) bx += (int)(lg >> 22);
     const unsigned stride = (unsigned)hot.h.src_stride;
     const unsigned dst_pitch = (unsigned)hot.h.dst_pitch, dst_plane = (unsigned)hot.h.dst_plane, lutc_pitch = (unsigned)hot.h.lutc_pitch;
@@ -780,6 +808,25 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
     }
     lbx = max(lbx, 1); lby = max(lby, 1);  // nothing live (empty masks): one workgroup that leaves at once keeps the events valid
     const dim3 grid_lut(ncam, lbx, lby);
+    // the LDS kernel's own deal (WarpDeal): every camera's live blocks in one list, an eighth of it per XCD
+    WarpParams q = p;
+    {
+        unsigned total = 0;
+        for (int i = 0; i < kCams; i++) {
+            if (i < ncam) {
+                WarpCam& c = q.cam[i];
+                const int nbx = (c.tw + 63) / 64, nby = (c.th + 15) / 16;
+                const int cols = min(c.live_bx1, nbx - 1) - c.live_bx0 + 1 - (int)((unsigned)c.live_by0_gap >> 22);
+                const int rows = min(c.live_by1, nby - 1) - (c.live_by0_gap & 0xfff) + 1;
+                c.deal_cols = (unsigned)max(cols, 1);
+                c.deal_mcols = c.deal_cols > 1 ? (unsigned)((1ull << 32) / c.deal_cols + 1ull) : 0u;
+                if (cols > 0 && rows > 0) total += (unsigned)cols * (unsigned)rows;
+            }
+            q.deal.end[i] = total;
+        }
+        q.deal.per = max((total + 7u) / 8u, 1u);
+    }
+    const dim3 grid_deal(8, q.deal.per, 1);
     // Tried and rejected on the blocks WITHIN a camera (A/B in one process, same outputs): (1) an XCD-aware block order
     // and (2) padding the column blocks to a multiple of 8 so that each XCD owns a 256-pixel column stripe.  Both cut the
     // fetched bytes to the minimum and both ran slower (23.8 / 27.1 us vs 21.8 us per 4-camera launch): concentrating
@@ -790,8 +837,8 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
     for (int i = 0; i < ncam; i++) all_lut &= p.cam[i].lut != nullptr;
 #define PANO_LAUNCH_K1(K, G)                                                                   \
     do {                                                                                       \
-        if (ev_start && ev_stop) hipExtLaunchKernelGGL(K, G, block, 0, s, ev_start, ev_stop, 0, p); \
-        else hipLaunchKernelGGL(K, G, block, 0, s, p);                                        \
+        if (ev_start && ev_stop) hipExtLaunchKernelGGL(K, G, block, 0, s, ev_start, ev_stop, 0, q); \
+        else hipLaunchKernelGGL(K, G, block, 0, s, q);                                        \
     } while (0)
     if (all_lut) {
         // the LDS kernel wants 4-byte aligned frames and strides % 16 == 0; anything else takes the general kernel (same
@@ -802,8 +849,8 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
                     p.cam[i].box != nullptr;
         bool gains = false;
         for (int i = 0; i < ncam; i++) gains |= p.cam[i].gain != nullptr;
-        if (fast && gains) PANO_LAUNCH_K1(warp_tiles_lut_kernel<true>, grid_lut);
-        else if (fast) PANO_LAUNCH_K1(warp_tiles_lut_kernel<false>, grid_lut);
+        if (fast && gains) PANO_LAUNCH_K1(warp_tiles_lut_kernel<true>, grid_deal);
+        else if (fast) PANO_LAUNCH_K1(warp_tiles_lut_kernel<false>, grid_deal);
         else PANO_LAUNCH_K1(warp_tiles_lut_checked_kernel, grid_lut);
     }
     else {
