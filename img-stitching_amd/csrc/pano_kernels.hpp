@@ -75,13 +75,12 @@ inline int warp_pack_live(int live_by0, int gap_bx0, int gap_len) { return live_
 // joints: dealt camera = XCD, the XCDs of config 2's largest cameras ran 23 % more waves than those of the smallest (5208 against
 // 4216) and finished 4 us after them (tools/wave_timeline.py).  Config 2: 18.2 -> 17.9 us warm, 21.8 -> 20.9 cold; config 4:
 // 60.1 -> 56.3 us (66.0 -> 63.2 with gains).
-struct WarpDeal {
+struct WarpDeal {         // passed to the kernel as nine scalar arguments (preloaded into SGPRs at wave launch)
     unsigned end[kCams];  // end[c] = blocks of cameras 0..c (cameras past the last: the total)
     unsigned per;         // blocks per XCD = ceil(total / 8)
 };
 struct WarpParams {
     WarpCam cam[kCams];
-    WarpDeal deal;
 };
 
 // one camera's pyramid slot.  Every Gaussian level of an 8-bit image stays in [0,255], so the levels are

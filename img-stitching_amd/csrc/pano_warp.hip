@@ -485,8 +485,13 @@ __global__ __launch_bounds__(256) void warp_tiles_lut_checked_kernel(WarpParams 
 // (checked by the launcher; anything else runs warp_tiles_lut_checked_kernel).
 // GAIN: an instantiation of its own that also applies the exposure gain maps (BlocksGainCompensator::apply) of the
 // cameras that carry one; the plain instantiation stays at 37 VGPRs.
+// The deal (WarpDeal) travels as nine scalar arguments IN FRONT of the camera blocks: gfx950 preloads the first kernel arguments into
+// SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=9), so finding the block costs no memory round trip.
+constexpr unsigned kWarpParamsAt = 64;  // offset of P in the kernarg segment: 9 dwords, then alignof(WarpParams)
 template <bool GAIN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void warp_tiles_lut_kernel(WarpParams P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void warp_tiles_lut_kernel(
+    unsigned de0, unsigned de1, unsigned de2, unsigned de3, unsigned de4, unsigned de5, unsigned de6, unsigned de7, unsigned dper, WarpParams P) {
+    static_assert(alignof(WarpParams) == 64, "kWarpParamsAt");
     __shared__ uint4 sbox[kBoxBytes / 16];
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     // GAIN: the workgroup's 64 columns of up to kGainRows rows of ghrow, then its 16 row entries {sy0, sy1, 1 - fy, fy} (as bits)
@@ -513,16 +518,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     union { i32x16 v; Hot h; } hot;
     // WarpParams is the only kernel argument: P.cam[i] sits at kernarg + i * sizeof(WarpCam)
     // Which block is this?  (WarpDeal)  blockIdx.x = XCD, blockIdx.y = position in the XCD's share of the list of live blocks
-    typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
-    u32x8 dend;
-    unsigned dper;
-    {
-        static_assert(offsetof(WarpParams, deal) == sizeof(WarpCam) * kCams && offsetof(WarpDeal, per) == 32 && kCams == 8, "deal layout");
-        const char __attribute__((address_space(4)))* kd =
-            (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(WarpCam) * kCams;
-        // early clobber: the address is read again by the second load, after the first may have landed
-        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dend), "=&s"(dper) : "s"(kd) : "memory");
-    }
+    const unsigned dend[kCams] = {de0, de1, de2, de3, de4, de5, de6, de7};
+    static_assert(kCams == 8, "eight end arguments");
     const unsigned lin = blockIdx.x * dper + blockIdx.y;
     if (lin >= dend[kCams - 1]) return;  // past the end of the list (the whole workgroup leaves)
     unsigned ci = 0, dstart = 0;
@@ -534,7 +531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         }
     }
     const char __attribute__((address_space(4)))* ka =
-        (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + ci * sizeof(WarpCam);
+        (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + (kWarpParamsAt + ci * sizeof(WarpCam));
     // GAIN: the camera's gain block {gain, grow_base, ghrow, grow4 | ghrow_pitch, gh} rides along (two more scalar loads in
     // flight with the first), so that the workgroup's gain rows can be requested together with its source box
     typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -559,7 +556,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
     // the camera block as a plain pointer for the rare out-of-line paths (a reference to the by-value kernel argument
     // would make the compiler copy all of WarpParams to scratch)
-    const WarpCam* const cg = (const WarpCam*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + ci * sizeof(WarpCam));
+    const WarpCam* const cg = (const WarpCam*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + (kWarpParamsAt + ci * sizeof(WarpCam)));
     // the pointers come out of the asm block without an address space: say "global", or every access is a flat_load
 #define PANO_GLOBAL __attribute__((address_space(1)))
     const uint8_t PANO_GLOBAL* const src = (const uint8_t PANO_GLOBAL*)hot.h.src;
@@ -810,6 +807,7 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
     const dim3 grid_lut(ncam, lbx, lby);
     // the LDS kernel's own deal (WarpDeal): every camera's live blocks in one list, an eighth of it per XCD
     WarpParams q = p;
+    WarpDeal deal;
     {
         unsigned total = 0;
         for (int i = 0; i < kCams; i++) {
@@ -822,11 +820,11 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
                 c.deal_mcols = c.deal_cols > 1 ? (unsigned)((1ull << 32) / c.deal_cols + 1ull) : 0u;
                 if (cols > 0 && rows > 0) total += (unsigned)cols * (unsigned)rows;
             }
-            q.deal.end[i] = total;
+            deal.end[i] = total;
         }
-        q.deal.per = max((total + 7u) / 8u, 1u);
+        deal.per = max((total + 7u) / 8u, 1u);
     }
-    const dim3 grid_deal(8, q.deal.per, 1);
+    const dim3 grid_deal(8, deal.per, 1);
     // Tried and rejected on the blocks WITHIN a camera (A/B in one process, same outputs): (1) an XCD-aware block order
     // and (2) padding the column blocks to a multiple of 8 so that each XCD owns a 256-pixel column stripe.  Both cut the
     // fetched bytes to the minimum and both ran slower (23.8 / 27.1 us vs 21.8 us per 4-camera launch): concentrating
@@ -849,8 +847,16 @@ void launch_warp_tiles(const WarpParams& p, int ncam, int max_tw, int max_th, hi
                     p.cam[i].box != nullptr;
         bool gains = false;
         for (int i = 0; i < ncam; i++) gains |= p.cam[i].gain != nullptr;
-        if (fast && gains) PANO_LAUNCH_K1(warp_tiles_lut_kernel<true>, grid_deal);
-        else if (fast) PANO_LAUNCH_K1(warp_tiles_lut_kernel<false>, grid_deal);
+#define PANO_LAUNCH_K1_DEAL(K)                                                                                                    \
+    do {                                                                                                                          \
+        const unsigned* e = deal.end;                                                                                             \
+        if (ev_start && ev_stop)                                                                                                  \
+            hipExtLaunchKernelGGL(K, grid_deal, block, 0, s, ev_start, ev_stop, 0, e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], deal.per, q); \
+        else hipLaunchKernelGGL(K, grid_deal, block, 0, s, e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], deal.per, q);         \
+    } while (0)
+        if (fast && gains) PANO_LAUNCH_K1_DEAL(warp_tiles_lut_kernel<true>);
+        else if (fast) PANO_LAUNCH_K1_DEAL(warp_tiles_lut_kernel<false>);
+#undef PANO_LAUNCH_K1_DEAL
         else PANO_LAUNCH_K1(warp_tiles_lut_checked_kernel, grid_lut);
     }
     else {
