@@ -610,7 +610,7 @@ pano_status build_tile_order(pano_ctx* c, hipStream_t s) {
     const int w = cv.cut_x + cv.cut_w - (cv.cut_x & ~3), h = cv.cut_y + cv.cut_h - (cv.cut_y & ~1);
     const int gx = (w + 127) / 128, gy = (h + 15) / 16;
     const size_t T = (size_t)gx * gy;
-    if (T == 0 || T >= 0xffffu) return PANO_OK;
+    if (T == 0 || gx >= 255 || gy >= 255) return PANO_OK;  // an entry holds bx and by in a byte each
     const size_t per = (T + 7) / 8;
     uint16_t* d_flags = nullptr;
     HIP_TRY(c, hipMalloc((void**)&d_flags, T * sizeof(uint16_t)));
@@ -627,7 +627,7 @@ pano_status build_tile_order(pano_ctx* c, hipStream_t s) {
         size_t o = lo;
         for (int pass = 1; pass >= 0; pass--)
             for (size_t t = lo; t < hi; t++)
-                if ((int)mixed(flags[t]) == pass) order[o++] = (uint32_t)t | (uint32_t)flags[t] << 16;
+                if ((int)mixed(flags[t]) == pass) order[o++] = (uint32_t)(t % gx) | (uint32_t)(t / gx) << 8 | (uint32_t)flags[t] << 16;
     }
     if (c->order_cap < order.size()) {
         dfree(c->order0);

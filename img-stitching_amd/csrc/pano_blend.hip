@@ -501,25 +501,29 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
 // NPL = 3: a lane does the three colour planes of its block.  NPL = 1 (canvas levels >= 1 only, where planes are stored
 // apart): grid.z = canvas * 3 + plane and a lane does one plane - a third of the serial work per wave, three times the
 // waves: these levels are one round of waves whose seam waves set the kernel's duration.
+// The scalars IN FRONT of the parameter blocks arrive in SGPRs at wave launch (kernarg preload, see the Makefile): what a wave needs
+// to find its tile costs ONE memory round trip (the order-table entry) - read field by field out of the by-value blocks, behind the
+// early exits, it was a chain of six (1.4 of a wave's 6.2 us, tools/wave_timeline_l0.py).
+//   shape 4 (level 0, ordered): grid (8 * max per, canvases); ord0 / ord1 = the canvases' order tables, a0 / a1 = their entries per XCD
+//   shape 3 (XCD bands): a 1-D grid; a0 / a1 = the multipliers that divide by gx and gy (2^32 / d + 1; 0: d == 1)
 template <bool L0, int NPL = 3>
-__global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, CanvasSet CS, int lvl) {
+__global__ __launch_bounds__(256) void blend_level_vec_kernel(int lvl, const uint32_t* ord0, const uint32_t* ord1, unsigned a0, unsigned a1,
+                                                              PyrParams P, CanvasSet CS) {
     static_assert(NPL == 3 || !L0, "level 0 writes interleaved BGR");
     unsigned bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
     unsigned hint = 0xfu;  // what the wave will find in the owner map, when a static table has said so (else 0xF: look)
     if (L0 && NPL == 3 && ((lvl >> 8) & 15) == 4) {
         // XCD bands with the seam tiles first (shape 4, level 0): the band of XCD k is walked in the order of the static table
         // CanvasParams::order0 - tiles that hold a wave without a single owner (the general path: four times the instructions,
-        // two dependent rounds of loads) come first, so their long chains run under the bulk instead of behind it
-        const unsigned maxper = ((unsigned)lvl >> 12) & 0xfffffu;
-        const unsigned k = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        const unsigned cvi = j / maxper, jj = j - cvi * maxper;
-        if (cvi >= (unsigned)CS.n) return;
-        const CanvasParams& Cq = CS.c[cvi];
-        if (jj >= (unsigned)Cq.order_per) return;
-        const unsigned ent = Cq.order0[k * Cq.order_per + jj];  // uniform: a scalar load
-        const unsigned tile = ent & 0xffffu;
-        if (tile == 0xffffu) return;
-        bxi = tile % (unsigned)Cq.order_gx; byi = tile / (unsigned)Cq.order_gx; bzi = cvi;
+        // two dependent rounds of loads) come first, so their long chains run under the bulk instead of behind it.
+        // entry: bx | by << 8 | the four waves' owner nibbles << 16 (0xffff in the low half: no tile)
+        const unsigned k = blockIdx.x & 7u, jj = blockIdx.x >> 3;
+        const unsigned per = blockIdx.y ? a1 : a0;
+        const uint32_t* ord = blockIdx.y ? ord1 : ord0;
+        if (jj >= per) return;
+        const unsigned ent = ord[k * per + jj];  // uniform: a scalar load
+        if ((ent & 0xffffu) == 0xffffu) return;
+        bxi = ent & 0xffu; byi = (ent >> 8) & 0xffu; bzi = blockIdx.y;
         hint = (ent >> (16 + 4 * __builtin_amdgcn_readfirstlane(threadIdx.y))) & 0xfu;
     } else if (((lvl >> 8) & 15) == 3) {
         // XCD bands (shape 3): a 1-D grid of 8 * per workgroups; the hardware deals consecutive ids round-robin
@@ -530,7 +534,10 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(PyrParams P, Canva
         const unsigned per = (total + 7u) / 8u;
         const unsigned logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
         if ((blockIdx.x >> 3) >= per || logical >= total) return;
-        bxi = logical % gx; byi = (logical / gx) % gy; bzi = logical / (gx * gy);
+        const unsigned row = a0 ? __umulhi(logical, a0) : logical;  // logical / gx
+        bxi = logical - row * gx;
+        bzi = a1 ? __umulhi(row, a1) : row;                         // row / gy
+        byi = row - bzi * gy;
     }
     const int pb = NPL == 3 ? 0 : (int)(bzi % 3);  // first plane of this lane
     const CanvasParams& C = CS.c[NPL == 3 ? bzi : bzi / 3];
@@ -623,9 +630,10 @@ void launch_tile_mixed(const CanvasParams& c, int gx, int gy, uint16_t* flags, h
 void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
 #define PANO_LAUNCH_L0(K, G)                                                                         \
     do {                                                                                             \
-        if (ev_start && ev_stop) hipExtLaunchKernelGGL(K, G, block, 0, s, ev_start, ev_stop, 0, p, cs, karg); \
-        else hipLaunchKernelGGL(K, G, block, 0, s, p, cs, karg);                                    \
+        if (ev_start && ev_stop) hipExtLaunchKernelGGL(K, G, block, 0, s, ev_start, ev_stop, 0, karg, ko0, ko1, ka0, ka1, p, cs); \
+        else hipLaunchKernelGGL(K, G, block, 0, s, karg, ko0, ko1, ka0, ka1, p, cs);                \
     } while (0)
+    auto magic = [](unsigned d) { return d > 1 ? (unsigned)((1ull << 32) / d + 1ull) : 0u; };
     const CanvasParams& c = cs.c[0];
     if (c.fast[l]) {
         int w = 0, h = 0;
@@ -660,14 +668,19 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
                 maxper = max(maxper, (unsigned)cs.c[g].order_per);
             }
             if (ordered && maxper > 0 && maxper < (1u << 20)) {  // XCD bands, seam tiles first
-                const int karg = (4 << 8) | (int)(maxper << 12);
-                PANO_LAUNCH_L0((blend_level_vec_kernel<true, 3>), dim3(8u * maxper * cs.n, 1, 1));
+                const int karg = 4 << 8;
+                const uint32_t *ko0 = cs.c[0].order0, *ko1 = cs.n > 1 ? cs.c[1].order0 : nullptr;
+                const unsigned ka0 = (unsigned)cs.c[0].order_per, ka1 = cs.n > 1 ? (unsigned)cs.c[1].order_per : 0u;
+                PANO_LAUNCH_L0((blend_level_vec_kernel<true, 3>), dim3(8u * maxper, cs.n, 1));
             } else {
                 const int karg = larg;
+                const uint32_t *ko0 = nullptr, *ko1 = nullptr;
+                const unsigned ka0 = magic(grid3.x), ka1 = magic(grid3.y);
                 PANO_LAUNCH_L0((blend_level_vec_kernel<true, 3>), grid);
             }
         } else {
-            hipLaunchKernelGGL((blend_level_vec_kernel<false, 1>), shape == 3 ? grid : dim3(grid.x, grid.y, cs.n * 3), block, 0, s, p, cs, larg);
+            hipLaunchKernelGGL((blend_level_vec_kernel<false, 1>), shape == 3 ? grid : dim3(grid.x, grid.y, cs.n * 3), block, 0, s, larg,
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, magic(grid3.x), magic(grid3.y), p, cs);
         }
         return;
     }

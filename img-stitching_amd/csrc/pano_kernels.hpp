@@ -113,7 +113,7 @@ struct CanvasParams {
     int opitch[kLevels];       // owner entries per block row
     int small_base;            // >0: levels small_base..bands run as one normalise launch + one LDS collapse launch
     const uint32_t* order0;    // level 0, or nullptr: per XCD band (order_per entries each, low half 0xffff = none) the 128 x 16-pixel
-    int order_per, order_gx;   // workgroup tiles in the order they are dispatched - seam tiles first; tile = by * order_gx + bx;
+    int order_per, order_gx;   // workgroup tiles in the order they are dispatched - seam tiles first; low half = bx | by << 8;
                                // high half: what the tile's four waves will find in the owner map, a nibble each (wave = threadIdx.y):
                                // 0..7 the single owner of every block of the wave, 0xE no owner anywhere, 0xF look it up
     int cam_lo, cam_n;         // this canvas blends cameras [cam_lo, cam_lo + cam_n) of the PyrParams it is launched with
