@@ -20,26 +20,54 @@ namespace pano {
 #define PANO_PYR_ROWS_UP 4
 #endif
 constexpr int kPyrRows0 = PANO_PYR_ROWS, kPyrRowsUp = PANO_PYR_ROWS_UP;  // output rows per lane: level 0 -> 1, the levels above
+// Prologue: cam_bits and l lead the arguments (preloaded into SGPRs at wave launch, see the Makefile), and the camera's fields
+// of the two levels are requested TOGETHER - six scalar loads, one wait.  Read field by field behind the early exits they were
+// seven dependent round trips per wave (about 1 us of a wave that lives 2 - 3).
+constexpr unsigned kPyrParamsAt = 8;  // offset of P in the kernarg segment: two dwords in front of it
 template <int R>
-__global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam_bits, int l) {
+__global__ __launch_bounds__(256) void pyr_down_kernel(unsigned cam_bits, int l, PyrParams P) {
+    static_assert(alignof(PyrParams) == 8, "kPyrParamsAt");
     constexpr int NR = 2 * R + 3;  // source rows of R output rows
     const int ci = blockIdx.z / 3, pl = blockIdx.z - ci * 3;
     if (!((cam_bits >> ci) & 1u)) return;
-    const PyrCam& c = P.cam[ci];
-    const int sw = c.w0 >> l, sh = c.h0 >> l;
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    i32x2 cwh, cgap, cpitch, cplane;
+    i32x4 clive;
+    u64x2 clvl;
+    {
+        const char __attribute__((address_space(4)))* cb =
+            (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + (kPyrParamsAt + (unsigned)ci * sizeof(PyrCam));
+        const char __attribute__((address_space(4)))* a_live = cb + (offsetof(PyrCam, live) + (unsigned)(l + 1) * 16u);
+        const char __attribute__((address_space(4)))* a_gap = cb + (offsetof(PyrCam, gap) + (unsigned)(l + 1) * 8u);
+        const char __attribute__((address_space(4)))* a_lvl = cb + (offsetof(PyrCam, lvl) + (unsigned)l * 8u);
+        const char __attribute__((address_space(4)))* a_pitch = cb + (offsetof(PyrCam, pitch) + (unsigned)l * 4u);
+        const char __attribute__((address_space(4)))* a_plane = cb + (offsetof(PyrCam, plane) + (unsigned)l * 4u);
+        const char __attribute__((address_space(4)))* a_wh = cb + offsetof(PyrCam, w0);
+        static_assert(offsetof(PyrCam, h0) == offsetof(PyrCam, w0) + 4, "w0, h0 adjacent");
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(cwh) : "s"(a_wh) : "memory");
+        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(clive) : "s"(a_live) : "memory");
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(cgap) : "s"(a_gap) : "memory");
+        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(clvl) : "s"(a_lvl) : "memory");
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(cpitch) : "s"(a_pitch) : "memory");
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(cplane) : "s"(a_plane) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cwh), "+s"(clive), "+s"(cgap), "+s"(clvl), "+s"(cpitch), "+s"(cplane) : : "memory");
+    }
+    const int sw = cwh.x >> l, sh = cwh.y >> l;
     const int dw = sw >> 1, dh = sh >> 1;
     // Outputs of level l + 1 that nothing downstream reads are not produced (their inputs may not exist either): the
     // grid is laid over the live rect, so that whole waves - not lanes - fall off its far side.
-    const int lx0 = c.live[l + 1][0], ly0 = c.live[l + 1][1], lx1 = c.live[l + 1][2], ly1 = c.live[l + 1][3];
+    const int lx0 = clive.x, ly0 = clive.y, lx1 = clive.z, ly1 = clive.w;
     const int t = (lx0 >> 2) + blockIdx.x * 64 + threadIdx.x;  // group of 4 output columns
     // a wave is one threadIdx.y: tell the compiler, and the row indices, the REFLECT_101 of the source rows and
     // their addresses are scalar work (a quarter of this kernel's vector instructions otherwise)
     const int y0 = ((int)((unsigned)ly0 / R) + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * R;  // first of R output rows
     if (y0 >= dh || y0 > ly1) return;
     if (t * 4 >= dw || t * 4 > lx1) return;
-    if (t * 4 >= c.gap[l + 1][0] && t * 4 + 3 <= c.gap[l + 1][1]) return;  // the dead middle of a +-pi straddler's tile
-    const uint8_t* __restrict__ src = c.lvl[l] + (size_t)pl * c.plane[l];
-    const int sp = c.pitch[l];
+    if (t * 4 >= cgap.x && t * 4 + 3 <= cgap.y) return;  // the dead middle of a +-pi straddler's tile
+    const uint8_t* __restrict__ src = (const uint8_t*)clvl.x + (size_t)pl * cplane.x;
+    const int sp = cpitch.x;
     // Every lane does NR 16-byte loads (columns 8t-4 .. 8t+11; lane 0 loads columns 0..15 and shifts).
     // REFLECT_101 at the two row ends touches at most three bytes, patched in registers:
     //   left  (t == 0): columns -2, -1 are columns 2, 1
@@ -48,7 +76,11 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam
     uint4 q[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++)
-        q[r] = *reinterpret_cast<const uint4*>(src + ((unsigned)(reflect101_idx(2 * y0 - 2 + r, sh) * sp) + (unsigned)off));  // scalar row + lane offset
+    {   // one 16-byte load at a 4-byte aligned address (left to itself the compiler made it an 8- and a 12-byte load that overlap)
+        typedef unsigned u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+        const u32x4a v = *reinterpret_cast<const u32x4a*>(src + ((unsigned)(reflect101_idx(2 * y0 - 2 + r, sh) * sp) + (unsigned)off));  // scalar row + lane offset
+        q[r] = make_uint4(v.x, v.y, v.z, v.w);
+    }
     if (t == 0) {
 #pragma unroll
         for (int r = 0; r < NR; r++) {
@@ -95,13 +127,13 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrParams P, unsigned cam
             for (int j = 0; j < 4; j++) acc[o][j] += h[j] * wk;
         }
     }
-    uint8_t* d = c.lvl[l + 1] + (size_t)pl * c.plane[l + 1] + (size_t)y0 * c.pitch[l + 1] + 4 * t;
+    uint8_t* d = (uint8_t*)clvl.y + (size_t)pl * cplane.y + (size_t)y0 * cpitch.y + 4 * t;
 #pragma unroll
     for (int o = 0; o < R; o++) {
         unsigned px = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) px |= (unsigned)(acc[o][j] >> 8) << (8 * j);  // no saturate_cast: the taps sum to 256, so 255 is the largest value there is
-        if (o == 0 || y0 + o < dh) *reinterpret_cast<unsigned*>(d + (size_t)o * c.pitch[l + 1]) = px;  // rows are padded to 16 bytes
+        if (o == 0 || y0 + o < dh) *reinterpret_cast<unsigned*>(d + (size_t)o * cpitch.y) = px;  // rows are padded to 16 bytes
     }
 }
 
@@ -358,8 +390,8 @@ void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s
     if (mw == 0 || mh == 0) return;
     const int R = l == 0 ? kPyrRows0 : kPyrRowsUp;
     dim3 block(64, 4, 1), grid((mw + 255) / 256, (mh + 4 * R - 1) / (4 * R), p.ncam * 3);
-    if (l == 0) hipLaunchKernelGGL(pyr_down_kernel<kPyrRows0>, grid, block, 0, s, p, cam_bits, l);
-    else hipLaunchKernelGGL(pyr_down_kernel<kPyrRowsUp>, grid, block, 0, s, p, cam_bits, l);
+    if (l == 0) hipLaunchKernelGGL(pyr_down_kernel<kPyrRows0>, grid, block, 0, s, cam_bits, l, p);
+    else hipLaunchKernelGGL(pyr_down_kernel<kPyrRowsUp>, grid, block, 0, s, cam_bits, l, p);
 }
 
 }  // namespace pano
