@@ -203,13 +203,47 @@ __device__ __forceinline__ void tail_put(uint8_t* box, int pitch, int bx0, int b
 }
 
 template <int TS, int THREADS, int MJ>
-__global__ __launch_bounds__(THREADS) void pyr_tail_kernel(PyrParams P, unsigned cam_bits, int b, int t) {
+__global__ __launch_bounds__(THREADS) void pyr_tail_kernel(unsigned cam_bits, int b, int t, PyrParams P) {
     static_assert(MJ >= 1 && MJ <= kTailMaxJ && tail_cap(TS, MJ, 0) % 8 == 0 && tail_cap(TS, MJ, 1) % 8 == 0 && tail_cap(TS, MJ, 2) % 8 == 0 &&
                       tail_cap(TS, MJ, 3) % 8 == 0, "LDS boxes 8-byte aligned");
     __shared__ __attribute__((aligned(16))) uint8_t lds[tail_lds_bytes(TS, MJ)];
     const int ci = blockIdx.z / 3, pl = blockIdx.z - ci * 3;
     if (!((cam_bits >> ci) & 1u)) return;
-    const PyrCam& c = P.cam[ci];
+    // The camera's fields of levels b .. b + 4, requested TOGETHER (cam_bits, b, t are preloaded): read where they are used -
+    // level after level, behind the block-uniform tests - they were fourteen dependent scalar round trips in front of the first
+    // row load, in a launch that is a single round of waves.  b <= kLevels - 5, so the reads stay inside PyrCam.
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
+    typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
+    struct {
+        i32x2 wh;      // w0, h0
+        i32x16 live;   // live[b + 1 .. b + 4][4]
+        i32x8 gap;     // gap[b + 1 .. b + 4][2]
+        u64x8 lvl;     // lvl[b .. b + 7] (the first five are used)
+        i32x8 pitch, plane;  // [b .. b + 7]
+    } c;
+    {
+        static_assert(alignof(PyrParams) == 8 && kLevels >= 9, "P sits 16 bytes into the kernarg segment; b + 4 < kLevels");
+        const char __attribute__((address_space(4)))* cb =
+            (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + (16u + (unsigned)ci * sizeof(PyrCam));
+        const char __attribute__((address_space(4)))* a_wh = cb + offsetof(PyrCam, w0);
+        const char __attribute__((address_space(4)))* a_live = cb + (offsetof(PyrCam, live) + (unsigned)(b + 1) * 16u);
+        const char __attribute__((address_space(4)))* a_gap = cb + (offsetof(PyrCam, gap) + (unsigned)(b + 1) * 8u);
+        const char __attribute__((address_space(4)))* a_lvl = cb + (offsetof(PyrCam, lvl) + (unsigned)b * 8u);
+        const char __attribute__((address_space(4)))* a_pitch = cb + (offsetof(PyrCam, pitch) + (unsigned)b * 4u);
+        const char __attribute__((address_space(4)))* a_plane = cb + (offsetof(PyrCam, plane) + (unsigned)b * 4u);
+        static_assert(offsetof(PyrCam, lvl) + 4 * 8 + 64 <= sizeof(PyrCam) && offsetof(PyrCam, pitch) + 4 * 4 + 32 <= sizeof(PyrCam) &&
+                          offsetof(PyrCam, plane) + 4 * 4 + 32 <= sizeof(PyrCam) && offsetof(PyrCam, live) + 5 * 16 + 64 <= sizeof(PyrCam) &&
+                          offsetof(PyrCam, gap) + 5 * 8 + 32 <= sizeof(PyrCam), "the batched reads stay inside PyrCam for b <= 4");
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(c.wh) : "s"(a_wh) : "memory");
+        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(c.live) : "s"(a_live) : "memory");
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(c.gap) : "s"(a_gap) : "memory");
+        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(c.lvl) : "s"(a_lvl) : "memory");
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(c.pitch) : "s"(a_pitch) : "memory");
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(c.plane) : "s"(a_plane) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c.wh), "+s"(c.live), "+s"(c.gap), "+s"(c.lvl), "+s"(c.pitch), "+s"(c.plane) : : "memory");
+    }
     const int J = t - b;  // <= MJ
     const int tid = threadIdx.y * 64 + threadIdx.x;
     // what this workgroup owns and needs of every level, top down (block-uniform: scalar registers)
@@ -221,13 +255,13 @@ __global__ __launch_bounds__(THREADS) void pyr_tail_kernel(PyrParams P, unsigned
         if (j > J || j > MJ) continue;
         const int l = b + j;
         const int Tl = TS >> (j - 1);
-        const int w = c.w0 >> l, h = c.h0 >> l;
+        const int w = c.wh.x >> l, h = c.wh.y >> l;
         TailBox o;
-        o.x0 = max((int)blockIdx.x * Tl, c.live[l][0]);
-        o.x1 = min(min((int)blockIdx.x * Tl + Tl - 1, w - 1), c.live[l][2]);
-        o.y0 = max((int)blockIdx.y * Tl, c.live[l][1]);
-        o.y1 = min(min((int)blockIdx.y * Tl + Tl - 1, h - 1), c.live[l][3]);
-        if (o.x0 >= c.gap[l][0] && o.x1 <= c.gap[l][1]) o.x1 = o.x0 - 1;  // inside the dead middle of a +-pi straddler's tile
+        o.x0 = max((int)blockIdx.x * Tl, c.live[4 * (j - 1) + 0]);
+        o.x1 = min(min((int)blockIdx.x * Tl + Tl - 1, w - 1), c.live[4 * (j - 1) + 2]);
+        o.y0 = max((int)blockIdx.y * Tl, c.live[4 * (j - 1) + 1]);
+        o.y1 = min(min((int)blockIdx.y * Tl + Tl - 1, h - 1), c.live[4 * (j - 1) + 3]);
+        if (o.x0 >= c.gap[2 * (j - 1)] && o.x1 <= c.gap[2 * (j - 1) + 1]) o.x1 = o.x0 - 1;  // inside the dead middle of a +-pi straddler's tile
         if (tail_empty(o)) o = TailBox{0, 0, -1, -1};
         own[j] = o;
         TailBox n = o;
@@ -240,7 +274,7 @@ __global__ __launch_bounds__(THREADS) void pyr_tail_kernel(PyrParams P, unsigned
     }
     if (tail_empty(nx)) return;  // nothing of this tile is live at any level (the whole workgroup leaves)
     {
-        const int w = c.w0 >> b, h = c.h0 >> b;
+        const int w = c.wh.x >> b, h = c.wh.y >> b;
         own[0] = TailBox{0, 0, -1, -1};
         need[0] = TailBox{max(2 * nx.x0 - 2, 0), max(2 * nx.y0 - 2, 0), min(2 * nx.x1 + 2, w - 1), min(2 * nx.y1 + 2, h - 1)};
     }
@@ -253,7 +287,7 @@ __global__ __launch_bounds__(THREADS) void pyr_tail_kernel(PyrParams P, unsigned
 #pragma unroll
         for (int j = 0; j <= kTailMaxJ; j++) {
             const int ax = j == 0 ? 15 : 7;
-            const int w = c.w0 >> (b + j), h = c.h0 >> (b + j);
+            const int w = c.wh.x >> (b + j), h = c.wh.y >> (b + j);
             sx0[j] = need[j].x0 & ~ax;
             sy0[j] = need[j].y0;
             pitch[j] = tail_empty(need[j]) ? 0 : ((need[j].x1 | ax) - sx0[j] + 1) + 2 * kTailSlack;
@@ -265,9 +299,9 @@ __global__ __launch_bounds__(THREADS) void pyr_tail_kernel(PyrParams P, unsigned
     // level b: global -> LDS, 16-byte chunks; lanes = 16 chunk columns x THREADS / 16 rows, every load in flight before the
     // first store
     {
-        const int w = c.w0 >> b, h = c.h0 >> b;
+        const int w = c.wh.x >> b, h = c.wh.y >> b;
         const int nrows = need[0].y1 - need[0].y0 + 1;  // <= 2 TS + 2 halo
-        const uint8_t* g = c.lvl[b] + (size_t)pl * c.plane[b] + (unsigned)(sy0[0] * c.pitch[b] + sx0[0]);
+        const uint8_t* g = (const uint8_t*)c.lvl[0] + (size_t)pl * c.plane[0] + (unsigned)(sy0[0] * c.pitch[0] + sx0[0]);
         const int cpr = (pitch[0] - 2 * kTailSlack) >> 4;
         static_assert((tail_pitch(TS, MJ, 0) - 2 * kTailSlack) / 16 <= 16, "16 chunk columns");
         const int cx = tid & 15, cy = tid >> 4;
@@ -278,7 +312,7 @@ __global__ __launch_bounds__(THREADS) void pyr_tail_kernel(PyrParams P, unsigned
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
                 const int r = min(cy + kRowsPerPass * k, nrows - 1);
-                d[k] = *reinterpret_cast<const uint4*>(g + (unsigned)(r * c.pitch[b] + 16 * cx));
+                d[k] = *reinterpret_cast<const uint4*>(g + (unsigned)(r * c.pitch[0] + 16 * cx));
             }
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
@@ -296,7 +330,7 @@ __global__ __launch_bounds__(THREADS) void pyr_tail_kernel(PyrParams P, unsigned
     for (int j = 1; j <= MJ; j++) {
         if (j > J || tail_empty(need[j])) continue;  // block-uniform
         const int l = b + j;
-        const int dw = c.w0 >> l, dh = c.h0 >> l;
+        const int dw = c.wh.x >> l, dh = c.wh.y >> l;
         const uint8_t* S = lds + off[j - 1];
         const int ps = pitch[j - 1];
         // items = column groups need.x0 >> 2 .. need.x1 >> 2 (<= 24) x row pairs need.y0 >> 1 .. need.y1 >> 1 (<= 47), dealt
@@ -305,8 +339,8 @@ __global__ __launch_bounds__(THREADS) void pyr_tail_kernel(PyrParams P, unsigned
         const int r0 = need[j].y0 >> 1, nry = (need[j].y1 >> 1) - r0 + 1;
         const int nitems = ngx * nry;
         const unsigned rcp = (65536u + (unsigned)ngx - 1u) / (unsigned)ngx;  // item / ngx == item * rcp >> 16 for item < 2730
-        uint8_t* const gl = c.lvl[l] + (size_t)pl * c.plane[l];
-        const int gp = c.pitch[l];
+        uint8_t* const gl = (uint8_t*)c.lvl[j] + (size_t)pl * c.plane[j];
+        const int gp = c.pitch[j];
         for (int item = tid; item < nitems; item += THREADS) {
             const int rp = (int)(((unsigned)item * rcp) >> 16);
             const int tg = g0 + item - rp * ngx;  // group of four output columns 4 tg .. 4 tg + 3
@@ -373,7 +407,7 @@ void launch_pyr_tail(const PyrParams& p, unsigned cam_bits, int b, int t, hipStr
     const int T = kPyrTailTile >> (J - 1);  // tile of the top level
     if (T < 1) return;
     dim3 grid((mw + T - 1) / T, (mh + T - 1) / T, p.ncam * 3);
-#define PANO_TAIL(MJ_) hipLaunchKernelGGL((pyr_tail_kernel<kPyrTailTile, 256, MJ_>), grid, dim3(64, 4, 1), 0, s, p, cam_bits, b, t)
+#define PANO_TAIL(MJ_) hipLaunchKernelGGL((pyr_tail_kernel<kPyrTailTile, 256, MJ_>), grid, dim3(64, 4, 1), 0, s, cam_bits, b, t, p)
     if (J <= 2) PANO_TAIL(2);
     else if (J == 3) PANO_TAIL(3);
     else PANO_TAIL(4);
