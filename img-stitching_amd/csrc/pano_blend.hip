@@ -504,27 +504,15 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
 // The scalars IN FRONT of the parameter blocks arrive in SGPRs at wave launch (kernarg preload, see the Makefile): what a wave needs
 // to find its tile costs ONE memory round trip (the order-table entry) - read field by field out of the by-value blocks, behind the
 // early exits, it was a chain of six (1.4 of a wave's 6.2 us, tools/wave_timeline_l0.py).
-//   shape 4 (level 0, ordered): grid (8 * max per, canvases); ord0 / ord1 = the canvases' order tables, a0 / a1 = their entries per XCD
 //   shape 3 (XCD bands): a 1-D grid; a0 / a1 = the multipliers that divide by gx and gy (2^32 / d + 1; 0: d == 1)
+//   (level 0 in seam-first order is a kernel of its own: blend_level0_ordered_kernel)
 template <bool L0, int NPL = 3>
 __global__ __launch_bounds__(256) void blend_level_vec_kernel(int lvl, const uint32_t* ord0, const uint32_t* ord1, unsigned a0, unsigned a1,
                                                               PyrParams P, CanvasSet CS) {
     static_assert(NPL == 3 || !L0, "level 0 writes interleaved BGR");
     unsigned bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
     unsigned hint = 0xfu;  // what the wave will find in the owner map, when a static table has said so (else 0xF: look)
-    if (L0 && NPL == 3 && ((lvl >> 8) & 15) == 4) {
-        // XCD bands with the seam tiles first (shape 4, level 0): the band of XCD k is walked in the order of the static table
-        // CanvasParams::order0 - tiles that hold a wave without a single owner (the general path: four times the instructions,
-        // two dependent rounds of loads) come first, so their long chains run under the bulk instead of behind it.
-        // entry: bx | by << 8 | the four waves' owner nibbles << 16 (0xffff in the low half: no tile)
-        const unsigned k = blockIdx.x & 7u, jj = blockIdx.x >> 3;
-        const unsigned per = blockIdx.y ? a1 : a0;
-        const uint32_t* ord = blockIdx.y ? ord1 : ord0;
-        if (jj >= per) return;
-        const unsigned ent = ord[k * per + jj];  // uniform: a scalar load
-        if ((ent & 0xffffu) == 0xffffu) return;
-        bxi = ent & 0xffu; byi = (ent >> 8) & 0xffu; bzi = blockIdx.y;
-        hint = (ent >> (16 + 4 * __builtin_amdgcn_readfirstlane(threadIdx.y))) & 0xfu;
+    if (false) {
     } else if (((lvl >> 8) & 15) == 3) {
         // XCD bands (shape 3): a 1-D grid of 8 * per workgroups; the hardware deals consecutive ids round-robin
         // over the 8 XCDs, so XCD k is given the logical workgroups [k * per, (k + 1) * per) - a contiguous band of canvas
@@ -559,6 +547,58 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(int lvl, const uin
         return;
     }
     blend_block<L0, NPL>(P, C, l, X0, Y0, pb, hint);
+}
+
+// Level 0 in seam-first order: XCD bands, the band of XCD k walked in the order of the static table CanvasParams::order0 - tiles
+// that hold a wave without a single owner (the general path: four times the instructions, two dependent rounds of loads) come
+// first, so their long chains run under the bulk instead of behind it.  grid (8 * max entries per XCD, canvases).
+// entry: bx | by << 8 | the four waves' owner nibbles << 16 (0xffff in the low half: no tile).
+// A wave's scalar prologue is ONE round trip: the tables and their lengths are preloaded arguments, and the canvas fields the
+// level-0 path reads (CanvasParams::hot0) are requested by the wave's first instructions, in flight with the table entry.
+struct BlendOrderedArgs {  // the kernel's argument list as the kernarg segment lays it out
+    const uint32_t *ord0, *ord1;
+    unsigned per0, per1;
+    PyrParams P;
+    CanvasSet CS;
+};
+__global__ __launch_bounds__(256) void blend_level0_ordered_kernel(const uint32_t* ord0, const uint32_t* ord1, unsigned per0, unsigned per1,
+                                                                   PyrParams P, CanvasSet CS) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
+    i32x16 h;
+    i32x4 h2;
+    {
+        const char __attribute__((address_space(4)))* hb = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
+            (offsetof(BlendOrderedArgs, CS) + offsetof(CanvasSet, c) + blockIdx.y * sizeof(CanvasParams) + offsetof(CanvasParams, hot0));
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40" : "=&s"(h), "=&s"(h2) : "s"(hb) : "memory");
+    }
+    const unsigned k = blockIdx.x & 7u, jj = blockIdx.x >> 3;
+    const unsigned per = blockIdx.y ? per1 : per0;
+    const uint32_t* ord = blockIdx.y ? ord1 : ord0;
+    if (jj >= per) return;
+    unsigned ent;  // the table entry: a scalar load spelled out (behind the asm above the compiler would fetch it with a vector load)
+    {
+        const char __attribute__((address_space(4)))* ep = (const char __attribute__((address_space(4)))*)ord + (size_t)(k * per + jj) * 4u;
+        asm volatile("s_load_dword %0, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ent), "+s"(h), "+s"(h2) : "s"(ep) : "memory");
+    }
+    if ((ent & 0xffffu) == 0xffffu) return;
+    const unsigned bxi = ent & 0xffu, byi = (ent >> 8) & 0xffu;
+    const unsigned hint = (ent >> (16 + 4 * __builtin_amdgcn_readfirstlane(threadIdx.y))) & 0xfu;
+    CanvasParams C;  // only what the level-0 path reads (the rest is never touched: everything below is inlined with l == 0)
+    C.cut_x = h[0]; C.cut_y = h[1]; C.cut_w = h[2]; C.cut_h = h[3];
+    C.w0 = h[4]; C.h0 = h[5]; C.bands = h[6]; C.cam_lo = h[7];
+    C.out = (uint8_t*)(((unsigned long long)(unsigned)h[9] << 32) | (unsigned)h[8]);
+    C.out_stride = h[10];
+    C.opitch[0] = h[11];
+    C.img[1] = (int16_t*)(((unsigned long long)(unsigned)h[13] << 32) | (unsigned)h[12]);
+    C.owner[0] = (const uint16_t*)(((unsigned long long)(unsigned)h[15] << 32) | (unsigned)h[14]);
+    C.cpitch[1] = h2[0]; C.cplane[1] = h2[1];
+    // level 0 covers only the block-aligned hull of the cut rectangle; a wave is 16 x 4 blocks of 4 x 2 pixels, a workgroup 2 x 2 waves
+    const int bx0 = C.cut_x & ~3, by0 = C.cut_y & ~1;
+    const int X0 = bx0 + ((bxi * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
+    const int Y0 = by0 + ((byi * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * 2;
+    if (X0 >= C.cut_x + C.cut_w || Y0 >= C.cut_y + C.cut_h) return;
+    blend_block<true, 3>(P, C, 0, X0, Y0, 0, hint);
 }
 
 // owner map of a vector level: one byte per 4 x 2 block (see CanvasParams::owner)
@@ -668,10 +708,21 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
                 maxper = max(maxper, (unsigned)cs.c[g].order_per);
             }
             if (ordered && maxper > 0 && maxper < (1u << 20)) {  // XCD bands, seam tiles first
-                const int karg = 4 << 8;
                 const uint32_t *ko0 = cs.c[0].order0, *ko1 = cs.n > 1 ? cs.c[1].order0 : nullptr;
                 const unsigned ka0 = (unsigned)cs.c[0].order_per, ka1 = cs.n > 1 ? (unsigned)cs.c[1].order_per : 0u;
-                PANO_LAUNCH_L0((blend_level_vec_kernel<true, 3>), dim3(8u * maxper, cs.n, 1));
+                CanvasSet q = cs;
+                for (int g = 0; g < q.n; g++) {
+                    CanvasParams& C = q.c[g];
+                    const unsigned long long po = (unsigned long long)(size_t)C.out, pi = (unsigned long long)(size_t)C.img[1],
+                                             pw = (unsigned long long)(size_t)C.owner[0];
+                    const int hot[20] = {C.cut_x, C.cut_y, C.cut_w, C.cut_h, C.w0, C.h0, C.bands, C.cam_lo, (int)(unsigned)po, (int)(unsigned)(po >> 32),
+                                         C.out_stride, C.opitch[0], (int)(unsigned)pi, (int)(unsigned)(pi >> 32), (int)(unsigned)pw,
+                                         (int)(unsigned)(pw >> 32), C.cpitch[1], C.cplane[1], 0, 0};
+                    for (int i = 0; i < 20; i++) C.hot0[i] = hot[i];
+                }
+                const dim3 go(8u * maxper, cs.n, 1);
+                if (ev_start && ev_stop) hipExtLaunchKernelGGL(blend_level0_ordered_kernel, go, block, 0, s, ev_start, ev_stop, 0, ko0, ko1, ka0, ka1, p, q);
+                else hipLaunchKernelGGL(blend_level0_ordered_kernel, go, block, 0, s, ko0, ko1, ka0, ka1, p, q);
             } else {
                 const int karg = larg;
                 const uint32_t *ko0 = nullptr, *ko1 = nullptr;

@@ -124,6 +124,10 @@ struct CanvasParams {
     int out_stride;            // bytes
     int cut_x, cut_y, cut_w, cut_h;  // in padded-canvas coordinates (pano rect origin == canvas origin)
     int final_w, final_h;      // dst_roi_final size (unpadded)
+    // what the ordered level-0 kernel reads of this block, packed by launch_blend_level so that a wave fetches it with two scalar
+    // loads at its first instruction: {cut_x, cut_y, cut_w, cut_h, w0, h0, bands, cam_lo, out (2), out_stride, opitch[0],
+    // img[1] (2), owner[0] (2), cpitch[1], cplane[1], -, -}
+    alignas(16) int hot0[20];
 };
 
 // Up to two canvases (the reference's upper and lower stitcher) share every blend launch: grid.z picks the canvas.
