@@ -216,7 +216,7 @@ struct __attribute__((packed, aligned(1))) Bgr4 {
 // store a finished 4 x 2 block: canvas level (planar int16) or, at level 0, dst_mask + convertTo(8U) + cut
 // ALLON: every pixel of the block carries weight (dst_mask set) - the caller's guarantee, no per-pixel select
 template <bool L0, bool ALLON = false, int NPL = 3>
-__device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0, int Y0, const int v[3][2][4], bool o00,
+__device__ __forceinline__ void store_block(const BlendLevel& C, int l, int X0, int Y0, const int v[3][2][4], bool o00,
                                             bool o01, bool o02, bool o03, bool o10, bool o11, bool o12, bool o13, int pb = 0) {
     if (!L0) {
 #pragma unroll
@@ -226,7 +226,7 @@ __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0
                 uint2 pk;
                 pk.x = ((unsigned)v[pl][r][0] & 0xffffu) | ((unsigned)v[pl][r][1] << 16);
                 pk.y = ((unsigned)v[pl][r][2] & 0xffffu) | ((unsigned)v[pl][r][3] << 16);
-                *reinterpret_cast<uint2*>(C.img[l] + (size_t)(pb + pl) * C.cplane[l] + (unsigned)(__mul24(Y0 + r, C.cpitch[l]) + X0)) = pk;
+                *reinterpret_cast<uint2*>(C.img + (size_t)(pb + pl) * C.cplane + (unsigned)(__mul24(Y0 + r, C.cpitch) + X0)) = pk;
             }
     } else {
         const bool on[2][4] = {{o00, o01, o02, o03}, {o10, o11, o12, o13}};
@@ -268,10 +268,10 @@ __device__ __forceinline__ void store_block(const CanvasParams& C, int l, int X0
 // the cut hull): the wave-uniform single-owner path when every lane of the wave sits on the same owner, else the general
 // path.  pb: first plane of this lane (NPL == 1: one plane per lane)
 template <bool L0, int NPL>
-__device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasParams& C, const int l, const int X0, const int Y0,
+__device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel& C, const int l, const int X0, const int Y0,
                                             const int pb, const unsigned hint = 0xfu) {
     const int cam_lo = C.cam_lo;
-    const int cw = C.w0 >> l, ch = C.h0 >> l;
+    const int cw = C.cw, ch = C.ch;
     // Away from the seams a block belongs to exactly one camera with weight 1.0f everywhere (or to none):
     // the static owner map says so in one byte, and the block needs no weights, no float math and no division:
     //   acc = lap, W = 1  =>  norm = lap - sign(lap)  (see below)
@@ -284,7 +284,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
         ucode = hint < 8u ? hint : 0xfeu;
         single = true;
     } else {
-        entry = C.owner[l][(unsigned)(__mul24(Y0 >> 1, C.opitch[l]) + (X0 >> 2))];
+        entry = C.owner[(unsigned)(__mul24(Y0 >> 1, C.opitch) + (X0 >> 2))];
         const unsigned code = entry & 0xffu;
         ucode = __builtin_amdgcn_readfirstlane(code);
         single = ucode != 0xffu && __builtin_amdgcn_ballot_w64(code != ucode) == 0;
@@ -294,10 +294,10 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
         // and every load is in flight before the first use
         int v[3][2][4];
         unsigned cp[3][3][2];
-        if (l < C.bands) {
+        if (C.up) {
 #pragma unroll
             for (int pl = 0; pl < NPL; pl++) {
-                load_coarse<int16_t>(C.img[l + 1] + (size_t)(pb + pl) * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1],
+                load_coarse<int16_t>(C.img_up + (size_t)(pb + pl) * C.cplane_up, cw >> 1, ch >> 1, C.cpitch_up,
                                      X0 >> 1, Y0 >> 1, cp[pl]);
             }
         }
@@ -312,14 +312,14 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
                 const uint8_t* g = c.lvl[l] + (size_t)(pb + pl) * c.plane[l] + (unsigned)(__mul24(y, c.pitch[l]) + x);
                 g0[pl] = *reinterpret_cast<const unsigned*>(g);
                 g1[pl] = *reinterpret_cast<const unsigned*>(g + c.pitch[l]);
-                if (l < C.bands)
+                if (C.up)
                     load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)(pb + pl) * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1],
                                          x >> 1, y >> 1, p[pl]);
             }
 #pragma unroll
             for (int pl = 0; pl < NPL; pl++) {
                 int up[2][4];
-                if (l < C.bands) {
+                if (C.up) {
                     up_block<uint8_t>(p[pl], up);
                 } else {
 #pragma unroll
@@ -341,7 +341,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
 #pragma unroll
                     for (int k = 0; k < 4; k++) v[pl][r][k] = 0;
         }
-        if (l < C.bands) {
+        if (C.up) {
 #pragma unroll
             for (int pl = 0; pl < NPL; pl++) {
                 int up[2][4];
@@ -369,10 +369,10 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
     const unsigned live = entry >> 8;
     // the coarser canvas level: early on the latency-bound small levels, late (fewer live registers) on level 0
     unsigned cp[3][3][2];
-    if (!L0 && l < C.bands) {
+    if (!L0 && C.up) {
 #pragma unroll
         for (int pl = 0; pl < NPL; pl++)
-            load_coarse<int16_t>(C.img[l + 1] + (size_t)(pb + pl) * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
+            load_coarse<int16_t>(C.img_up + (size_t)(pb + pl) * C.cplane_up, cw >> 1, ch >> 1, C.cpitch_up, X0 >> 1,
                                  Y0 >> 1, cp[pl]);
     }
     // the accumulators are int16 by definition (dst += static_cast<short>(..) wraps): two per register (v_pk_add_i16) - the general
@@ -422,7 +422,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
             const uint8_t* g = c.lvl[l] + (size_t)(pb + pl) * c.plane[l] + (size_t)y * c.pitch[l] + x;
             g0[pl] = *reinterpret_cast<const unsigned*>(g);
             g1[pl] = *reinterpret_cast<const unsigned*>(g + c.pitch[l]);
-            if (l < C.bands)
+            if (C.up)
                 load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)(pb + pl) * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1], x >> 1,
                                      y >> 1, p[pl]);
         }
@@ -433,7 +433,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
 #pragma unroll
         for (int pl = 0; pl < NPL; pl++) {
             int up[2][4];
-            if (l < C.bands) {
+            if (C.up) {
                 up_block<uint8_t>(p[pl], up);
             } else {
 #pragma unroll
@@ -455,10 +455,10 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
             }
         }
     }
-    if (L0 && l < C.bands) {
+    if (L0 && C.up) {
 #pragma unroll
         for (int pl = 0; pl < NPL; pl++)
-            load_coarse<int16_t>(C.img[l + 1] + (size_t)(pb + pl) * C.cplane[l + 1], cw >> 1, ch >> 1, C.cpitch[l + 1], X0 >> 1,
+            load_coarse<int16_t>(C.img_up + (size_t)(pb + pl) * C.cplane_up, cw >> 1, ch >> 1, C.cpitch_up, X0 >> 1,
                                  Y0 >> 1, cp[pl]);
     }
     // (short)(n / (1.0f + 1e-5f)) == n - sign(n) for every int16 n: the quotient lies strictly between
@@ -473,7 +473,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) {
         int up[2][4];
-        if (l < C.bands) {
+        if (C.up) {
             up_block<int16_t>(cp[pl], up);
         } else {
 #pragma unroll
@@ -487,7 +487,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
                 int nrm;
                 if (unitW) nrm = toward_zero_by_one(a);
                 else nrm = (int16_t)(int)((float)a / (W[r][k] + 1e-5f));
-                v[pl][r][k] = l < C.bands ? sat16i(nrm + up[r][k]) : nrm;
+                v[pl][r][k] = C.up ? sat16i(nrm + up[r][k]) : nrm;
             }
     }
     bool on[2][4];
@@ -501,24 +501,45 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const CanvasPara
 // NPL = 3: a lane does the three colour planes of its block.  NPL = 1 (canvas levels >= 1 only, where planes are stored
 // apart): grid.z = canvas * 3 + plane and a lane does one plane - a third of the serial work per wave, three times the
 // waves: these levels are one round of waves whose seam waves set the kernel's duration.
-// The scalars IN FRONT of the parameter blocks arrive in SGPRs at wave launch (kernarg preload, see the Makefile): what a wave needs
-// to find its tile costs ONE memory round trip (the order-table entry) - read field by field out of the by-value blocks, behind the
-// early exits, it was a chain of six (1.4 of a wave's 6.2 us, tools/wave_timeline_l0.py).
-//   shape 3 (XCD bands): a 1-D grid; a0 / a1 = the multipliers that divide by gx and gy (2^32 / d + 1; 0: d == 1)
+// The scalars IN FRONT of the parameter blocks arrive in SGPRs at wave launch (kernarg preload, see the Makefile), and the
+// canvas' fields of this level (BlendLevel = CanvasParams::hot, packed by the launcher) come with two scalar loads: one round
+// trip where reading them field by field behind the early exits took five or six (tools/wave_timeline_l0.py).
+//   shape 3 (XCD bands): a 1-D grid; a0 / a1 = the multipliers that divide by gx and gy (2^32 / d + 1; 0: d == 1), total = workgroups
+//   shape 2: a plain 3-D grid
 //   (level 0 in seam-first order is a kernel of its own: blend_level0_ordered_kernel)
+struct BlendVecArgs {  // the kernel's argument list as the kernarg segment lays it out
+    int lvl;
+    unsigned a0, a1, total;
+    PyrParams P;
+    CanvasSet CS;
+};
+typedef int blend_i32x8 __attribute__((ext_vector_type(8)));
+typedef int blend_i32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void blend_level_from(const blend_i32x16& a, const blend_i32x8& b, BlendLevel& V) {
+    int w[24];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = a[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[16 + i] = b[i];
+    __builtin_memcpy(&V, w, sizeof(V));
+}
+__device__ __forceinline__ void load_blend_level(unsigned cs_at, unsigned canvas, BlendLevel& V) {
+    blend_i32x16 a;
+    blend_i32x8 b;
+    const char __attribute__((address_space(4)))* hb = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
+        (cs_at + (unsigned)offsetof(CanvasSet, c) + canvas * (unsigned)sizeof(CanvasParams) + (unsigned)offsetof(CanvasParams, hot));
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(hb) : "memory");
+    blend_level_from(a, b, V);
+}
 template <bool L0, int NPL = 3>
-__global__ __launch_bounds__(256) void blend_level_vec_kernel(int lvl, const uint32_t* ord0, const uint32_t* ord1, unsigned a0, unsigned a1,
-                                                              PyrParams P, CanvasSet CS) {
+__global__ __launch_bounds__(256) void blend_level_vec_kernel(int lvl, unsigned a0, unsigned a1, unsigned total, PyrParams P, CanvasSet CS) {
     static_assert(NPL == 3 || !L0, "level 0 writes interleaved BGR");
     unsigned bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
-    unsigned hint = 0xfu;  // what the wave will find in the owner map, when a static table has said so (else 0xF: look)
-    if (false) {
-    } else if (((lvl >> 8) & 15) == 3) {
+    if (((lvl >> 8) & 15) == 3) {
         // XCD bands (shape 3): a 1-D grid of 8 * per workgroups; the hardware deals consecutive ids round-robin
         // over the 8 XCDs, so XCD k is given the logical workgroups [k * per, (k + 1) * per) - a contiguous band of canvas
         // rows, whose neighbouring workgroups share their cache lines and pyrUp halos in ONE L2
         const unsigned gx = ((unsigned)lvl >> 12) & 0x3ffu, gy = ((unsigned)lvl >> 22) & 0x3ffu;
-        const unsigned total = gx * gy * (unsigned)(NPL == 3 ? CS.n : CS.n * 3);
         const unsigned per = (total + 7u) / 8u;
         const unsigned logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
         if ((blockIdx.x >> 3) >= per || logical >= total) return;
@@ -528,9 +549,10 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(int lvl, const uin
         byi = row - bzi * gy;
     }
     const int pb = NPL == 3 ? 0 : (int)(bzi % 3);  // first plane of this lane
-    const CanvasParams& C = CS.c[NPL == 3 ? bzi : bzi / 3];
+    BlendLevel C;
+    load_blend_level((unsigned)offsetof(BlendVecArgs, CS), NPL == 3 ? bzi : bzi / 3, C);
     const int l = L0 ? 0 : (lvl & 0xff);
-    const int cw = C.w0 >> l, ch = C.h0 >> l;
+    const int cw = C.cw, ch = C.ch;
     // level 0 covers only the block-aligned hull of the cut rectangle
     const int bx0 = L0 ? (C.cut_x & ~3) : 0, by0 = L0 ? (C.cut_y & ~1) : 0;
     // a wave is 16 x 4 blocks = 64 x 8 pixels (not a 256-pixel strip): four times fewer waves straddle a seam,
@@ -546,15 +568,15 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(int lvl, const uin
     } else if (X0 >= cw || Y0 >= ch) {
         return;
     }
-    blend_block<L0, NPL>(P, C, l, X0, Y0, pb, hint);
+    blend_block<L0, NPL>(P, C, l, X0, Y0, pb, 0xfu);
 }
 
 // Level 0 in seam-first order: XCD bands, the band of XCD k walked in the order of the static table CanvasParams::order0 - tiles
 // that hold a wave without a single owner (the general path: four times the instructions, two dependent rounds of loads) come
 // first, so their long chains run under the bulk instead of behind it.  grid (8 * max entries per XCD, canvases).
 // entry: bx | by << 8 | the four waves' owner nibbles << 16 (0xffff in the low half: no tile).
-// A wave's scalar prologue is ONE round trip: the tables and their lengths are preloaded arguments, and the canvas fields the
-// level-0 path reads (CanvasParams::hot0) are requested by the wave's first instructions, in flight with the table entry.
+// A wave's scalar prologue is ONE round trip: the tables and their lengths are preloaded arguments, and the canvas' fields
+// (BlendLevel = CanvasParams::hot) are requested by the wave's first instructions, in flight with the table entry.
 struct BlendOrderedArgs {  // the kernel's argument list as the kernarg segment lays it out
     const uint32_t *ord0, *ord1;
     unsigned per0, per1;
@@ -563,14 +585,12 @@ struct BlendOrderedArgs {  // the kernel's argument list as the kernarg segment 
 };
 __global__ __launch_bounds__(256) void blend_level0_ordered_kernel(const uint32_t* ord0, const uint32_t* ord1, unsigned per0, unsigned per1,
                                                                    PyrParams P, CanvasSet CS) {
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    typedef int i32x16 __attribute__((ext_vector_type(16)));
-    i32x16 h;
-    i32x4 h2;
+    blend_i32x16 ha;
+    blend_i32x8 hb8;
     {
         const char __attribute__((address_space(4)))* hb = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
-            (offsetof(BlendOrderedArgs, CS) + offsetof(CanvasSet, c) + blockIdx.y * sizeof(CanvasParams) + offsetof(CanvasParams, hot0));
-        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40" : "=&s"(h), "=&s"(h2) : "s"(hb) : "memory");
+            (offsetof(BlendOrderedArgs, CS) + offsetof(CanvasSet, c) + blockIdx.y * sizeof(CanvasParams) + offsetof(CanvasParams, hot));
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40" : "=&s"(ha), "=&s"(hb8) : "s"(hb) : "memory");
     }
     const unsigned k = blockIdx.x & 7u, jj = blockIdx.x >> 3;
     const unsigned per = blockIdx.y ? per1 : per0;
@@ -579,20 +599,13 @@ __global__ __launch_bounds__(256) void blend_level0_ordered_kernel(const uint32_
     unsigned ent;  // the table entry: a scalar load spelled out (behind the asm above the compiler would fetch it with a vector load)
     {
         const char __attribute__((address_space(4)))* ep = (const char __attribute__((address_space(4)))*)ord + (size_t)(k * per + jj) * 4u;
-        asm volatile("s_load_dword %0, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ent), "+s"(h), "+s"(h2) : "s"(ep) : "memory");
+        asm volatile("s_load_dword %0, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ent), "+s"(ha), "+s"(hb8) : "s"(ep) : "memory");
     }
     if ((ent & 0xffffu) == 0xffffu) return;
     const unsigned bxi = ent & 0xffu, byi = (ent >> 8) & 0xffu;
     const unsigned hint = (ent >> (16 + 4 * __builtin_amdgcn_readfirstlane(threadIdx.y))) & 0xfu;
-    CanvasParams C;  // only what the level-0 path reads (the rest is never touched: everything below is inlined with l == 0)
-    C.cut_x = h[0]; C.cut_y = h[1]; C.cut_w = h[2]; C.cut_h = h[3];
-    C.w0 = h[4]; C.h0 = h[5]; C.bands = h[6]; C.cam_lo = h[7];
-    C.out = (uint8_t*)(((unsigned long long)(unsigned)h[9] << 32) | (unsigned)h[8]);
-    C.out_stride = h[10];
-    C.opitch[0] = h[11];
-    C.img[1] = (int16_t*)(((unsigned long long)(unsigned)h[13] << 32) | (unsigned)h[12]);
-    C.owner[0] = (const uint16_t*)(((unsigned long long)(unsigned)h[15] << 32) | (unsigned)h[14]);
-    C.cpitch[1] = h2[0]; C.cplane[1] = h2[1];
+    BlendLevel C;
+    blend_level_from(ha, hb8, C);
     // level 0 covers only the block-aligned hull of the cut rectangle; a wave is 16 x 4 blocks of 4 x 2 pixels, a workgroup 2 x 2 waves
     const int bx0 = C.cut_x & ~3, by0 = C.cut_y & ~1;
     const int X0 = bx0 + ((bxi * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
@@ -670,12 +683,14 @@ void launch_tile_mixed(const CanvasParams& c, int gx, int gy, uint16_t* flags, h
 void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
 #define PANO_LAUNCH_L0(K, G)                                                                         \
     do {                                                                                             \
-        if (ev_start && ev_stop) hipExtLaunchKernelGGL(K, G, block, 0, s, ev_start, ev_stop, 0, karg, ko0, ko1, ka0, ka1, p, cs); \
-        else hipLaunchKernelGGL(K, G, block, 0, s, karg, ko0, ko1, ka0, ka1, p, cs);                \
+        if (ev_start && ev_stop) hipExtLaunchKernelGGL(K, G, block, 0, s, ev_start, ev_stop, 0, karg, ka0, ka1, ktotal, p, q); \
+        else hipLaunchKernelGGL(K, G, block, 0, s, karg, ka0, ka1, ktotal, p, q);                   \
     } while (0)
     auto magic = [](unsigned d) { return d > 1 ? (unsigned)((1ull << 32) / d + 1ull) : 0u; };
     const CanvasParams& c = cs.c[0];
     if (c.fast[l]) {
+        CanvasSet q = cs;  // with each canvas' fields of this level packed for the kernels (BlendLevel)
+        for (int g = 0; g < q.n; g++) pack_blend_level(q.c[g], l);
         int w = 0, h = 0;
         for (int g = 0; g < cs.n; g++) {
             const CanvasParams& cg = cs.c[g];
@@ -710,28 +725,17 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
             if (ordered && maxper > 0 && maxper < (1u << 20)) {  // XCD bands, seam tiles first
                 const uint32_t *ko0 = cs.c[0].order0, *ko1 = cs.n > 1 ? cs.c[1].order0 : nullptr;
                 const unsigned ka0 = (unsigned)cs.c[0].order_per, ka1 = cs.n > 1 ? (unsigned)cs.c[1].order_per : 0u;
-                CanvasSet q = cs;
-                for (int g = 0; g < q.n; g++) {
-                    CanvasParams& C = q.c[g];
-                    const unsigned long long po = (unsigned long long)(size_t)C.out, pi = (unsigned long long)(size_t)C.img[1],
-                                             pw = (unsigned long long)(size_t)C.owner[0];
-                    const int hot[20] = {C.cut_x, C.cut_y, C.cut_w, C.cut_h, C.w0, C.h0, C.bands, C.cam_lo, (int)(unsigned)po, (int)(unsigned)(po >> 32),
-                                         C.out_stride, C.opitch[0], (int)(unsigned)pi, (int)(unsigned)(pi >> 32), (int)(unsigned)pw,
-                                         (int)(unsigned)(pw >> 32), C.cpitch[1], C.cplane[1], 0, 0};
-                    for (int i = 0; i < 20; i++) C.hot0[i] = hot[i];
-                }
                 const dim3 go(8u * maxper, cs.n, 1);
                 if (ev_start && ev_stop) hipExtLaunchKernelGGL(blend_level0_ordered_kernel, go, block, 0, s, ev_start, ev_stop, 0, ko0, ko1, ka0, ka1, p, q);
                 else hipLaunchKernelGGL(blend_level0_ordered_kernel, go, block, 0, s, ko0, ko1, ka0, ka1, p, q);
             } else {
                 const int karg = larg;
-                const uint32_t *ko0 = nullptr, *ko1 = nullptr;
-                const unsigned ka0 = magic(grid3.x), ka1 = magic(grid3.y);
+                const unsigned ka0 = magic(grid3.x), ka1 = magic(grid3.y), ktotal = grid3.x * grid3.y * (unsigned)cs.n;
                 PANO_LAUNCH_L0((blend_level_vec_kernel<true, 3>), grid);
             }
         } else {
             hipLaunchKernelGGL((blend_level_vec_kernel<false, 1>), shape == 3 ? grid : dim3(grid.x, grid.y, cs.n * 3), block, 0, s, larg,
-                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, magic(grid3.x), magic(grid3.y), p, cs);
+                               magic(grid3.x), magic(grid3.y), grid3.x * grid3.y * (unsigned)(cs.n * 3), p, q);
         }
         return;
     }

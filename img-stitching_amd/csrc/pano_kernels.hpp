@@ -124,11 +124,42 @@ struct CanvasParams {
     int out_stride;            // bytes
     int cut_x, cut_y, cut_w, cut_h;  // in padded-canvas coordinates (pano rect origin == canvas origin)
     int final_w, final_h;      // dst_roi_final size (unpadded)
-    // what the ordered level-0 kernel reads of this block, packed by launch_blend_level so that a wave fetches it with two scalar
-    // loads at its first instruction: {cut_x, cut_y, cut_w, cut_h, w0, h0, bands, cam_lo, out (2), out_stride, opitch[0],
-    // img[1] (2), owner[0] (2), cpitch[1], cplane[1], -, -}
-    alignas(16) int hot0[20];
+    // what the vector blend kernels read of this block for the level they are launched on (BlendLevel), packed by
+    // launch_blend_level so that a wave fetches it with two scalar loads at its first instructions
+    alignas(16) int hot[24];
 };
+// A canvas at one level, as the vector blend kernels see it (CanvasParams::hot holds exactly this)
+struct BlendLevel {
+    int cut_x, cut_y, cut_w, cut_h;  // level 0: the cut rectangle
+    int cw, ch;                      // size of the level (w0 >> l, h0 >> l)
+    int up;                          // != 0: there is a coarser level (l < bands)
+    int cam_lo;
+    uint8_t* out;                    // level 0: the panorama
+    int out_stride;
+    int opitch;                      // owner entries per block row of this level
+    int16_t* img;                    // this level's collapsed canvas (levels >= 1: written here)
+    const int16_t* img_up;           // level l + 1
+    const uint16_t* owner;
+    int cpitch, cplane, cpitch_up, cplane_up;
+    int pad_[2];
+};
+static_assert(sizeof(BlendLevel) == 24 * sizeof(int), "BlendLevel is CanvasParams::hot");
+inline void pack_blend_level(CanvasParams& C, int l) {
+    BlendLevel v{};
+    v.cut_x = C.cut_x; v.cut_y = C.cut_y; v.cut_w = C.cut_w; v.cut_h = C.cut_h;
+    v.cw = C.w0 >> l; v.ch = C.h0 >> l;
+    v.up = l < C.bands ? 1 : 0;
+    v.cam_lo = C.cam_lo;
+    v.out = C.out; v.out_stride = C.out_stride;
+    v.opitch = C.opitch[l];
+    v.img = C.img[l];
+    v.img_up = l + 1 < kLevels ? C.img[l + 1] : nullptr;
+    v.owner = C.owner[l];
+    v.cpitch = C.cpitch[l]; v.cplane = C.cplane[l];
+    v.cpitch_up = l + 1 < kLevels ? C.cpitch[l + 1] : 0; v.cplane_up = l + 1 < kLevels ? C.cplane[l + 1] : 0;
+    static_assert(sizeof(v) == sizeof(C.hot), "hot block");
+    __builtin_memcpy(C.hot, &v, sizeof(v));
+}
 
 // Up to two canvases (the reference's upper and lower stitcher) share every blend launch: grid.z picks the canvas.
 // Their level structure (bands, vector levels, small_base) must be identical; their geometry need not be.
