@@ -5,6 +5,13 @@
 
 namespace pano {
 
+// BlendLevel's pointers come out of scalar registers (asm loads) without an address space: every dereference says "global",
+// or it is a flat_load / flat_store
+#define PANO_G __attribute__((address_space(1)))
+typedef unsigned blend_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned blend_u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned blend_u32x3u __attribute__((ext_vector_type(3), aligned(1)));  // at any byte alignment
+
 // ------------------------------------------------------------------------------------------------
 // K3 (generic form, any alignment): one level of the blend, one thread per canvas pixel.
 //   acc  = sum over cameras in feed order of (short)(lap * w)          (wrapping short add)
@@ -119,7 +126,10 @@ __device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int 
         const unsigned sel = sh0 | (sh1 << 8) | (sh2 << 16) | (sh3 << 24);
         uint2 d[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint2*>(S + (unsigned)(__mul24(yi[r], pitch) + ab));  // v_mul_lo_u32 is quarter rate
+        for (int r = 0; r < 3; r++) {  // v_mul_lo_u32 is quarter rate
+            const blend_u32x2 t = *(const blend_u32x2 PANO_G*)(S + (unsigned)(__mul24(yi[r], pitch) + ab));
+            d[r] = make_uint2(t.x, t.y);
+        }
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const unsigned win = __builtin_amdgcn_alignbyte(d[r].y, d[r].x, (unsigned)(base - ab));
@@ -134,7 +144,10 @@ __device__ __forceinline__ void load_coarse(const T* __restrict__ S, int n, int 
         const unsigned selB = (2 * sh2) | ((2 * sh2 + 1) << 8) | ((2 * sh3) << 16) | ((2 * sh3 + 1) << 24);
         uint3 d[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) d[r] = *reinterpret_cast<const uint3*>(S + (unsigned)(__mul24(yi[r], pitch) + ab));
+        for (int r = 0; r < 3; r++) {
+            const blend_u32x3 t = *(const blend_u32x3 PANO_G*)(S + (unsigned)(__mul24(yi[r], pitch) + ab));
+            d[r] = make_uint3(t.x, t.y, t.z);
+        }
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const unsigned w0 = __builtin_amdgcn_alignbyte(d[r].y, d[r].x, bs);
@@ -226,7 +239,7 @@ __device__ __forceinline__ void store_block(const BlendLevel& C, int l, int X0, 
                 uint2 pk;
                 pk.x = ((unsigned)v[pl][r][0] & 0xffffu) | ((unsigned)v[pl][r][1] << 16);
                 pk.y = ((unsigned)v[pl][r][2] & 0xffffu) | ((unsigned)v[pl][r][3] << 16);
-                *reinterpret_cast<uint2*>(C.img + (size_t)(pb + pl) * C.cplane + (unsigned)(__mul24(Y0 + r, C.cpitch) + X0)) = pk;
+                *(blend_u32x2 PANO_G*)(C.img + (size_t)(pb + pl) * C.cplane + (unsigned)(__mul24(Y0 + r, C.cpitch) + X0)) = blend_u32x2{pk.x, pk.y};
             }
     } else {
         const bool on[2][4] = {{o00, o01, o02, o03}, {o10, o11, o12, o13}};
@@ -240,7 +253,7 @@ __device__ __forceinline__ void store_block(const BlendLevel& C, int l, int X0, 
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++) b[3 * k + pl] = (ALLON || on[r][k]) ? (unsigned)sat8i(v[pl][r][k]) : 0u;
             // signed: a block that starts left of the cut has a negative column offset (its bytes are masked below)
-            uint8_t* d = C.out + (int)(__mul24(Y - C.cut_y, C.out_stride) + 3 * (X0 - C.cut_x));
+            uint8_t PANO_G* d = (uint8_t PANO_G*)C.out + (int)(__mul24(Y - C.cut_y, C.out_stride) + 3 * (X0 - C.cut_x));
             const bool whole = X0 >= C.cut_x && X0 + 4 <= C.cut_x + C.cut_w;
             if (whole) {
                 // one 12-byte store at whatever alignment the row has: a cv::Mat panorama has rows of 3 * width bytes, so three
@@ -250,7 +263,7 @@ __device__ __forceinline__ void store_block(const BlendLevel& C, int l, int X0, 
                 pk.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
                 pk.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
                 pk.z = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
-                *reinterpret_cast<Bgr4*>(d) = pk;
+                *(blend_u32x3u PANO_G*)d = blend_u32x3u{pk.x, pk.y, pk.z};
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++)
@@ -267,7 +280,10 @@ __device__ __forceinline__ void store_block(const BlendLevel& C, int l, int X0, 
 // One 4 x 2 block of a vector level (X0 multiple of 4, Y0 even; the caller has checked that it lies inside the level /
 // the cut hull): the wave-uniform single-owner path when every lane of the wave sits on the same owner, else the general
 // path.  pb: first plane of this lane (NPL == 1: one plane per lane)
-template <bool L0, int NPL>
+// UP: there is a coarser level (launch-uniform: UP).  A template parameter and not a test of UP, because behind a run-time
+// test every load_coarse - loads AND the permutes that consume them - sat in a conditional block of its own, and the wave waited for
+// each plane's windows before it requested the next plane's: six dependent vector round trips where the code meant one.
+template <bool L0, int NPL, bool UP>
 __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel& C, const int l, const int X0, const int Y0,
                                             const int pb, const unsigned hint = 0xfu) {
     const int cam_lo = C.cam_lo;
@@ -284,7 +300,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
         ucode = hint < 8u ? hint : 0xfeu;
         single = true;
     } else {
-        entry = C.owner[(unsigned)(__mul24(Y0 >> 1, C.opitch) + (X0 >> 2))];
+        entry = ((const uint16_t PANO_G*)C.owner)[(unsigned)(__mul24(Y0 >> 1, C.opitch) + (X0 >> 2))];
         const unsigned code = entry & 0xffu;
         ucode = __builtin_amdgcn_readfirstlane(code);
         single = ucode != 0xffu && __builtin_amdgcn_ballot_w64(code != ucode) == 0;
@@ -294,7 +310,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
         // and every load is in flight before the first use
         int v[3][2][4];
         unsigned cp[3][3][2];
-        if (C.up) {
+        if (UP) {
 #pragma unroll
             for (int pl = 0; pl < NPL; pl++) {
                 load_coarse<int16_t>(C.img_up + (size_t)(pb + pl) * C.cplane_up, cw >> 1, ch >> 1, C.cpitch_up,
@@ -312,14 +328,14 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
                 const uint8_t* g = c.lvl[l] + (size_t)(pb + pl) * c.plane[l] + (unsigned)(__mul24(y, c.pitch[l]) + x);
                 g0[pl] = *reinterpret_cast<const unsigned*>(g);
                 g1[pl] = *reinterpret_cast<const unsigned*>(g + c.pitch[l]);
-                if (C.up)
+                if (UP)
                     load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)(pb + pl) * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1],
                                          x >> 1, y >> 1, p[pl]);
             }
 #pragma unroll
             for (int pl = 0; pl < NPL; pl++) {
                 int up[2][4];
-                if (C.up) {
+                if (UP) {
                     up_block<uint8_t>(p[pl], up);
                 } else {
 #pragma unroll
@@ -341,7 +357,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
 #pragma unroll
                     for (int k = 0; k < 4; k++) v[pl][r][k] = 0;
         }
-        if (C.up) {
+        if (UP) {
 #pragma unroll
             for (int pl = 0; pl < NPL; pl++) {
                 int up[2][4];
@@ -369,7 +385,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
     const unsigned live = entry >> 8;
     // the coarser canvas level: early on the latency-bound small levels, late (fewer live registers) on level 0
     unsigned cp[3][3][2];
-    if (!L0 && C.up) {
+    if (!L0 && UP) {
 #pragma unroll
         for (int pl = 0; pl < NPL; pl++)
             load_coarse<int16_t>(C.img_up + (size_t)(pb + pl) * C.cplane_up, cw >> 1, ch >> 1, C.cpitch_up, X0 >> 1,
@@ -422,7 +438,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
             const uint8_t* g = c.lvl[l] + (size_t)(pb + pl) * c.plane[l] + (size_t)y * c.pitch[l] + x;
             g0[pl] = *reinterpret_cast<const unsigned*>(g);
             g1[pl] = *reinterpret_cast<const unsigned*>(g + c.pitch[l]);
-            if (C.up)
+            if (UP)
                 load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)(pb + pl) * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1], x >> 1,
                                      y >> 1, p[pl]);
         }
@@ -433,7 +449,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
 #pragma unroll
         for (int pl = 0; pl < NPL; pl++) {
             int up[2][4];
-            if (C.up) {
+            if (UP) {
                 up_block<uint8_t>(p[pl], up);
             } else {
 #pragma unroll
@@ -455,7 +471,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
             }
         }
     }
-    if (L0 && C.up) {
+    if (L0 && UP) {
 #pragma unroll
         for (int pl = 0; pl < NPL; pl++)
             load_coarse<int16_t>(C.img_up + (size_t)(pb + pl) * C.cplane_up, cw >> 1, ch >> 1, C.cpitch_up, X0 >> 1,
@@ -473,7 +489,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) {
         int up[2][4];
-        if (C.up) {
+        if (UP) {
             up_block<int16_t>(cp[pl], up);
         } else {
 #pragma unroll
@@ -487,7 +503,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
                 int nrm;
                 if (unitW) nrm = toward_zero_by_one(a);
                 else nrm = (int16_t)(int)((float)a / (W[r][k] + 1e-5f));
-                v[pl][r][k] = C.up ? sat16i(nrm + up[r][k]) : nrm;
+                v[pl][r][k] = UP ? sat16i(nrm + up[r][k]) : nrm;
             }
     }
     bool on[2][4];
@@ -568,7 +584,8 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(int lvl, unsigned 
     } else if (X0 >= cw || Y0 >= ch) {
         return;
     }
-    blend_block<L0, NPL>(P, C, l, X0, Y0, pb, 0xfu);
+    if (C.up) blend_block<L0, NPL, true>(P, C, l, X0, Y0, pb, 0xfu);
+    else blend_block<L0, NPL, false>(P, C, l, X0, Y0, pb, 0xfu);
 }
 
 // Level 0 in seam-first order: XCD bands, the band of XCD k walked in the order of the static table CanvasParams::order0 - tiles
@@ -611,7 +628,8 @@ __global__ __launch_bounds__(256) void blend_level0_ordered_kernel(const uint32_
     const int X0 = bx0 + ((bxi * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
     const int Y0 = by0 + ((byi * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * 2;
     if (X0 >= C.cut_x + C.cut_w || Y0 >= C.cut_y + C.cut_h) return;
-    blend_block<true, 3>(P, C, 0, X0, Y0, 0, hint);
+    if (C.up) blend_block<true, 3, true>(P, C, 0, X0, Y0, 0, hint);
+    else blend_block<true, 3, false>(P, C, 0, X0, Y0, 0, hint);
 }
 
 // owner map of a vector level: one byte per 4 x 2 block (see CanvasParams::owner)
