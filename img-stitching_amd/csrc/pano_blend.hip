@@ -280,7 +280,7 @@ __device__ __forceinline__ void store_block(const BlendLevel& C, int l, int X0, 
 // One 4 x 2 block of a vector level (X0 multiple of 4, Y0 even; the caller has checked that it lies inside the level /
 // the cut hull): the wave-uniform single-owner path when every lane of the wave sits on the same owner, else the general
 // path.  pb: first plane of this lane (NPL == 1: one plane per lane)
-// UP: there is a coarser level (launch-uniform: UP).  A template parameter and not a test of UP, because behind a run-time
+// UP: there is a coarser level (launch-uniform: BlendLevel::up).  A template parameter and not a test of it, because behind a run-time
 // test every load_coarse - loads AND the permutes that consume them - sat in a conditional block of its own, and the wave waited for
 // each plane's windows before it requested the next plane's: six dependent vector round trips where the code meant one.
 template <bool L0, int NPL, bool UP>
