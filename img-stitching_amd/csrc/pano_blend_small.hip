@@ -25,18 +25,26 @@ __global__ __launch_bounds__(256) void norm_small_kernel(PyrParams P, CanvasSet 
     const int cw = C.w0 >> l, ch = C.h0 >> l;
     const int X = blockIdx.x * 64 + threadIdx.x, Y = blockIdx.y * 4 + threadIdx.y;
     if (X >= cw || Y >= ch) return;
+    // Weights: ONE unconditional load per camera slot (a pixel outside the camera's tile, or a slot past cam_n, reads the tile's
+    // first weight and drops it) - as conditional loads each sat in a block of its own with its wait: eight round trips in a row
     float wv[kCams];
+    {
+        float wl[kCams];
+        bool in[kCams];
 #pragma unroll
-    for (int i = 0; i < kCams; i++) {
-        wv[i] = 0.f;
-        if (i < cam_n) {
-            const PyrCam& c = P.cam[cam_lo + i];
+        for (int i = 0; i < kCams; i++) {
+            const PyrCam& c = P.cam[cam_lo + min(i, cam_n - 1)];  // a slot past cam_n re-reads the last camera's (cam_n >= 1)
             const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
-            if ((unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l)) wv[i] = cam_weight(c, l, x, y);
+            in[i] = i < cam_n && (unsigned)x < (unsigned)(c.w0 >> l) && (unsigned)y < (unsigned)(c.h0 >> l);
+            wl[i] = c.wgt[l][in[i] ? (size_t)y * c.wpitch[l] + x : 0];  // small levels are never level 0
         }
+#pragma unroll
+        for (int i = 0; i < kCams; i++) wv[i] = in[i] ? wl[i] : 0.f;
     }
     int acc[3] = {0, 0, 0};
     float W = 0.f;
+    const bool up = l < C.bands;  // block-uniform, tested OUTSIDE the plane loops: inside them every plane's ten loads were a
+                                  // conditional block of their own with its wait
 #pragma unroll
     for (int i = 0; i < kCams; i++) {
         const float w = wv[i];
@@ -45,14 +53,46 @@ __global__ __launch_bounds__(256) void norm_small_kernel(PyrParams P, CanvasSet 
         const int x = X - (c.tx >> l), y = Y - (c.ty >> l);
         const int tw = c.w0 >> l, th = c.h0 >> l;
         W += w;
+        int lap[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            int lap = c.lvl[l][(size_t)k * c.plane[l] + (size_t)y * c.pitch[l] + x];
-            if (l < C.bands)
-                lap = sat16i(lap - pyr_up_px<uint8_t>(c.lvl[l + 1] + (size_t)k * c.plane[l + 1], tw >> 1, th >> 1,
-                                                      c.pitch[l + 1], x, y));
-            acc[k] = (int16_t)(acc[k] + (int16_t)(int)((float)lap * w));
+        for (int k = 0; k < 3; k++) lap[k] = c.lvl[l][(size_t)k * c.plane[l] + (size_t)y * c.pitch[l] + x];
+        if (up) {
+            // the 3 x 3 taps of pyr_up_px for the three planes: all loads, then the arithmetic
+            const int n = tw >> 1, m = th >> 1, cx = x >> 1, cy = y >> 1;
+            int xi[3], wx[3], yi[3], wy[3];
+            if (!(x & 1)) {
+                xi[0] = cx > 0 ? cx - 1 : (n > 1 ? 1 : 0); xi[1] = cx; xi[2] = min(cx + 1, n - 1);
+                wx[0] = 1; wx[1] = 6; wx[2] = 1;
+            } else {
+                xi[0] = cx; xi[1] = min(cx + 1, n - 1); xi[2] = cx;
+                wx[0] = 4; wx[1] = 4; wx[2] = 0;
+            }
+            if (!(y & 1)) {
+                yi[0] = cy > 0 ? cy - 1 : (m > 1 ? 1 : 0); yi[1] = cy; yi[2] = min(cy + 1, m - 1);
+                wy[0] = 1; wy[1] = 6; wy[2] = 1;
+            } else {
+                yi[0] = cy; yi[1] = min(cy + 1, m - 1); yi[2] = cy;
+                wy[0] = 4; wy[1] = 4; wy[2] = 0;
+            }
+            int tap[3][3][3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint8_t* S = c.lvl[l + 1] + (size_t)k * c.plane[l + 1];
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+#pragma unroll
+                    for (int t = 0; t < 3; t++) tap[k][j][t] = S[(size_t)yi[j] * c.pitch[l + 1] + xi[t]];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                int a = 0;
+#pragma unroll
+                for (int j = 0; j < 3; j++) a += (tap[k][j][0] * wx[0] + tap[k][j][1] * wx[1] + tap[k][j][2] * wx[2]) * wy[j];
+                lap[k] = sat16i(lap[k] - sat16i((a + 32) >> 6));
+            }
         }
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc[k] = (int16_t)(acc[k] + (int16_t)(int)((float)lap[k] * w));
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
