@@ -600,7 +600,8 @@ struct BlendOrderedArgs {  // the kernel's argument list as the kernarg segment 
     PyrParams P;
     CanvasSet CS;
 };
-__global__ __launch_bounds__(256) void blend_level0_ordered_kernel(const uint32_t* ord0, const uint32_t* ord1, unsigned per0, unsigned per1,
+// 5 waves / SIMD = at most 96 VGPRs (the allocator stopped at 97: a granule more, and a wave less)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void blend_level0_ordered_kernel(const uint32_t* ord0, const uint32_t* ord1, unsigned per0, unsigned per1,
                                                                    PyrParams P, CanvasSet CS) {
     blend_i32x16 ha;
     blend_i32x8 hb8;
