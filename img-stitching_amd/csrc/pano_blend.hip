@@ -409,28 +409,17 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
         const PyrCam& c = P.cam[cam_lo + i];
         const int x = X0 - (c.tx >> l), y = Y0 - (c.ty >> l);
         const int tw = c.w0 >> l, th = c.h0 >> l;
-        float w[2][4];
+        // every load of this camera - its weights AND its pixels - goes out before any is used (with the weights converted and tested
+        // in front of the pixel loads, as the source once read, the wave waited for the weights first: a round trip per camera)
+        unsigned mk[2] = {0u, 0u};
+        float4 wf[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
         if (L0) {
-            const unsigned mk[2] = {*reinterpret_cast<const unsigned*>(c.mask0 + (unsigned)(__mul24(y, c.pitch[0]) + x)),
-                                    *reinterpret_cast<const unsigned*>(c.mask0 + (unsigned)(__mul24(y + 1, c.pitch[0]) + x))};
-#pragma unroll
-            for (int r = 0; r < 2; r++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) w[r][k] = (float)((mk[r] >> (8 * k)) & 0xffu) * (float)(1. / 255.);
+            mk[0] = *reinterpret_cast<const unsigned*>(c.mask0 + (unsigned)(__mul24(y, c.pitch[0]) + x));
+            mk[1] = *reinterpret_cast<const unsigned*>(c.mask0 + (unsigned)(__mul24(y + 1, c.pitch[0]) + x));
         } else {
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const float4 f = *reinterpret_cast<const float4*>(c.wgt[l] + (size_t)(y + r) * c.wpitch[l] + x);
-                w[r][0] = f.x; w[r][1] = f.y; w[r][2] = f.z; w[r][3] = f.w;
-            }
+            for (int r = 0; r < 2; r++) wf[r] = *reinterpret_cast<const float4*>(c.wgt[l] + (size_t)(y + r) * c.wpitch[l] + x);
         }
-        // away from the seams the weight is exactly 1.0f on the whole block: no float path
-        bool unit = true;
-#pragma unroll
-        for (int r = 0; r < 2; r++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) unit &= w[r][k] == 1.0f;
-        // issue every load of this camera before using any
         unsigned g0[3], g1[3];
         unsigned p[3][3][2];
 #pragma unroll
@@ -442,6 +431,24 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
                 load_coarse<uint8_t>(c.lvl[l + 1] + (size_t)(pb + pl) * c.plane[l + 1], tw >> 1, th >> 1, c.pitch[l + 1], x >> 1,
                                      y >> 1, p[pl]);
         }
+        float w[2][4];
+        if (L0) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) w[r][k] = (float)((mk[r] >> (8 * k)) & 0xffu) * (float)(1. / 255.);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                w[r][0] = wf[r].x; w[r][1] = wf[r].y; w[r][2] = wf[r].z; w[r][3] = wf[r].w;
+            }
+        }
+        // away from the seams the weight is exactly 1.0f on the whole block: no float path
+        bool unit = true;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) unit &= w[r][k] == 1.0f;
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
