@@ -100,8 +100,8 @@ struct pano_ctx {
     long long k1_blocks[kMaxCams] = {}, k1_flagged[kMaxCams] = {};
     bool use_lut = true;
     uint16_t* owner[kMaxLevels] = {};
-    uint32_t* order0 = nullptr;      // CanvasParams::order0
-    size_t order_cap = 0;
+    uint32_t* order[kOrderLevels] = {};   // CanvasParams::order
+    size_t order_cap[kOrderLevels] = {};
     bool order_dirty = false;
     bool l0_order = true;            // PANO_L0_ORDER=0: plain band order
     float* wsum[kMaxLevels] = {};
@@ -256,8 +256,10 @@ void free_device(pano_ctx* c) {
         dfree(c->stage_in[i]);
         for (int l = 0; l < kMaxLevels; l++) dfree(c->wgt[i][l]);
     }
-    dfree(c->order0);
-    c->order_cap = 0;
+    for (int l = 0; l < kOrderLevels; l++) {
+        dfree(c->order[l]);
+        c->order_cap[l] = 0;
+    }
     for (int l = 0; l < kMaxLevels; l++) {
         dfree(c->owner[l]);
         dfree(c->wsum[l]);
@@ -603,42 +605,47 @@ pano_status upload_gain_tables(pano_ctx* c, int i, const float* h_gain) {
 // the owner map and the cut).  PANO_L0_ORDER=0 keeps the plain band order
 pano_status build_tile_order(pano_ctx* c, hipStream_t s) {
     c->order_dirty = false;
-    c->cv.order0 = nullptr;
-    c->cv.order_per = c->cv.order_gx = 0;
-    if (!c->l0_order || c->plan.bands < 0 || !c->cv.fast[0]) return PANO_OK;
-    const CanvasParams& cv = c->cv;
-    const int w = cv.cut_x + cv.cut_w - (cv.cut_x & ~3), h = cv.cut_y + cv.cut_h - (cv.cut_y & ~1);
-    const int gx = (w + 127) / 128, gy = (h + 15) / 16;
-    const size_t T = (size_t)gx * gy;
-    if (T == 0 || gx >= 255 || gy >= 255) return PANO_OK;  // an entry holds bx and by in a byte each
-    const size_t per = (T + 7) / 8;
-    uint16_t* d_flags = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_flags, T * sizeof(uint16_t)));
-    launch_tile_mixed(cv, gx, gy, d_flags, s);
-    std::vector<uint16_t> flags(T);  // four owner nibbles per tile, one per wave (0xF: that wave takes the general path)
-    hipError_t fe = hipMemcpyAsync(flags.data(), d_flags, T * sizeof(uint16_t), hipMemcpyDeviceToHost, s);
-    if (fe == hipSuccess) fe = hipStreamSynchronize(s);
-    (void)hipFree(d_flags);
-    HIP_TRY(c, fe);
-    auto mixed = [](uint16_t f) { return (f & 0xf) == 0xf || ((f >> 4) & 0xf) == 0xf || ((f >> 8) & 0xf) == 0xf || (f >> 12) == 0xf; };
-    std::vector<uint32_t> order(8 * per, 0xffffu);
-    for (size_t k = 0; k < 8; k++) {
-        const size_t lo = k * per, hi = std::min(T, lo + per);
-        size_t o = lo;
-        for (int pass = 1; pass >= 0; pass--)
-            for (size_t t = lo; t < hi; t++)
-                if ((int)mixed(flags[t]) == pass) order[o++] = (uint32_t)(t % gx) | (uint32_t)(t / gx) << 8 | (uint32_t)flags[t] << 16;
+    for (int l = 0; l < kOrderLevels; l++) {
+        c->cv.order[l] = nullptr;
+        c->cv.order_per[l] = 0;
     }
-    if (c->order_cap < order.size()) {
-        dfree(c->order0);
-        c->order_cap = 0;
-        HIP_TRY(c, hipMalloc((void**)&c->order0, order.size() * sizeof(uint32_t)));
-        c->order_cap = order.size();
+    if (!c->l0_order || c->plan.bands < 0) return PANO_OK;
+    for (int l = 0; l < kOrderLevels && l <= c->plan.bands; l++) {
+        const CanvasParams& cv = c->cv;
+        if (!cv.fast[l] || (cv.small_base > 0 && l >= cv.small_base)) break;  // the vector kernel's levels
+        const int w = l == 0 ? cv.cut_x + cv.cut_w - (cv.cut_x & ~3) : (cv.w0 >> l);
+        const int h = l == 0 ? cv.cut_y + cv.cut_h - (cv.cut_y & ~1) : (cv.h0 >> l);
+        const int gx = (w + 127) / 128, gy = (h + 15) / 16;
+        const size_t T = (size_t)gx * gy;
+        if (T == 0 || gx >= 255 || gy >= 255) continue;  // an entry holds bx and by in a byte each
+        const size_t per = (T + 7) / 8;
+        uint16_t* d_flags = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&d_flags, T * sizeof(uint16_t)));
+        launch_tile_mixed(cv, l, gx, gy, d_flags, s);
+        std::vector<uint16_t> flags(T);  // four owner nibbles per tile, one per wave (0xF: that wave takes the general path)
+        hipError_t fe = hipMemcpyAsync(flags.data(), d_flags, T * sizeof(uint16_t), hipMemcpyDeviceToHost, s);
+        if (fe == hipSuccess) fe = hipStreamSynchronize(s);
+        (void)hipFree(d_flags);
+        HIP_TRY(c, fe);
+        auto mixed = [](uint16_t f) { return (f & 0xf) == 0xf || ((f >> 4) & 0xf) == 0xf || ((f >> 8) & 0xf) == 0xf || (f >> 12) == 0xf; };
+        std::vector<uint32_t> order(8 * per, 0xffffu);
+        for (size_t k = 0; k < 8; k++) {
+            const size_t lo = k * per, hi = std::min(T, lo + per);
+            size_t o = lo;
+            for (int pass = 1; pass >= 0; pass--)
+                for (size_t t = lo; t < hi; t++)
+                    if ((int)mixed(flags[t]) == pass) order[o++] = (uint32_t)(t % gx) | (uint32_t)(t / gx) << 8 | (uint32_t)flags[t] << 16;
+        }
+        if (c->order_cap[l] < order.size()) {
+            dfree(c->order[l]);
+            c->order_cap[l] = 0;
+            HIP_TRY(c, hipMalloc((void**)&c->order[l], order.size() * sizeof(uint32_t)));
+            c->order_cap[l] = order.size();
+        }
+        HIP_TRY(c, hipMemcpy(c->order[l], order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->cv.order[l] = c->order[l];
+        c->cv.order_per[l] = (int)per;
     }
-    HIP_TRY(c, hipMemcpy(c->order0, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    c->cv.order0 = c->order0;
-    c->cv.order_per = (int)per;
-    c->cv.order_gx = gx;
     return PANO_OK;
 }
 

@@ -529,7 +529,7 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
 // trip where reading them field by field behind the early exits took five or six (tools/wave_timeline_l0.py).
 //   shape 3 (XCD bands): a 1-D grid; a0 / a1 = the multipliers that divide by gx and gy (2^32 / d + 1; 0: d == 1), total = workgroups
 //   shape 2: a plain 3-D grid
-//   (level 0 in seam-first order is a kernel of its own: blend_level0_ordered_kernel)
+//   (the levels in seam-first order run a kernel of their own: blend_level_ordered_kernel)
 struct BlendVecArgs {  // the kernel's argument list as the kernarg segment lays it out
     int lvl;
     unsigned a0, a1, total;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(int lvl, unsigned 
     else blend_block<L0, NPL, false>(P, C, l, X0, Y0, pb, 0xfu);
 }
 
-// Level 0 in seam-first order: XCD bands, the band of XCD k walked in the order of the static table CanvasParams::order0 - tiles
+// A vector level in seam-first order: XCD bands, the band of XCD k walked in the order of the static table CanvasParams::order[l] - tiles
 // that hold a wave without a single owner (the general path: four times the instructions, two dependent rounds of loads) come
 // first, so their long chains run under the bulk instead of behind it.  grid (8 * max entries per XCD, canvases).
 // entry: bx | by << 8 | the four waves' owner nibbles << 16 (0xffff in the low half: no tile).
@@ -604,22 +604,28 @@ __global__ __launch_bounds__(256) void blend_level_vec_kernel(int lvl, unsigned 
 struct BlendOrderedArgs {  // the kernel's argument list as the kernarg segment lays it out
     const uint32_t *ord0, *ord1;
     unsigned per0, per1;
+    int l;
     PyrParams P;
     CanvasSet CS;
 };
-// 5 waves / SIMD = at most 96 VGPRs (the allocator stopped at 97: a granule more, and a wave less)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void blend_level0_ordered_kernel(const uint32_t* ord0, const uint32_t* ord1, unsigned per0, unsigned per1,
-                                                                   PyrParams P, CanvasSet CS) {
+// L0 (NPL 3): 5 waves / SIMD = at most 96 VGPRs (the allocator stopped at 97: a granule more, and a wave less).
+// Levels >= 1 (NPL 1): blockIdx.y = canvas * 3 + plane, l = the level.
+template <bool L0, int NPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(L0 ? 5 : 8, 8))) void blend_level_ordered_kernel(
+    const uint32_t* ord0, const uint32_t* ord1, unsigned per0, unsigned per1, int l, PyrParams P, CanvasSet CS) {
+    static_assert((L0 && NPL == 3) || (!L0 && NPL == 1), "level 0 does three planes per lane, the levels above one");
+    const unsigned cvi = NPL == 3 ? blockIdx.y : blockIdx.y / 3u;
+    const int pb = NPL == 3 ? 0 : (int)(blockIdx.y - cvi * 3u);
     blend_i32x16 ha;
     blend_i32x8 hb8;
     {
         const char __attribute__((address_space(4)))* hb = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
-            (offsetof(BlendOrderedArgs, CS) + offsetof(CanvasSet, c) + blockIdx.y * sizeof(CanvasParams) + offsetof(CanvasParams, hot));
+            (offsetof(BlendOrderedArgs, CS) + offsetof(CanvasSet, c) + cvi * sizeof(CanvasParams) + offsetof(CanvasParams, hot));
         asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40" : "=&s"(ha), "=&s"(hb8) : "s"(hb) : "memory");
     }
     const unsigned k = blockIdx.x & 7u, jj = blockIdx.x >> 3;
-    const unsigned per = blockIdx.y ? per1 : per0;
-    const uint32_t* ord = blockIdx.y ? ord1 : ord0;
+    const unsigned per = cvi ? per1 : per0;
+    const uint32_t* ord = cvi ? ord1 : ord0;
     if (jj >= per) return;
     unsigned ent;  // the table entry: a scalar load spelled out (behind the asm above the compiler would fetch it with a vector load)
     {
@@ -632,12 +638,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     BlendLevel C;
     blend_level_from(ha, hb8, C);
     // level 0 covers only the block-aligned hull of the cut rectangle; a wave is 16 x 4 blocks of 4 x 2 pixels, a workgroup 2 x 2 waves
-    const int bx0 = C.cut_x & ~3, by0 = C.cut_y & ~1;
+    const int bx0 = L0 ? (C.cut_x & ~3) : 0, by0 = L0 ? (C.cut_y & ~1) : 0;
     const int X0 = bx0 + ((bxi * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
     const int Y0 = by0 + ((byi * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * 2;
-    if (X0 >= C.cut_x + C.cut_w || Y0 >= C.cut_y + C.cut_h) return;
-    if (C.up) blend_block<true, 3, true>(P, C, 0, X0, Y0, 0, hint);
-    else blend_block<true, 3, false>(P, C, 0, X0, Y0, 0, hint);
+    if (L0) {
+        if (X0 >= C.cut_x + C.cut_w || Y0 >= C.cut_y + C.cut_h) return;
+    } else if (X0 >= C.cw || Y0 >= C.ch) {
+        return;
+    }
+    const int lv = L0 ? 0 : l;
+    if (C.up) blend_block<L0, NPL, true>(P, C, lv, X0, Y0, pb, hint);
+    else blend_block<L0, NPL, false>(P, C, lv, X0, Y0, pb, hint);
 }
 
 // owner map of a vector level: one byte per 4 x 2 block (see CanvasParams::owner)
@@ -677,17 +688,18 @@ void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint16
     hipLaunchKernelGGL(build_owner_kernel, grid, block, 0, s, p, c, l, owner);
 }
 
-// What will the four waves of every 128 x 16-pixel workgroup tile of level 0 find in the owner map?  One nibble per wave
-// (wave = threadIdx.y of blend_level_vec_kernel's 2 x 2 shape over the hull of the cut): 0..7 = every block of the wave inside
-// the cut has that single owner, 0xE = none of them has an owner, 0xF = anything else (the wave has to look).  Static: it
-// follows the owner map and the cut.
-__global__ __launch_bounds__(256) void tile_mixed_kernel(CanvasParams C, int gx, uint16_t* flags) {
-    const int bx0 = C.cut_x & ~3, by0 = C.cut_y & ~1;
+// What will the four waves of every 128 x 16-pixel workgroup tile of vector level l find in the owner map?  One nibble per wave
+// (wave = threadIdx.y of the blend kernels' 2 x 2 shape; level 0: over the hull of the cut): 0..7 = every block of the wave
+// inside the level / the cut has that single owner, 0xE = none of them has an owner, 0xF = anything else (the wave has to look).
+// Static: it follows the owner map and the cut.
+__global__ __launch_bounds__(256) void tile_mixed_kernel(CanvasParams C, int l, int gx, uint16_t* flags) {
+    const int bx0 = l == 0 ? (C.cut_x & ~3) : 0, by0 = l == 0 ? (C.cut_y & ~1) : 0;
+    const int xe = l == 0 ? C.cut_x + C.cut_w : (C.w0 >> l), ye = l == 0 ? C.cut_y + C.cut_h : (C.h0 >> l);
     const int X0 = bx0 + ((blockIdx.x * 2 + (threadIdx.y & 1)) * 16 + (threadIdx.x & 15)) * 4;
     const int Y0 = by0 + ((blockIdx.y * 2 + (threadIdx.y >> 1)) * 4 + (threadIdx.x >> 4)) * 2;
-    const bool valid = X0 < C.cut_x + C.cut_w && Y0 < C.cut_y + C.cut_h;
+    const bool valid = X0 < xe && Y0 < ye;
     unsigned code = 0;
-    if (valid) code = C.owner[0][(unsigned)(__mul24(Y0 >> 1, C.opitch[0]) + (X0 >> 2))] & 0xffu;
+    if (valid) code = C.owner[l][(unsigned)(__mul24(Y0 >> 1, C.opitch[l]) + (X0 >> 2))] & 0xffu;
     const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
     unsigned nib = 0xEu;  // a wave with no block inside the cut does nothing at all
     if (vm) {
@@ -702,8 +714,8 @@ __global__ __launch_bounds__(256) void tile_mixed_kernel(CanvasParams C, int gx,
     __syncthreads();
     if (threadIdx.x == 0 && threadIdx.y == 0) flags[blockIdx.y * gx + blockIdx.x] = (uint16_t)all;
 }
-void launch_tile_mixed(const CanvasParams& c, int gx, int gy, uint16_t* flags, hipStream_t s) {
-    hipLaunchKernelGGL(tile_mixed_kernel, dim3(gx, gy, 1), dim3(64, 4, 1), 0, s, c, gx, flags);
+void launch_tile_mixed(const CanvasParams& c, int l, int gx, int gy, uint16_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(tile_mixed_kernel, dim3(gx, gy, 1), dim3(64, 4, 1), 0, s, c, l, gx, flags);
 }
 
 void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -741,24 +753,28 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
             const unsigned zext = l == 0 ? cs.n : cs.n * 3;
             grid = dim3(8u * ((grid3.x * grid3.y * zext + 7u) / 8u), 1, 1);
         }
+        // XCD bands, seam tiles first, the waves told their owners (the ordered kernel), where every canvas of the set has the table
+        bool ordered = shape == 3 && l < kOrderLevels;
+        unsigned maxper = 0;
+        for (int g = 0; ordered && g < cs.n; g++) {
+            ordered = cs.c[g].order[l] != nullptr;
+            maxper = max(maxper, (unsigned)cs.c[g].order_per[l]);
+        }
+        ordered = ordered && maxper > 0 && maxper < (1u << 20);
+        const uint32_t *ko0 = ordered ? cs.c[0].order[l] : nullptr, *ko1 = ordered && cs.n > 1 ? cs.c[1].order[l] : nullptr;
+        const unsigned kp0 = ordered ? (unsigned)cs.c[0].order_per[l] : 0u, kp1 = ordered && cs.n > 1 ? (unsigned)cs.c[1].order_per[l] : 0u;
         if (l == 0) {
-            bool ordered = shape == 3;
-            unsigned maxper = 0;
-            for (int g = 0; g < cs.n; g++) {
-                ordered = ordered && cs.c[g].order0 != nullptr;
-                maxper = max(maxper, (unsigned)cs.c[g].order_per);
-            }
-            if (ordered && maxper > 0 && maxper < (1u << 20)) {  // XCD bands, seam tiles first
-                const uint32_t *ko0 = cs.c[0].order0, *ko1 = cs.n > 1 ? cs.c[1].order0 : nullptr;
-                const unsigned ka0 = (unsigned)cs.c[0].order_per, ka1 = cs.n > 1 ? (unsigned)cs.c[1].order_per : 0u;
+            if (ordered) {
                 const dim3 go(8u * maxper, cs.n, 1);
-                if (ev_start && ev_stop) hipExtLaunchKernelGGL(blend_level0_ordered_kernel, go, block, 0, s, ev_start, ev_stop, 0, ko0, ko1, ka0, ka1, p, q);
-                else hipLaunchKernelGGL(blend_level0_ordered_kernel, go, block, 0, s, ko0, ko1, ka0, ka1, p, q);
+                if (ev_start && ev_stop) hipExtLaunchKernelGGL((blend_level_ordered_kernel<true, 3>), go, block, 0, s, ev_start, ev_stop, 0, ko0, ko1, kp0, kp1, 0, p, q);
+                else hipLaunchKernelGGL((blend_level_ordered_kernel<true, 3>), go, block, 0, s, ko0, ko1, kp0, kp1, 0, p, q);
             } else {
                 const int karg = larg;
                 const unsigned ka0 = magic(grid3.x), ka1 = magic(grid3.y), ktotal = grid3.x * grid3.y * (unsigned)cs.n;
                 PANO_LAUNCH_L0((blend_level_vec_kernel<true, 3>), grid);
             }
+        } else if (ordered) {
+            hipLaunchKernelGGL((blend_level_ordered_kernel<false, 1>), dim3(8u * maxper, cs.n * 3, 1), block, 0, s, ko0, ko1, kp0, kp1, l, p, q);
         } else {
             hipLaunchKernelGGL((blend_level_vec_kernel<false, 1>), shape == 3 ? grid : dim3(grid.x, grid.y, cs.n * 3), block, 0, s, larg,
                                magic(grid3.x), magic(grid3.y), grid3.x * grid3.y * (unsigned)(cs.n * 3), p, q);

@@ -103,6 +103,7 @@ struct PyrParams {
     int ncam;
 };
 
+constexpr int kOrderLevels = 3;  // blend levels that can run in seam-first tile order (the vector levels of five bands)
 struct CanvasParams {
     int16_t* img[kLevels];     // collapsed canvas levels, planar int16 (level 0 is never materialised)
     int cpitch[kLevels];       // int16 elements per row
@@ -112,10 +113,12 @@ struct CanvasParams {
                                // 0xFF mixed; high byte = bit i set when camera i carries weight anywhere on the block
     int opitch[kLevels];       // owner entries per block row
     int small_base;            // >0: levels small_base..bands run as one normalise launch + one LDS collapse launch
-    const uint32_t* order0;    // level 0, or nullptr: per XCD band (order_per entries each, low half 0xffff = none) the 128 x 16-pixel
-    int order_per, order_gx;   // workgroup tiles in the order they are dispatched - seam tiles first; low half = bx | by << 8;
-                               // high half: what the tile's four waves will find in the owner map, a nibble each (wave = threadIdx.y):
-                               // 0..7 the single owner of every block of the wave, 0xE no owner anywhere, 0xF look it up
+    // vector levels 0 .. kOrderLevels - 1, or nullptr: per XCD band (order_per entries each, low half 0xffff = none) the 128 x 16-pixel
+    // workgroup tiles in the order they are dispatched - seam tiles first; low half = bx | by << 8; high half: what the tile's four
+    // waves will find in the owner map, a nibble each (wave = threadIdx.y): 0..7 the single owner of every block of the wave,
+    // 0xE no owner anywhere, 0xF look it up
+    const uint32_t* order[kOrderLevels];
+    int order_per[kOrderLevels];
     int cam_lo, cam_n;         // this canvas blends cameras [cam_lo, cam_lo + cam_n) of the PyrParams it is launched with
     int w0, h0;                // padded canvas size
     int bands;
@@ -206,8 +209,9 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
                         hipEvent_t ev_stop = nullptr);
 // the small levels small_base..bands in two launches: normalise, then the collapse chain through LDS
 void launch_blend_small(const PyrParams& p, const CanvasSet& cs, hipStream_t s);
-// per 128 x 16-pixel tile of level 0 (gx x gy of them over the hull of the cut): the owner nibbles of its four waves (0xF: no single owner)
-void launch_tile_mixed(const CanvasParams& c, int gx, int gy, uint16_t* flags, hipStream_t s);
+// per 128 x 16-pixel tile of vector level l (gx x gy of them; level 0: over the hull of the cut): the owner nibbles of its four
+// waves (0xF: no single owner)
+void launch_tile_mixed(const CanvasParams& c, int l, int gx, int gy, uint16_t* flags, hipStream_t s);
 // owner map of a vector level (run when masks change)
 void launch_build_owner(const PyrParams& p, const CanvasParams& c, int l, uint16_t* owner, hipStream_t s);
 // Blender::NO path
