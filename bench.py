@@ -484,7 +484,7 @@ def main():
                 b0_bytes = int(8.5 * ow * oh * NG)
                 b0_ms = bms[3] / bn[3]
                 b0_gbs = b0_bytes / (b0_ms * 1e-3) / 1e9
-                blend0 = {"kernel": "blend_level_vec_kernel<true,3>", "bound": "hbm", "algorithmic_bytes_per_launch": b0_bytes,
+                blend0 = {"kernel": "blend_level_ordered_kernel<true,3>", "bound": "hbm", "algorithmic_bytes_per_launch": b0_bytes,
                           "avg_launch_us": round(b0_ms * 1e3, 2), "achieved": round(b0_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(b0_gbs / HBM_PEAK_GBS, 4)}
             cold = None
