@@ -715,7 +715,7 @@ def config4_leg(pano, torch, steps):
            "panoramas_per_s": round(1.0 / dt, 1), "frames_in_flight": F, "steps": steps,
            "one_frame_at_a_time_stage_us": {k: round(ms[i] / max(n[i], 1) * 1e3, 2) for i, k in enumerate(("warp", "pyramid", "blend", "blend_level0"))},
            "roofline": {"warp_with_gains": roof("warp_tiles_lut_kernel<true>", sb + db, ms[0], n[0]),
-                        "blend_level0": roof("blend_level_vec_kernel<true,3>", 8.5 * ow * oh, ms[3], n[3]),
+                        "blend_level0": roof("blend_level_ordered_kernel<true,3>", 8.5 * ow * oh, ms[3], n[3]),
                         "measured": "%d frames one at a time, dispatch events of the kernels" % steps}}
     del ctx
     return out

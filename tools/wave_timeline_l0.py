@@ -48,4 +48,4 @@ for rep in range(3):
                 "waves_per_xcc": np.bincount(xcc, minlength=8).tolist(),
                 "seam_waves_per_xcc": np.bincount(xcc[seam], minlength=8).tolist(),
                 "last_wave_end_us_per_xcc": [round(float(us[xcc == k, 2].max()), 2) if (xcc == k).any() else None for k in range(8)]})
-print(json.dumps({"kernel": "blend_level_vec_kernel<true,3>, config 2, one launch at a time, instrumented build", "launches": res}, indent=1))
+print(json.dumps({"kernel": "blend_level_ordered_kernel<true,3>, config 2, one launch at a time, instrumented build", "launches": res}, indent=1))
