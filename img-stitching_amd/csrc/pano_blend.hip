@@ -609,13 +609,17 @@ struct BlendOrderedArgs {  // the kernel's argument list as the kernarg segment 
     CanvasSet CS;
 };
 // L0 (NPL 3): 5 waves / SIMD = at most 96 VGPRs (the allocator stopped at 97: a granule more, and a wave less).
-// Levels >= 1 (NPL 1): blockIdx.y = canvas * 3 + plane, l = the level.
+// Levels >= 1 (NPL 1): one plane per lane, l = the level.
 template <bool L0, int NPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(L0 ? 5 : 8, 8))) void blend_level_ordered_kernel(
     const uint32_t* ord0, const uint32_t* ord1, unsigned per0, unsigned per1, int l, PyrParams P, CanvasSet CS) {
     static_assert((L0 && NPL == 3) || (!L0 && NPL == 1), "level 0 does three planes per lane, the levels above one");
-    const unsigned cvi = NPL == 3 ? blockIdx.y : blockIdx.y / 3u;
-    const int pb = NPL == 3 ? 0 : (int)(blockIdx.y - cvi * 3u);
+    // grid (8 * canvases [* 3 planes], entries per XCD): blockIdx.x = XCD + 8 * (canvas [* 3 + plane]), blockIdx.y = position in the
+    // XCD's list - so that the seam tiles of BOTH canvases are dispatched first (canvas-major, the second canvas' seam waves
+    // started when the first canvas' whole list was out: half-way through the launch)
+    const unsigned zi = blockIdx.x >> 3;
+    const unsigned cvi = NPL == 3 ? zi : zi / 3u;
+    const int pb = NPL == 3 ? 0 : (int)(zi - cvi * 3u);
     blend_i32x16 ha;
     blend_i32x8 hb8;
     {
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(L0 ? 5 : 8,
             (offsetof(BlendOrderedArgs, CS) + offsetof(CanvasSet, c) + cvi * sizeof(CanvasParams) + offsetof(CanvasParams, hot));
         asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40" : "=&s"(ha), "=&s"(hb8) : "s"(hb) : "memory");
     }
-    const unsigned k = blockIdx.x & 7u, jj = blockIdx.x >> 3;
+    const unsigned k = blockIdx.x & 7u, jj = blockIdx.y;
     const unsigned per = cvi ? per1 : per0;
     const uint32_t* ord = cvi ? ord1 : ord0;
     if (jj >= per) return;
@@ -760,12 +764,12 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
             ordered = cs.c[g].order[l] != nullptr;
             maxper = max(maxper, (unsigned)cs.c[g].order_per[l]);
         }
-        ordered = ordered && maxper > 0 && maxper < (1u << 20);
+        ordered = ordered && maxper > 0 && maxper < 65536u;  // grid.y
         const uint32_t *ko0 = ordered ? cs.c[0].order[l] : nullptr, *ko1 = ordered && cs.n > 1 ? cs.c[1].order[l] : nullptr;
         const unsigned kp0 = ordered ? (unsigned)cs.c[0].order_per[l] : 0u, kp1 = ordered && cs.n > 1 ? (unsigned)cs.c[1].order_per[l] : 0u;
         if (l == 0) {
             if (ordered) {
-                const dim3 go(8u * maxper, cs.n, 1);
+                const dim3 go(8u * cs.n, maxper, 1);
                 if (ev_start && ev_stop) hipExtLaunchKernelGGL((blend_level_ordered_kernel<true, 3>), go, block, 0, s, ev_start, ev_stop, 0, ko0, ko1, kp0, kp1, 0, p, q);
                 else hipLaunchKernelGGL((blend_level_ordered_kernel<true, 3>), go, block, 0, s, ko0, ko1, kp0, kp1, 0, p, q);
             } else {
@@ -774,7 +778,7 @@ void launch_blend_level(const PyrParams& p, const CanvasSet& cs, int l, hipStrea
                 PANO_LAUNCH_L0((blend_level_vec_kernel<true, 3>), grid);
             }
         } else if (ordered) {
-            hipLaunchKernelGGL((blend_level_ordered_kernel<false, 1>), dim3(8u * maxper, cs.n * 3, 1), block, 0, s, ko0, ko1, kp0, kp1, l, p, q);
+            hipLaunchKernelGGL((blend_level_ordered_kernel<false, 1>), dim3(8u * cs.n * 3, maxper, 1), block, 0, s, ko0, ko1, kp0, kp1, l, p, q);
         } else {
             hipLaunchKernelGGL((blend_level_vec_kernel<false, 1>), shape == 3 ? grid : dim3(grid.x, grid.y, cs.n * 3), block, 0, s, larg,
                                magic(grid3.x), magic(grid3.y), grid3.x * grid3.y * (unsigned)(cs.n * 3), p, q);
