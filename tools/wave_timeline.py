@@ -62,5 +62,7 @@ for rep in range(3):
                 "phase_us_p90": {nm: round(float(np.percentile(ph[:, i], 90)), 3) for i, nm in enumerate(names)},
                 "waves_resident_every_1us": resident[::4],
                 "waves_per_xcc": np.bincount(xcc, minlength=8).tolist(),
+                "wave_lifetime_us_mean_per_xcc": [round(float(life[xcc == k].mean()), 2) if (xcc == k).any() else None for k in range(8)],
+                "phase_us_mean_per_xcc": {nm: [round(float(ph[xcc == k, i].mean()), 3) if (xcc == k).any() else None for k in range(8)] for i, nm in enumerate(names)},
                 "last_wave_end_us_per_xcc": [round(float(us[xcc == k, 8].max()), 2) if (xcc == k).any() else None for k in range(8)]})
 print(json.dumps({"kernel": "warp_tiles_lut_kernel<false>, config 2, one launch at a time, instrumented build (nine s_memrealtime + waits per wave: the launch takes longer than the product's)", "launches": res}, indent=1))
