@@ -101,6 +101,9 @@ struct PyrCam {
 struct PyrParams {
     PyrCam cam[kCams];
     int ncam;
+    // set by launch_pyr_down for the launch: per camera {live workgroup columns, 2^32 / columns + 1, workgroups per plane (columns x
+    // rows), 2^32 / that + 1} (a multiplier of 0: divide by 1) - the kernel's own deal of its live workgroups over the XCDs
+    unsigned deal[kCams][4];
 };
 
 constexpr int kOrderLevels = 3;  // blend levels that can run in seam-first tile order (the vector levels of five bands)

@@ -20,19 +20,42 @@ namespace pano {
 #define PANO_PYR_ROWS_UP 4
 #endif
 constexpr int kPyrRows0 = PANO_PYR_ROWS, kPyrRowsUp = PANO_PYR_ROWS_UP;  // output rows per lane: level 0 -> 1, the levels above
-// Prologue: cam_bits and l lead the arguments (preloaded into SGPRs at wave launch, see the Makefile), and the camera's fields
-// of the two levels are requested TOGETHER - six scalar loads, one wait.  Read field by field behind the early exits they were
-// seven dependent round trips per wave (about 1 us of a wave that lives 2 - 3).
-constexpr unsigned kPyrParamsAt = 8;  // offset of P in the kernarg segment: two dwords in front of it
+// The deal (like K1's, pano_kernels.hpp WarpDeal): the LIVE workgroups of every camera of the launch - camera after camera, plane
+// after plane, row after row - form one list and XCD k (= blockIdx.x: grid.x is 8) takes the k-th eighth of it: no workgroup is
+// launched only to find its rows dead, every XCD has the same number, and a plane's neighbouring workgroups - which share three rows
+// and a 128-byte line each - sit in one L2.  The prefix sums (e0 .. e7: workgroups of cameras 0 .. c) and the share per XCD lead the
+// arguments (preloaded into SGPRs at wave launch, see the Makefile: no memory round trip); the level rides in per's top bits.
+// Prologue: the camera's fields of the two levels and its deal entry are requested TOGETHER - seven scalar loads, one wait.  Read
+// field by field behind the early exits they were seven dependent round trips per wave (about 1 us of a wave that lives 2 - 3).
+constexpr unsigned kPyrParamsAt = 40;  // offset of P in the kernarg segment: nine dwords in front of it, then alignof(PyrParams)
 template <int R>
-__global__ __launch_bounds__(256) void pyr_down_kernel(unsigned cam_bits, int l, PyrParams P) {
-    static_assert(alignof(PyrParams) == 8, "kPyrParamsAt");
+__global__ __launch_bounds__(256) void pyr_down_kernel(unsigned e0, unsigned e1, unsigned e2, unsigned e3, unsigned e4, unsigned e5, unsigned e6,
+                                                       unsigned e7, unsigned per_l, PyrParams P) {
+    static_assert(alignof(PyrParams) == 8 && kCams == 8, "kPyrParamsAt, eight prefix sums");
     constexpr int NR = 2 * R + 3;  // source rows of R output rows
-    const int ci = blockIdx.z / 3, pl = blockIdx.z - ci * 3;
-    if (!((cam_bits >> ci) & 1u)) return;
+    const unsigned per = per_l & 0x0fffffffu;
+    const int l = (int)(per_l >> 28);
+    const unsigned lin = blockIdx.x * per + blockIdx.y;
+    if (lin >= e7) return;  // past the end of the list (the whole workgroup leaves)
+    const unsigned ends[kCams] = {e0, e1, e2, e3, e4, e5, e6, e7};
+    unsigned ci = 0, dstart = 0;
+#pragma unroll
+    for (int c = 0; c < kCams - 1; c++) {
+        if (lin >= ends[c]) {
+            ci = c + 1;
+            dstart = ends[c];
+        }
+    }
     typedef int i32x2 __attribute__((ext_vector_type(2)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u32x4 cdeal;
+    {
+        const char __attribute__((address_space(4)))* a_deal = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
+            (kPyrParamsAt + (unsigned)offsetof(PyrParams, deal) + ci * 16u);
+        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(cdeal) : "s"(a_deal) : "memory");
+    }
     i32x2 cwh, cgap, cpitch, cplane;
     i32x4 clive;
     u64x2 clvl;
@@ -52,17 +75,22 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(unsigned cam_bits, int l,
         asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(clvl) : "s"(a_lvl) : "memory");
         asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(cpitch) : "s"(a_pitch) : "memory");
         asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(cplane) : "s"(a_plane) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cwh), "+s"(clive), "+s"(cgap), "+s"(clvl), "+s"(cpitch), "+s"(cplane) : : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cwh), "+s"(clive), "+s"(cgap), "+s"(clvl), "+s"(cpitch), "+s"(cplane), "+s"(cdeal) : : "memory");
     }
+    // position in the camera's list -> plane, workgroup row, workgroup column (divisions by multiplication)
+    const unsigned dl = lin - dstart;
+    const unsigned pl = cdeal.w ? __umulhi(dl, cdeal.w) : dl;
+    const unsigned dr = dl - pl * cdeal.z;
+    const unsigned by = cdeal.y ? __umulhi(dr, cdeal.y) : dr, bx = dr - by * cdeal.x;
     const int sw = cwh.x >> l, sh = cwh.y >> l;
     const int dw = sw >> 1, dh = sh >> 1;
     // Outputs of level l + 1 that nothing downstream reads are not produced (their inputs may not exist either): the
     // grid is laid over the live rect, so that whole waves - not lanes - fall off its far side.
     const int lx0 = clive.x, ly0 = clive.y, lx1 = clive.z, ly1 = clive.w;
-    const int t = (lx0 >> 2) + blockIdx.x * 64 + threadIdx.x;  // group of 4 output columns
+    const int t = (lx0 >> 2) + (int)bx * 64 + threadIdx.x;  // group of 4 output columns
     // a wave is one threadIdx.y: tell the compiler, and the row indices, the REFLECT_101 of the source rows and
     // their addresses are scalar work (a quarter of this kernel's vector instructions otherwise)
-    const int y0 = ((int)((unsigned)ly0 / R) + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * R;  // first of R output rows
+    const int y0 = ((int)((unsigned)ly0 / R) + (int)by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * R;  // first of R output rows
     if (y0 >= dh || y0 > ly1) return;
     if (t * 4 >= dw || t * 4 > lx1) return;
     if (t * 4 >= cgap.x && t * 4 + 3 <= cgap.y) return;  // the dead middle of a +-pi straddler's tile
@@ -415,17 +443,39 @@ void launch_pyr_tail(const PyrParams& p, unsigned cam_bits, int b, int t, hipStr
 }
 
 void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s) {
-    int mw = 0, mh = 0;
-    for (int i = 0; i < p.ncam; i++)
-        if ((cam_bits >> i) & 1u) {
-            mw = max(mw, p.cam[i].w0 >> (l + 1));
-            mh = max(mh, p.cam[i].h0 >> (l + 1));
-        }
-    if (mw == 0 || mh == 0) return;
     const int R = l == 0 ? kPyrRows0 : kPyrRowsUp;
-    dim3 block(64, 4, 1), grid((mw + 255) / 256, (mh + 4 * R - 1) / (4 * R), p.ncam * 3);
-    if (l == 0) hipLaunchKernelGGL(pyr_down_kernel<kPyrRows0>, grid, block, 0, s, cam_bits, l, p);
-    else hipLaunchKernelGGL(pyr_down_kernel<kPyrRowsUp>, grid, block, 0, s, cam_bits, l, p);
+    PyrParams q = p;
+    unsigned ends[kCams], total = 0;
+    auto magic = [](unsigned d) { return d > 1 ? (unsigned)((1ull << 32) / d + 1ull) : 0u; };
+    for (int i = 0; i < kCams; i++) {
+        unsigned cols = 0, rows = 0;
+        if (i < p.ncam && ((cam_bits >> i) & 1u)) {
+            const PyrCam& c = p.cam[i];
+            const int dw = (c.w0 >> l) >> 1, dh = (c.h0 >> l) >> 1;
+            const int lx0 = c.live[l + 1][0], ly0 = c.live[l + 1][1], lx1 = min(c.live[l + 1][2], dw - 1), ly1 = min(c.live[l + 1][3], dh - 1);
+            if (lx0 >= 0 && ly0 >= 0 && lx1 >= lx0 && ly1 >= ly0) {
+                // the kernel's own tests: a workgroup's first lane is column group (lx0 >> 2) + 64 bx, its first wave's rows start at
+                // (ly0 / R + 4 by) * R
+                cols = (unsigned)(((lx1 >> 2) - (lx0 >> 2)) / 64 + 1);
+                rows = (unsigned)((ly1 / R - ly0 / R) / 4 + 1);
+            }
+        }
+        q.deal[i][0] = max(cols, 1u);
+        q.deal[i][1] = magic(q.deal[i][0]);
+        q.deal[i][2] = max(cols * rows, 1u);
+        q.deal[i][3] = magic(q.deal[i][2]);
+        total += 3u * cols * rows;
+        ends[i] = total;
+    }
+    if (total == 0) return;
+    const unsigned per = (total + 7u) / 8u;
+    if (per >= (1u << 16)) return;  // (grid.y; a plane of that many workgroups does not exist)
+    const unsigned per_l = per | (unsigned)l << 28;
+    const dim3 block(64, 4, 1), grid(8, per, 1);
+    if (l == 0)
+        hipLaunchKernelGGL(pyr_down_kernel<kPyrRows0>, grid, block, 0, s, ends[0], ends[1], ends[2], ends[3], ends[4], ends[5], ends[6], ends[7], per_l, q);
+    else
+        hipLaunchKernelGGL(pyr_down_kernel<kPyrRowsUp>, grid, block, 0, s, ends[0], ends[1], ends[2], ends[3], ends[4], ends[5], ends[6], ends[7], per_l, q);
 }
 
 }  // namespace pano
