@@ -469,7 +469,8 @@ void launch_pyr_down(const PyrParams& p, unsigned cam_bits, int l, hipStream_t s
     }
     if (total == 0) return;
     const unsigned per = (total + 7u) / 8u;
-    if (per >= (1u << 16)) return;  // (grid.y; a plane of that many workgroups does not exist)
+    // (per is grid.y: a launch of more than 65535 x 8 workgroups - half a gigapixel of level l + 1 - fails in hipLaunchKernel and
+    // surfaces as the entry's error, like K1's)
     const unsigned per_l = per | (unsigned)l << 28;
     const dim3 block(64, 4, 1), grid(8, per, 1);
     if (l == 0)
