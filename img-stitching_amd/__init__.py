@@ -84,7 +84,7 @@ def load_library():
 MAX_FRAME_SLOTS = 4  # PANO_MAX_FRAME_SLOTS
 
 EXPORTS = [
-    "pano_create", "pano_destroy", "pano_last_error", "pano_version", "pano_set_camera",
+    "pano_create", "pano_destroy", "pano_last_error", "pano_version", "pano_set_camera", "pano_verify_cameras",
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_get_camera", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
     "pano_build_masks_voronoi", "pano_build_masks_graphcut", "pano_refresh_masks_begin", "pano_refresh_masks_poll", "pano_refresh_masks_wait", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
@@ -159,6 +159,18 @@ class Context:
         K = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
         R = np.ascontiguousarray(np.asarray(R, np.float32).reshape(9))
         self._ck(self.lib.pano_set_camera(self.h, i, _vp(K.ctypes.data), _vp(R.ctypes.data)))
+
+    def verify_cameras(self, K_est, R_est, ex_thres, in_thres):
+        """verifyCamParams (ocvstitcher.hpp:365-421): (ok, first failing camera or -1)"""
+        K = np.ascontiguousarray(np.asarray(K_est, np.float32).reshape(-1))
+        R = np.ascontiguousarray(np.asarray(R_est, np.float32).reshape(-1))
+        assert K.size == 9 * self.n and R.size == 9 * self.n
+        worst = C.c_int(-1)
+        self.lib.pano_verify_cameras.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        st = self.lib.pano_verify_cameras(self.h, _vp(K.ctypes.data), _vp(R.ctypes.data), ex_thres, in_thres, C.addressof(worst))
+        if st not in (0, -1):
+            self._ck(st)
+        return st == 0, worst.value
 
     def set_cameras_from_list(self, text):
         self._ck(self.lib.pano_set_cameras_from_list(self.h, text.encode()))

@@ -72,6 +72,16 @@ const char* pano_version(void);
 /* camK[i] / cameraR[i], row-major f32 - useDefaultCamParams (ocvstitcher.hpp:423-450),
  * initCamParams (:452-520) */
 pano_status pano_set_camera(pano_ctx* ctx, int i, const float K[9], const float R[9]);
+/* Every way of setting cameras (this entry, the list, the file loaders) validates them: all 18 values finite, fx, fy > 0,
+ * max |R^T R - I| <= 1e-3 and det R > 0; anything else is PANO_EINVAL with the reason in pano_last_error, and the context
+ * keeps its previous cameras.  (The reference plans whatever it is given and fails later in a CV_Assert.) */
+/* verifyCamParams (ocvstitcher.hpp:365-421): compare N ESTIMATED cameras (K_est / R_est: N x 9 row-major f32, e.g. from a
+ * caller-side bundle adjustment) with the cameras the context holds (the defaults): per camera the Euclidean distance of the
+ * Euler angles in degrees (rotationMatrixToEulerAngles, :229-253) against ex_thres (yaml stitcherCameraExThres) and of
+ * (fx, fy) against in_thres (stitcherCameraInThres).  PANO_OK: the estimate is plausible; PANO_ERR (== RET_ERR): "environment
+ * is not suitable for calibration, use default parameters" - *worst_camera (optional) names the first camera that failed.
+ * Changes nothing in the context. */
+pano_status pano_verify_cameras(pano_ctx* ctx, const float* K_est, const float* R_est, float ex_thres, float in_thres, int* worst_camera);
 /* parse the reference's `18*N+1` comma-separated list (defaultCamParams, ocvstitcher.hpp:423-450;
  * cameras.yaml `cams:`), sets all N cameras and warped_image_scale */
 pano_status pano_set_cameras_from_list(pano_ctx* ctx, const char* comma_separated_floats);

@@ -174,3 +174,81 @@ def test_new_camera_matrix_matches_oracle(pano, po, rig_r):
     ctx.set_cameras_from_list(",".join(repr(v) for v in rig_r["stitchers"][0]["cams"]))
     with pytest.raises(pano.PanoError):
         ctx.prepare()                                                                  # front end on one camera only
+
+
+def _ry(deg):
+    a = np.deg2rad(deg)
+    return np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+
+
+def test_cameras_are_validated_at_the_boundary(pano, c1, tmp_path):
+    """VERDICT r03 #8 (ocvstitcher.hpp:365-421 / SURVEY 5): non-finite values, a scaled R, a sheared R and a reflected R are
+    refused with PANO_EINVAL and a reason; the context keeps what it had; the reference's own records pass"""
+    ctx = pano.Context(4, 480, 270, scale=c1["scale"], device=-1)
+    K, R = np.asarray(c1["K"][0], np.float32).reshape(3, 3), np.asarray(c1["R"][1], np.float32).reshape(3, 3)
+    ctx.set_camera(0, K, R)
+    bad = []
+    k = K.copy(); k[0, 2] = np.nan; bad.append((k, R, "finite"))
+    r = R.copy(); r[1, 1] = np.inf; bad.append((K, r, "finite"))
+    k = K.copy(); k[0, 0] = 0; bad.append((k, R, "focal"))
+    k = K.copy(); k[1, 1] = -391; bad.append((k, R, "focal"))
+    bad.append((K, R * 1.01, "orthonormal"))
+    r = R.copy(); r[0, 1] += 0.01; bad.append((K, r, "orthonormal"))
+    bad.append((K, R @ np.diag([1, -1, 1]).astype(np.float32), "reflection"))
+    bad.append((K, np.zeros((3, 3), np.float32), "orthonormal"))
+    for k, r, why in bad:
+        with pytest.raises(pano.PanoError) as e:
+            ctx.set_camera(0, k, r)
+        assert e.value.status == -2 and why in str(e.value), (why, str(e.value))
+    gk, gr, _ = ctx.get_camera(0)
+    assert np.array_equal(np.asarray(gk, np.float32).reshape(3, 3), K) and np.array_equal(np.asarray(gr, np.float32).reshape(3, 3), R)
+    # a rotation perturbed inside the tolerance (six significant digits, like the reference's text files) is accepted
+    ctx.set_camera(1, K, np.round(_ry(-42.9).astype(np.float64), 5).astype(np.float32))
+    # the list and the file loaders are all or nothing: camera 2 of 4 is bad -> nothing changes
+    good = [np.concatenate([K.reshape(-1), _ry(-20.0 * i).reshape(-1)]) for i in range(4)]
+    vals = np.concatenate(good + [np.float32([c1["scale"]])])
+    ctx.set_cameras_from_list(",".join("%.9g" % v for v in vals))
+    before = [ctx.get_camera(i) for i in range(4)]
+    broken = [g.copy() for g in good]
+    broken[2][9:] *= 1.5
+    with pytest.raises(pano.PanoError):
+        ctx.set_cameras_from_list(",".join("%.9g" % v for v in np.concatenate(broken + [np.float32([c1["scale"]])])))
+    p = tmp_path / "cameraparaout_9.txt"
+    p.write_text("2026-01-01-00-00-00:\n" + "".join(",".join("%.9g" % v for v in b) + ",\n" for b in broken) + "%g\n" % c1["scale"])
+    with pytest.raises(pano.PanoError):
+        ctx.load_camera_file(str(p))
+    after = [ctx.get_camera(i) for i in range(4)]
+    assert all(np.array_equal(np.asarray(a[0]), np.asarray(b[0])) and np.array_equal(np.asarray(a[1]), np.asarray(b[1])) for a, b in zip(before, after))
+    with pytest.raises(pano.PanoError):
+        ctx.set_cameras_from_list(",".join("%.9g" % v for v in np.concatenate(good + [np.float32([-1.0])])))
+
+
+def test_verify_cameras_like_the_reference(pano, c1):
+    """verifyCamParams (ocvstitcher.hpp:394-417): Euler-angle distance in degrees against stitcherCameraExThres, (fx, fy)
+    distance against stitcherCameraInThres; RET_ERR keeps the defaults"""
+    n = 4
+    ctx = pano.Context(n, 480, 270, scale=c1["scale"], device=-1)
+    K = np.asarray(c1["K"][0], np.float32).reshape(3, 3)
+    Rs = [_ry(-45.0 * i) for i in range(n)]
+    for i in range(n):
+        ctx.set_camera(i, K, Rs[i])
+    Ks = np.stack([K] * n)
+    assert ctx.verify_cameras(Ks, np.stack(Rs), 5.0, 50.0) == (True, -1)
+    # camera 2 turned by 3 degrees: inside a 5-degree threshold, outside a 2-degree one
+    Re = [r.copy() for r in Rs]
+    Re[2] = _ry(-90.0 + 3.0)
+    assert ctx.verify_cameras(Ks, np.stack(Re), 5.0, 50.0) == (True, -1)
+    assert ctx.verify_cameras(Ks, np.stack(Re), 2.0, 50.0) == (False, 2)
+    # the reference's own formula on the same pair
+    def euler(R):
+        R = R.astype(np.float64)
+        sy = np.float32(np.sqrt(R[0, 0] ** 2 + R[1, 0] ** 2))
+        return np.float32(np.rad2deg([np.arctan2(R[2, 1], R[2, 2]), np.arctan2(-R[2, 0], sy), np.arctan2(R[1, 0], R[0, 0])]))
+    d = float(np.linalg.norm(euler(Rs[2]).astype(np.float64) - euler(Re[2]).astype(np.float64)))
+    assert ctx.verify_cameras(Ks, np.stack(Re), d * 1.001, 50.0)[0] and not ctx.verify_cameras(Ks, np.stack(Re), d * 0.999, 50.0)[0]
+    # focal lengths: (fx + 30, fy + 40) is 50 away
+    Ke = Ks.copy(); Ke[1, 0, 0] += 30; Ke[1, 1, 1] += 40
+    assert ctx.verify_cameras(Ke, np.stack(Rs), 5.0, 50.5) == (True, -1)
+    assert ctx.verify_cameras(Ke, np.stack(Rs), 5.0, 49.5) == (False, 1)
+    Ke[3, 0, 0] = np.nan
+    assert ctx.verify_cameras(Ke, np.stack(Rs), 5.0, 1e9) == (False, 3)

@@ -85,16 +85,30 @@ def test_replay_frames_on_gpu(replay_bin, rig_r, tmp_path):
 
 
 @pytest.mark.gpu
-def test_replay_paced_loop_with_mask_refresh_beside_it(replay_bin, rig_r, tmp_path):
-    """the capture loop of src/master.cpp paced at 60 fps with a graph-cut mask refresh every 30 frames: run beside the loop
-    (pano::Stitcher::asyncMaskRefresh -> pano_refresh_masks_*) no tick is lost"""
+def test_replay_loop_with_mask_refresh_beside_it_unpaced(replay_bin, rig_r, tmp_path):
+    """the capture loop of src/master.cpp with a graph-cut mask refresh every 10 frames running BESIDE it
+    (pano::Stitcher::asyncMaskRefresh -> pano_refresh_masks_*), not paced - no wall clock in this test: every frame is composed,
+    and the stacked image behind three refreshes from the same real frames is the oracle's, byte for byte (the paced twin of this
+    run lives in test_zz_gpu_paced_loops.py, last in the collection order)"""
+    import numpy as np
+    from conftest import GOLDEN, load_png_bgr
     cfg = write_cfgs(tmp_path, rig_r)
-    r = subprocess.run([replay_bin, str(cfg), "--frames", "120", "--fps", "60", "--refresh-every", "30", "--async-refresh"],
+    ppms = []
+    for i in range(4):
+        a = load_png_bgr(os.path.join(GOLDEN, f"r_cam{i}.png"))[:, :, ::-1]
+        p = tmp_path / f"r{i}.ppm"
+        with open(p, "wb") as f:
+            f.write(b"P6\n960 540\n255\n" + np.ascontiguousarray(a).tobytes())
+        ppms.append(str(p))
+    r = subprocess.run([replay_bin, str(cfg), "--frames", "40", "--refresh-every", "10", "--async-refresh"] + ppms,
                        capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 0, r.stderr + r.stdout
-    # a wall-clock loop on a shared box: every frame is composed; a tick or two may be late, never a refresh's worth of them
-    m = re.search(r"120 frames offered, (\d+) composed, dropped (\d+)", r.stdout)
-    assert m and int(m.group(1)) + int(m.group(2)) == 120 and int(m.group(2)) <= 2 and "beside the loop" in r.stdout, r.stdout
+    assert len([l for l in r.stdout.splitlines() if l.startswith("frame ")]) == 40      # dropped 0: nothing here can drop one
+    raw = open(tmp_path / "final.ppm", "rb").read()
+    head = b"P6\n1470 500\n255\n"
+    assert raw.startswith(head)
+    got = np.frombuffer(raw[len(head):], np.uint8).reshape(500, 1470, 3)[:, :, ::-1]
+    assert np.array_equal(got, load_png_bgr(os.path.join(GOLDEN, "r_stacked.png")))
 
 
 @pytest.fixture(scope="module")

@@ -1139,21 +1139,6 @@ def test_host_entry_pageable_pinned_and_strided(pano, po, torch, c1):
         b.close()
 
 
-def test_paced_60fps_stream(pano, po):
-    """BASELINE config 5 in small: 2 x 4 x 960x540 frames offered at 60 fps for one second through pano_stream_* (page-locked
-    slots, two panoramas in flight; tools/stream_60fps.py is the harness): no frame dropped, and the sampled panoramas are the
-    oracle's"""
-    import importlib.util
-    from conftest import ROOT
-    spec = importlib.util.spec_from_file_location("stream_60fps", os.path.join(ROOT, "tools", "stream_60fps.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    r = mod.run(fps=60.0, frames=60, width=960, height=540, bands=4, check=True)
-    assert r["dropped"] == 0 and r["frames_composed"] == 60, r
-    assert r["sampled_frames_equal_oracle"] is True, r
-    assert r["achieved_fps"] > 55.0, r
-
-
 def test_host_entries_upload_only_what_the_warp_reads(pano, po):
     """pano_get_source_rect: with masks set, the host entries (pano_compose_host, pano_stream_submit) upload only the frame bytes
     the warp's live patches tap.  Proof that nothing outside that rectangle is ever read: frames whose bytes OUTSIDE it are
@@ -1197,26 +1182,6 @@ def test_host_entries_upload_only_what_the_warp_reads(pano, po):
     assert ctx.source_rect(1)[3] == 0                            # nothing of camera 1 is read any more
     for b in pin:
         b.close()
-
-
-def test_paced_60fps_stream_at_full_size_with_mask_refresh(pano, po):
-    """BASELINE config 5 at its stated size: 8 x 1920x1080 frames offered at 60 fps for ten seconds (600 ticks) through
-    pano_stream_*, with the reference's mask refresh every 200 frames (include/ocvstitcher.hpp:1152-1159) running BESIDE the loop
-    (pano_refresh_masks_begin / _poll: graph cuts on a thread of the library).  The capture loop it stands for is
-    src/master.cpp:302-411.  No tick may be lost to a refresh (one is ~110 ms of host max-flow: inline it costs 6 ticks each); a
-    wall-clock loop on a shared box is allowed two late ticks in 600.  Panoramas sampled before, between and after the refreshes
-    are the oracle's for the masks in force at their tick"""
-    import importlib.util
-    from conftest import ROOT
-    spec = importlib.util.spec_from_file_location("stream_60fps", os.path.join(ROOT, "tools", "stream_60fps.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    r = mod.run(fps=60.0, frames=600, width=1920, height=1080, bands=5, check=True, refresh_every=200, refresh_async=True)
-    print(r)
-    assert r["dropped"] <= 2 and r["frames_composed"] + r["dropped"] == 600, r
-    assert r["mask_refresh"]["masks_installed"] >= 2, r            # both stitchers' refreshes came through
-    assert r["sampled_frames_equal_oracle"] is True and r["sampled_frames"] == [0, 300, 599], r
-    assert r["achieved_fps"] > 58.0, r
 
 
 def test_258st_frames_bit_exact(pano, po, st258):
