@@ -506,12 +506,19 @@ def main():
                     cold = dict(k1_roofline(cms, cn), frame_sets=cold_sets,
                                 bytes_rotated=int(cold_sets * NG * NC * W * H * 3),
                                 note="one frame at a time over rotating frame sets larger than the 256 MiB Infinity Cache")
-            roofline = {"kernel": "warp_tiles_lut_kernel", "bound": "hbm", "achieved": alone["achieved"],
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alone["frac"],
+            # the headline fraction is the COLD one: the warm loop re-reads the same 49.8 MB of frames every step
+            # with a 256 MiB Infinity Cache in front of HBM; `warm` keeps the figure earlier rounds led with
+            warm_how = ("K steps, one frame at a time, the same frames every step, dispatch events of the kernel" if stats_iso is not None
+                        else "K steps under the conditions of the timed region, dispatch events of the kernel")
+            lead = cold if cold is not None else alone
+            roofline = {"kernel": "warp_tiles_lut_kernel", "bound": "hbm", "achieved": lead["achieved"],
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lead["frac"],
                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                        "avg_launch_us": alone["avg_launch_us"], "launches_per_step": launches_per_step,
-                        "measured": "K steps, one frame at a time, dispatch events of the kernel" if stats_iso is not None
-                                    else "K steps under the conditions of the timed region, dispatch events of the kernel",
+                        "avg_launch_us": lead["avg_launch_us"], "launches_per_step": launches_per_step,
+                        "measured": ("K steps, one frame at a time over %d rotating frame sets (larger than the 256 MiB Infinity Cache: no "
+                                     "launch finds its frames where an earlier one left them), dispatch events of the kernel" % cold_sets)
+                                    if cold is not None else warm_how,
+                        "warm": dict(alone, measured=warm_how),
                         "in_timed_region": dict(timed, frames_in_flight=F),
                         "one_frame_at_a_time_panoramas_per_s": alone_rate,
                         "one_frame_at_a_time_stage_us": alone_stage,
@@ -530,7 +537,7 @@ def main():
                 torch.cuda.synchronize()
                 copy_gbs = 2 * x.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
                 roofline["device_copy_ceiling_GBps"] = round(copy_gbs, 1)
-                roofline["frac_of_copy_ceiling"] = round(alone["achieved"] / copy_gbs, 4)
+                roofline["frac_of_copy_ceiling"] = round(lead["achieved"] / copy_gbs, 4)
                 del x, y
             except Exception:  # the side measurement never breaks the line
                 pass
@@ -553,7 +560,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8/int16 fixed-point (f32 weights)",
             "data": "synthetic",
-            "config": {"workload": "C2: 8x1920x1080 BGR8 -> 2 groups x 4 cameras, spherical warp + %d-band "
+            "config": {"workload": "C2: 8x1920x1080 BGR8 frames resident in HBM (device pointers in, device panoramas out: no PCIe in the "
+                                   "timed region; the link-inclusive rate is `h2d_inclusive`) -> 2 groups x 4 cameras, spherical warp + %d-band "
                                    "multi-band blend, Voronoi seams, pano 2 x %dx%d" % (args.bands, ow, oh),
                        "parallelism": ("single GPU, %d frames in flight" % F) if world == 1 else
                                       ("cameras sharded %d/rank, %s" % (per_rank,
@@ -659,6 +667,46 @@ def main():
             # compose and D2H of consecutive panoramas overlapped); PCIe-inclusive, so never `value`
             result["h2d_inclusive_panoramas_per_s"] = rate
             result["host_streaming_panoramas_per_s"] = rate
+            # ... and its own roofline: this path is bound by the host link, not by HBM.  Bytes per panorama pair that cross it: up =
+            # the live source rectangles of the 8 frames (pano_get_source_rect), down = the two panoramas.  Ceiling = plain page-locked
+            # hipMemcpyAsync of 64 MiB blocks, both directions at once on two streams (what the link gives a copy loop on this box);
+            # frac = the time the link needs for one step's bytes at those rates (full duplex: the longer direction) / the step time
+            try:
+                up_b = sum(r[2] * r[3] for c in ctxs for r in (c.source_rect(i) for i in range(NC)))
+                down_b = NG * ow * oh * 3
+                nb = 64 << 20
+                hp_up, hp_dn = torch.empty(nb, dtype=torch.uint8).pin_memory(), torch.empty(nb, dtype=torch.uint8).pin_memory()
+                d_up, d_dn = torch.empty(nb, dtype=torch.uint8, device="cuda"), torch.empty(nb, dtype=torch.uint8, device="cuda")
+                s_up, s_dn = torch.cuda.Stream(), torch.cuda.Stream()
+                torch.cuda.synchronize()
+
+                def both(reps):
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                    with torch.cuda.stream(s_up):
+                        ev[0].record()
+                        for _ in range(reps):
+                            d_up.copy_(hp_up, non_blocking=True)
+                        ev[1].record()
+                    with torch.cuda.stream(s_dn):
+                        ev[2].record()
+                        for _ in range(reps):
+                            hp_dn.copy_(d_dn, non_blocking=True)
+                        ev[3].record()
+                    torch.cuda.synchronize()
+                    return nb * reps / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9, nb * reps / (ev[2].elapsed_time(ev[3]) * 1e-3) / 1e9
+                both(2)
+                c_up, c_dn = both(12)
+                t_link = max(up_b / (c_up * 1e9), down_b / (c_dn * 1e9))
+                result["h2d_inclusive"] = {
+                    "panoramas_per_s": rate, "bound": "host link (PCIe), full duplex", "up_bytes_per_step": int(up_b), "down_bytes_per_step": int(down_b),
+                    "up_GBps": round(rate * up_b / 1e9, 2), "down_GBps": round(rate * down_b / 1e9, 2),
+                    "pinned_copy_ceiling_GBps": {"up": round(c_up, 2), "down": round(c_dn, 2),
+                                                 "measured": "hipMemcpyAsync of page-locked 64 MiB blocks, 12 each way, both directions at once"},
+                    "frac": round(t_link * rate, 4),
+                    "note": "frames of %d steps land in the library's page-locked slots; H2D, compose and D2H of consecutive steps overlap (pano_stream_*)" % nstream}
+                del hp_up, hp_dn, d_up, d_dn
+            except Exception as exc:  # noqa: BLE001 - a side measurement never breaks the line
+                result["h2d_inclusive"] = {"panoramas_per_s": rate, "error": repr(exc)[:200]}
         if world == 1 and not args.no_c4:
             try:
                 result["c4"] = config4_leg(pano, torch, max(60, min(args.steps, 200)))

@@ -177,6 +177,7 @@ struct pano_ctx {
     };
     std::vector<GraphEntry> graphs;
     bool use_graph = false;
+    uint64_t graph_replays = 0;   // hipGraphLaunch calls so far (pano_debug_graph_stats)
 
     MaskJob* job = nullptr;
     MaskJob* job_trash = nullptr;  // (unused since the pool: kept for a refresh that failed half way)
@@ -2037,6 +2038,7 @@ pano_status pano_compose(pano_ctx* c, const uint8_t* const* d_frames, const size
             for (int i = 0; i < n && same; i++) same = g.frames[i] == d_frames[i] && g.strides[i] == strides[i];
             if (same) {
                 HIP_TRY(c, hipGraphLaunch(g.exec, s));
+                c->graph_replays++;
                 return PANO_OK;
             }
         }
@@ -2056,6 +2058,7 @@ pano_status pano_compose(pano_ctx* c, const uint8_t* const* d_frames, const size
                 if (c->graphs.size() >= 8) drop_graphs(c);
                 c->graphs.push_back(g);
                 HIP_TRY(c, hipGraphLaunch(g.exec, s));
+                c->graph_replays++;
                 return PANO_OK;
             }
             if (e == hipSuccess && g.graph) (void)hipGraphDestroy(g.graph);
@@ -2069,6 +2072,13 @@ pano_status pano_compose(pano_ctx* c, const uint8_t* const* d_frames, const size
     }
     if ((st = pano_feed_cameras(c, (1u << n) - 1u, d_frames, strides, stream)) != PANO_OK) return st;
     return pano_blend(c, d_out, out_stride, stream);
+}
+
+pano_status pano_debug_graph_stats(const pano_ctx* c, int* graphs_held, uint64_t* replays) {
+    if (!c) return PANO_EINVAL;
+    if (graphs_held) *graphs_held = c->use_graph ? (int)c->graphs.size() : -1;
+    if (replays) *replays = c->graph_replays;
+    return PANO_OK;
 }
 
 pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b, const uint8_t* const* fa, const size_t* sa, uint8_t* oa, size_t osa,

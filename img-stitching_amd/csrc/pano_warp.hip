@@ -547,12 +547,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     if (GAIN) {
         static_assert(sizeof(GainBlk) == 32 && offsetof(WarpCam, gain) == 80 && offsetof(WarpCam, grow_base) == 88 && offsetof(WarpCam, ghrow) == 96 &&
                           offsetof(WarpCam, grow4) == 104 && offsetof(WarpCam, ghrow_pitch) == 112 && offsetof(WarpCam, gh) == 116, "gain block layout");
-        asm volatile("s_load_dwordx8 %0, %2, 0x50\n\ts_load_dwordx2 %1, %2, 0x70" : "=s"(gq.v), "=s"(gq2) : "s"(ka) : "memory");
-        asm volatile("s_load_dwordx2 %0, %1, 0x78" : "=&s"(dcm) : "s"(ka) : "memory");
-        asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hot.v), "+s"(gq.v), "+s"(gq2), "+s"(dcm) : "s"(ka) : "memory");
+        // every batch of scalar loads and its wait are ONE asm statement with early-clobber outputs: between two statements the
+        // compiler may copy a register whose load has not landed yet
+        asm volatile("s_load_dwordx8 %0, %4, 0x50\n\ts_load_dwordx2 %1, %4, 0x70\n\ts_load_dwordx2 %2, %4, 0x78\n\ts_load_dwordx16 %3, %4, 0x0\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(gq.v), "=&s"(gq2), "=&s"(dcm), "=&s"(hot.v) : "s"(ka) : "memory");
     } else {
-        asm volatile("s_load_dwordx2 %0, %1, 0x78" : "=&s"(dcm) : "s"(ka) : "memory");
-        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hot.v), "+s"(dcm) : "s"(ka) : "memory");
+        asm volatile("s_load_dwordx2 %0, %2, 0x78\n\ts_load_dwordx16 %1, %2, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dcm), "=&s"(hot.v) : "s"(ka) : "memory");
     }
     // the camera block as a plain pointer for the rare out-of-line paths (a reference to the by-value kernel argument
     // would make the compiler copy all of WarpParams to scratch)
@@ -578,14 +578,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // the blocks anything downstream reads (4 ints behind the hot part) and this workgroup's source box: two more
     // scalar loads, issued together
     i32x4 live;  // {live_bx1, live_by1, src_w, src_h}
-    asm volatile("s_load_dwordx4 %0, %1, 0x40" : "=s"(live) : "s"(ka) : "memory");
     static_assert(offsetof(WarpCam, live_bx1) == 64 && offsetof(WarpCam, src_h) == 76, "second scalar load layout");
     i32x4 bb;
-    {
-        const char __attribute__((address_space(4)))* bp =
-            (const char __attribute__((address_space(4)))*)hot.h.box + (unsigned)(by * gxc + bx) * 16u;
-        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(bb) : "s"(bp) : "memory");
-    }
+    const char __attribute__((address_space(4)))* const bp =
+        (const char __attribute__((address_space(4)))*)hot.h.box + (unsigned)(by * gxc + bx) * 16u;
     // Wave shape: 16 lanes x 4 rows = a 64 x 4 pixel patch, not a 256-pixel strip.  Where the projection tilts rows
     // (towards the tile edges) a long strip drags in dozens of source rows; compact patches keep the box small.
     // Measured per 4-camera launch (global taps): 256x1 21.7 us, 128x2 19.2, 64x4 19.2, 32x8 21.4, 16x16 36.6.
@@ -606,13 +602,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // (256 B) into LDS with ONE vector load in each of two waves, and every lane reads its row entry and four gains from there.
     const bool gains = GAIN && gq.g.gain != nullptr;
     int gbase = -1;
-    if (gains) {
-        // workgroup-uniform: a scalar load, spelled out (left to the compiler it became a vector load with a wait behind it),
-        // in flight together with the loads of `live` and the source box above
-        const char __attribute__((address_space(4)))* gbp = (const char __attribute__((address_space(4)))*)gq.g.grow_base + (unsigned)by * 4u;
-        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(gbase) : "s"(gbp) : "memory");
+    // `live`, the source box and (GAIN) the patch's first gain row - workgroup-uniform scalar loads, spelled out (left to the compiler
+    // the last became a vector load with a wait behind it) - go out together BEHIND the request of the lane's table entry above, and
+    // are waited for in the same asm statement (early-clobber outputs: nothing can touch the registers before the loads have landed)
+    if (GAIN) {
+        // a camera without gains reads a dword of its own kernarg block instead (dropped below): the statement stays unconditional
+        const char __attribute__((address_space(4)))* const gbp =
+            gains ? (const char __attribute__((address_space(4)))*)gq.g.grow_base + (unsigned)by * 4u : ka;
+        asm volatile("s_load_dwordx4 %0, %3, 0x40\n\ts_load_dwordx4 %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(live), "=&s"(bb), "=&s"(gbase) : "s"(ka), "s"(bp), "s"(gbp) : "memory");
+        if (!gains) gbase = -1;
+    } else {
+        asm volatile("s_load_dwordx4 %0, %2, 0x40\n\ts_load_dwordx4 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(live), "=&s"(bb) : "s"(ka), "s"(bp) : "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bb), "+s"(live), "+s"(gbase) : : "memory");  // bb, live, gbase are only valid past this point
     if (bx > live.x || by > live.y) return;  // beyond this camera's live blocks (workgroup-uniform)
     const int src_w = live.z, src_h = live.w;
     const int bh = bb.z >> 8, cpr = bb.z & 255;

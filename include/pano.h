@@ -324,7 +324,6 @@ pano_status pano_get_warp_bytes(const pano_ctx* ctx, uint64_t* src_bytes, uint64
 pano_status pano_get_warp_table_stats(const pano_ctx* ctx, uint64_t* table_bytes, uint64_t* blocks, uint64_t* blocks_checked);
 
 /* ---- stage inspection (parity tests) ------------------------------------------------------- */
-/* Gaussian level `level` of camera i's bordered tile, int16 x3 interleaved, tight rows */
 /* The bytes of camera i's frame that the warp reads with the present masks: byte columns [rect[0], rect[0] + rect[2]) of rows
  * [rect[1], rect[1] + rect[3]), columns on 64-byte boundaries.  The remap table is static (fixed K / R), so every 64 x 16 patch of
  * the warp taps a fixed box of the frame, and the masks say which patches anything downstream reads: pano_compose_host,
@@ -345,7 +344,12 @@ pano_status pano_get_live_rect(const pano_ctx* ctx, int i, int level, int rect[4
  * groups of four, README.md:27-29; here the ring may be one context).  gap = {first dead column, number of dead columns}
  * of the live rect at `level` ({0, 0}: none): the warp / pyramid kernels step over them. */
 pano_status pano_get_live_gap(const pano_ctx* ctx, int i, int level, int gap[2]);
+/* Gaussian level `level` of camera i's bordered tile, int16 x3 interleaved, tight rows */
 pano_status pano_debug_get_level(pano_ctx* ctx, int i, int level, int16_t* h_dst, int* w, int* h);
+/* hipGraph replay of the frame's launch sequence (environment PANO_GRAPH=1 at pano_prepare; BASELINE config 5 "hipGraph capture"):
+ * *graphs_held = graphs captured and kept (one per set of caller buffers and frame slot; -1: replay is off, or capture was not
+ * available and the library launches directly), *replays = hipGraphLaunch calls so far.  For tests: proof that the graph path ran. */
+pano_status pano_debug_graph_stats(const pano_ctx* ctx, int* graphs_held, uint64_t* replays);
 /* f32 weight level of camera i (pyrDown chain of mask/255 with constant border) */
 pano_status pano_debug_get_weights(pano_ctx* ctx, int i, int level, float* h_dst, int* w, int* h);
 /* canvas: summed weights / collapsed image of a level */

@@ -83,7 +83,8 @@ def build_timed(out_dir=None):
     math: the arithmetic is unchanged), OpenMP.  A second library, so that the checker build (-O2, portable) is untouched; built
     on the host it is timed on (-march=native), into a scratch directory."""
     import tempfile
-    out = os.path.join(out_dir or tempfile.gettempdir(), "libpano_oracle_timed_%d.so" % os.getuid())
+    # a directory of its own, mode 0700, made for this build: nobody else on a shared box can have put a file or a link at the path
+    out = os.path.join(out_dir or tempfile.mkdtemp(prefix="pano_oracle_timed_"), "libpano_oracle_timed.so")
     src = os.path.join(_HERE, "pano_oracle.c")
     subprocess.check_call(["gcc", "-O3", "-march=native", "-std=gnu99", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
                            "-shared", "-o", out, src, "-lm"])

@@ -80,18 +80,7 @@ def rig_r():
     return json.load(open(os.path.join(GOLDEN, "r_cams.json")))
 
 
-def build_fake_rccl():
-    """tests/src/fake_rccl.cpp -> tests/_build/libfake_rccl.so (hipcc, host code only; rebuilt when the source is newer)"""
-    import subprocess
-    src = os.path.join(ROOT, "tests", "src", "fake_rccl.cpp")
-    out_dir = os.path.join(ROOT, "tests", "_build")
-    out = os.path.join(out_dir, "libfake_rccl.so")
-    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-        os.makedirs(out_dir, exist_ok=True)
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        subprocess.check_call([hipcc, "-O1", "-std=c++17", "-shared", "-fPIC", src, "-o", out + ".tmp", "-lrt", "-lpthread"])
-        os.replace(out + ".tmp", out)
-    return out
+from helpers import build_fake_rccl  # noqa: E402  (pytest-free: __graft_entry__.build() uses it too)
 
 
 @pytest.fixture(scope="session")

@@ -1,7 +1,10 @@
 """shared synthetic inputs for the tests and bench.py (no reference files needed at run time)"""
 import math
+import os
 
 import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def synth_frame(w, h, seed):
@@ -46,3 +49,17 @@ def c4_gain_map(gw, gh, seed):
     f = (coarse[y0, x0] * (1 - fy) * (1 - fx) + coarse[y0, x0 + 1] * (1 - fy) * fx
          + coarse[y0 + 1, x0] * fy * (1 - fx) + coarse[y0 + 1, x0 + 1] * fy * fx)
     return (0.8 + 0.45 * f).astype(np.float32)
+
+
+def build_fake_rccl():
+    """tests/src/fake_rccl.cpp -> tests/_build/libfake_rccl.so (hipcc, host code only; rebuilt when the source is newer)"""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "src", "fake_rccl.cpp")
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    out = os.path.join(out_dir, "libfake_rccl.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(out_dir, exist_ok=True)
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.check_call([hipcc, "-O1", "-std=c++17", "-shared", "-fPIC", src, "-o", out + ".tmp", "-lrt", "-lpthread"])
+        os.replace(out + ".tmp", out)
+    return out

@@ -32,5 +32,51 @@ def test_bench_line_in_the_drivers_form():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # algorithmic bytes over the measured mean launch duration
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["avg_launch_us"] / 1e3) < 0.01 * r["achieved"]
-    assert 0.2 < r["frac"] < 0.7 and 0.2 < r["cold"]["frac"] <= r["frac"] + 0.02
+    # the headline fraction is the COLD one (rotating frame sets); the warm figure rides along
+    assert 0.2 < r["frac"] < 0.7 and r["cold"]["frac"] == r["frac"] and r["frac"] <= r["warm"]["frac"] + 0.02 and "rotating" in r["measured"]
     assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
+    assert "resident in HBM" in d["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_bench_line_host_link_roofline():
+    """the PCIe-inclusive path (SURVEY 8(d)(i)) carries a roofline of its own: rates up and down against a page-locked copy
+    ceiling measured in the same run (VERDICT r03 #6)"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-c4",
+                        "--no-isolated-pass"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    h = d["h2d_inclusive"]
+    assert "error" not in h, h
+    assert h["panoramas_per_s"] == d["h2d_inclusive_panoramas_per_s"] > 60.0        # the north star's target, link included
+    assert abs(h["up_GBps"] - h["panoramas_per_s"] * h["up_bytes_per_step"] / 1e9) < 0.02 * h["up_GBps"]
+    assert 0 < h["up_bytes_per_step"] <= 8 * 1920 * 1080 * 3 and h["down_bytes_per_step"] == 2 * 3893 * 991 * 3
+    c = h["pinned_copy_ceiling_GBps"]
+    assert c["up"] > 1.0 and c["down"] > 1.0 and 0.05 < h["frac"] < 1.1, h
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_through_the_rccl_double():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on the box's ONE GPU:
+    gloo carries the votes and reductions, the data-path exchange is the C-ABI's pano_gather_slots between the two real peers
+    through the RCCL test double (PANO_RCCL_LIB; RCCL itself refuses two ranks on one device).  What tools/bench_rehearsal.sh
+    did by hand (VERDICT r03 #7b): exit 0, the contract keys, a communicator of 2 ranks, the exchange kind `cabi` - and bench.py
+    itself has compared the sharded panorama with rank 0's whole-rig one before it timed anything (it exits 3 otherwise)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import build_fake_rccl
+    env = dict(os.environ, PANO_BENCH_BACKEND="gloo", PANO_RCCL_LIB=build_fake_rccl(), FAKE_RCCL_TIMEOUT_S="120")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:] + p.stdout[-1000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "multi_gpu"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0 and d["scaling"] == "strong"
+    mg = d["multi_gpu"]
+    assert mg["exchange"] == "cabi" and mg["rccl_ranks"] == 2 and "fake_rccl" in mg["rccl_library"], mg
+    assert "pano_gather_slots" in d["config"]["parallelism"]
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-3

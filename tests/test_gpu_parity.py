@@ -221,6 +221,44 @@ def test_exposure_gain_apply(pano, po, c1):
     ctx.set_gain_map(0, None)
 
 
+def test_exposure_gain_apply_fine_maps(pano, po, c1):
+    """K1's gain path has two branches (pano_warp.hip): the patch's gain rows staged in LDS (a 16-row patch reads at most
+    kGainRows = 4 rows of the horizontally resized map), and a per-lane fallback from global memory for maps finer than that
+    (grow_base == -1).  Block maps of 32-pixel blocks only ever take the first.  Here: maps of th / 3 rows (every patch takes the
+    fallback), th / 6 rows (patches of both kinds in one camera, by where the rows fall) and the usual th / 32, one camera each,
+    plus a camera without a map - against the oracle's apply on the same maps"""
+    rng = np.random.default_rng(11)
+    masks = oracle_masks(po, c1)
+    ctx = make_ctx(pano, c1, 0, num_bands=2)
+    full = []
+    for i, div in enumerate((3, 6, 32, None)):
+        r = ctx.roi(i)
+        ctx.set_mask(i, masks[i])
+        if div is None:
+            full.append(np.ones((r[3], r[2]), np.float32))   # the oracle wants a map per camera: x 1.0f is the identity
+            continue
+        g = (0.8 + 0.45 * rng.random(((r[3] + div - 1) // div, (r[2] + div - 1) // div))).astype(np.float32)
+        full.append(po.resize_linear_32f(g, r[2], r[3]))
+        ctx.set_gain_map(i, g)
+    want, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 2, gain_maps=full)
+    assert np.array_equal(ctx.compose_host(c1["frames"]), want)
+    # the same through the device entry of both stitchers at once (pano_compose_pair: the gain instantiation with 8 cameras)
+    ctx2 = make_ctx(pano, c1, 0, num_bands=2)
+    for i in range(4):
+        ctx2.set_mask(i, masks[i])
+    import torch
+    d = [torch.from_numpy(f).cuda() for f in c1["frames"]]
+    ow, oh = ctx.output_size()
+    o = [torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    st = torch.cuda.current_stream().cuda_stream
+    ptr = [t.data_ptr() for t in d]
+    ctx.compose_pair(ctx2, ptr, [480 * 3] * 4, o[0].data_ptr(), ow * 3, ptr, [480 * 3] * 4, o[1].data_ptr(), ow * 3, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(o[0].cpu().numpy(), want)
+    want2, _ = po.compose(c1["frames"], c1["K"], c1["R"], c1["scale"], masks, 2)
+    assert np.array_equal(o[1].cpu().numpy(), want2)
+
+
 def test_device_entry_and_sharded_feed(pano, po, torch, c1):
     """pano_compose on device pointers == pano_feed_cameras in two shards + pano_blend (the multi-GPU split)"""
     masks = oracle_masks(po, c1)

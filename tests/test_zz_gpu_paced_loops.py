@@ -85,3 +85,25 @@ def test_replay_paced_loop_with_mask_refresh_beside_it(pano, rig_r, tmp_path_fac
     _report("replay_cpp_120_ticks_refresh_every_30", {"composed": int(m.group(1)), "dropped": int(m.group(2)), "achieved_fps": float(m.group(3))})
     if STRICT:
         assert int(m.group(2)) <= 2, r.stdout
+
+
+def test_config5_as_baseline_states_it(pano, po):
+    """BASELINE.json configs[4] in its stated combination, in ONE run (VERDICT r03 #7a): 8 x RAW 1920x1080 frames offered at 60 fps
+    through pano_stream_* (page-locked double-buffered slots: H2D || compose || D2H), the undistort -> crop -> resize front end of
+    include/nvcam.hpp:898-921 fused into the warp (pano_set_undistort), the frame's launch sequence replayed as a hipGraph
+    (PANO_GRAPH=1), 120 ticks.  Hard: the sampled panoramas equal the oracle's of the fused map, every tick is accounted for, and the
+    graph path really ran (graphs held, one replay per composed frame).  A process of its own: PANO_GRAPH is read at pano_prepare."""
+    import sys
+    env = dict(os.environ, PANO_GRAPH="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stream_60fps.py"), "--frames", "120", "--raw", "--check"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    _report("config5_raw_undistort_hipgraph_120_ticks", r)
+    assert "fused undistort front end" in r["config"] and "hipGraph replay" in r["config"], r["config"]
+    assert r["frames_composed"] + r["dropped"] == 120, r
+    assert r["sampled_frames_equal_oracle"] is True and r["sampled_frames"] == [0, 60, 119], r
+    for g in r["hipgraph"]:     # two page-locked slots -> two buffer sets -> two graphs per stitcher; every frame after the captures is a replay
+        assert g["graphs_held"] == 2 and g["replays"] >= r["frames_composed"], r["hipgraph"]
+    if STRICT:
+        assert r["dropped"] == 0 and r["achieved_fps"] > 58.0, r

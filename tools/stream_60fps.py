@@ -24,11 +24,21 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# the lens of cfg/cameras.yaml sensing/imx390/fov120 (K, distorParams and rect of its 960 x 540 entry), scaled to an undistorted size
+def imx390_front(raw_wh, undist_wh):
+    k = undist_wh[0] / 960.0
+    K = [4.890925118101495e+02 * k, 0, 4.940763211103715e+02 * k, 0, 4.912630345468579e+02 * k, 2.865820139005963e+02 * k, 0, 0, 1]
+    return {"raw": tuple(raw_wh), "undist": tuple(undist_wh), "K": K, "dist": [-0.2838, 0.0628, 0, 0],
+            "rect": tuple(int(round(v * k)) for v in (70, 66, 885, 410))}
+
+
 def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=False, device=0, pipeline=None, refresh_every=0,
-        refresh_async=True):
+        refresh_async=True, front=None):
     """refresh_every: N > 0 refreshes the graph-cut masks of both stitchers every N ticks like ocvStitcher::process (every 200
     frames, ocvstitcher.hpp:1152-1159) - inline (refresh_async False: pano_build_masks_graphcut inside the tick, as the reference
     does) or beside the loop (pano_refresh_masks_begin / _poll).
+    front: None, or imx390_front(raw size, undistorted size): the frames offered are RAW camera frames and the undistort -> crop ->
+    resize front end of include/nvcam.hpp:898-921 runs fused inside the warp (pano_set_undistort) - BASELINE config 5 as stated.
     pipeline: True = wait for tick k's panorama after submitting tick k + 1 (two in flight, what throughput needs), False = wait
     right after the submit (lowest latency); None = False when a period leaves room for it (fps <= 100)"""
     if pipeline is None:
@@ -42,11 +52,14 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
         ctx = pano.Context(NC, width, height, scale=g["scale"], num_bands=bands, device=device)
         for i in range(NC):
             ctx.set_camera(i, g["K"][i], g["R"][i])
+            if front:
+                ctx.set_undistort(i, front["raw"], front["undist"], front["K"], front["dist"], front["rect"])
         ctx.prepare()
         ctx.build_masks_voronoi()
         ctxs.append(ctx)
     # rotating frame sets in ordinary (pageable) host memory: what a capture queue hands over
-    sets = [[[synth_frame(width, height, 1000 + 100 * s + grp * NC + i) for i in range(NC)] for grp in range(NG)] for s in range(nsets)]
+    fw, fh = front["raw"] if front else (width, height)
+    sets = [[[synth_frame(fw, fh, 1000 + 100 * s + grp * NC + i) for i in range(NC)] for grp in range(NG)] for s in range(nsets)]
     ins = [[[ctxs[grp].stream_input(s, i) for i in range(NC)] for grp in range(NG)] for s in range(2)]
     period = 1.0 / fps
     tick_t, done_t = {}, {}
@@ -121,12 +134,15 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
             ctxs[grp].refresh_masks_wait()
     lat = np.array([done_t[k] - tick_t[k] for k in sorted(done_t)]) * 1e3
     out = {"config": "C5: %d x %dx%d -> 2 panoramas, %d bands, paced at %.1f fps, %d frames, pano_stream_* (2 slots)%s" %
-                     (NG * NC, width, height, bands, fps, frames, ", hipGraph replay" if os.environ.get("PANO_GRAPH") == "1" else ""),
+                     (NG * NC, fw, fh, bands, fps, frames, (", hipGraph replay" if os.environ.get("PANO_GRAPH") == "1" else "") +
+                      (", fused undistort front end (raw %dx%d -> undistorted %dx%d -> rect %s -> %dx%d)" % (fw, fh, front["undist"][0], front["undist"][1],
+                                                                                                       list(front["rect"]), width, height) if front else "")),
            "target_fps": fps, "frames_offered": frames, "frames_composed": int(len(lat)), "dropped": int(dropped),
            "achieved_fps": round(len(lat) / (t_end - t0), 2),
            "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 3), "p99": round(float(np.percentile(lat, 99)), 3),
                           "max": round(float(lat.max()), 3)},
            "pipelined": bool(pipeline),
+           "hipgraph": [dict(zip(("graphs_held", "replays"), c.graph_stats())) for c in ctxs],
            "mask_refresh": None if not refresh_every else {"every_ticks": refresh_every, "how": "beside the loop (pano_refresh_masks_*)" if refresh_async else
                                                             "inline (pano_build_masks_graphcut inside the tick, as ocvStitcher::process does)",
                                                             "masks_installed": refreshed[0]},
@@ -137,9 +153,10 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
         import pano_oracle as po
         po.set_threads(min(16, os.cpu_count() or 1))
         ok = True
+        fe = [po.front_end(front["raw"], front["undist"], front["K"], front["dist"], front["rect"], (width, height)) for _ in range(NC)] if front else None
         for k, got in sample.items():
             for grp in range(NG):
-                want, _ = po.compose(sets[k % nsets][grp], g["K"], g["R"], g["scale"], sample_masks[k][grp], bands)
+                want, _ = po.compose(sets[k % nsets][grp], g["K"], g["R"], g["scale"], sample_masks[k][grp], bands, front=fe)
                 ok &= bool(np.array_equal(got[grp], want))
         po.set_threads(1)
         out["sampled_frames_equal_oracle"] = ok
@@ -158,10 +175,13 @@ def main():
     ap.add_argument("--refresh-every", type=int, default=0, help="refresh the graph-cut masks every N ticks (the reference: 200)")
     ap.add_argument("--refresh-inline", action="store_true", help="... inside the tick like the reference, instead of beside the loop")
     ap.add_argument("--pipeline", type=int, default=-1, help="1: two panoramas in flight, 0: wait after every submit, -1: by fps")
+    ap.add_argument("--raw", action="store_true", help="offer RAW frames of --width x --height: the imx390 lens front end (undistort, crop, "
+                                                        "resize) runs fused in the warp - BASELINE config 5 as stated (with PANO_GRAPH=1)")
     a = ap.parse_args()
     print(json.dumps(run(a.fps, a.frames, a.width, a.height, a.bands, check=a.check,
                          pipeline=None if a.pipeline < 0 else bool(a.pipeline), refresh_every=a.refresh_every,
-                         refresh_async=not a.refresh_inline)), flush=True)
+                         refresh_async=not a.refresh_inline,
+                         front=imx390_front((a.width, a.height), (a.width, a.height)) if a.raw else None)), flush=True)
 
 
 if __name__ == "__main__":
