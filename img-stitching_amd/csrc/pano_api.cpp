@@ -178,6 +178,7 @@ struct pano_ctx {
     std::vector<GraphEntry> graphs;
     bool use_graph = false;
     uint64_t graph_replays = 0;   // hipGraphLaunch calls so far (pano_debug_graph_stats)
+    std::string gc_dump_path;     // pano_debug_graphcut_dump
 
     MaskJob* job = nullptr;
     MaskJob* job_trash = nullptr;  // (unused since the pool: kept for a refresh that failed half way)
@@ -1611,7 +1612,9 @@ static pano_status build_masks_voronoi_impl(pano_ctx* c) {
 // GraphCutSeamFinder over the seam-scale warps `sm` (PairwiseSeamFinder::run order; GraphCutSeamFinder::Impl::findInPair per
 // overlapping pair: weights on the GPU, the max-flow on the host - pano_graphcut.hpp -, the mask update on the GPU; a later pair
 // sees the masks the earlier left).  Touches nothing of a context: it also runs on the refresh thread (pano_refresh_masks_begin)
-static pano_status graphcut_pairs(int n, SeamWarps& sm, Scratch& tmp, hipStream_t s, std::string& err) {
+// dump (optional, pano_debug_graphcut_dump): every pair's graph AS THE GPU BUILT IT and the labels the host max-flow gave it are
+// appended - int32 {i, j, W, H}, then W*H f32 term, wh, wv and W*H label bytes (1 = source side)
+static pano_status graphcut_pairs(int n, SeamWarps& sm, Scratch& tmp, hipStream_t s, std::string& err, FILE* dump = nullptr) {
 #define GC_TRY(expr)                                                              \
     do {                                                                          \
         hipError_t e_ = (expr);                                                   \
@@ -1653,6 +1656,14 @@ static pano_status graphcut_pairs(int n, SeamWarps& sm, Scratch& tmp, hipStream_
             GridMaxFlow flow(q.W, q.H, term.data(), wh.data(), wv.data());
             flow.run();
             for (size_t k = 0; k < nv; k++) in_source[k] = flow.inSource((int)k) ? 1 : 0;
+            if (dump) {
+                const int hdr[4] = {i, j, q.W, q.H};
+                fwrite(hdr, sizeof(int), 4, dump);
+                fwrite(term.data(), sizeof(float), nv, dump);
+                fwrite(wh.data(), sizeof(float), nv, dump);
+                fwrite(wv.data(), sizeof(float), nv, dump);
+                fwrite(in_source.data(), 1, nv, dump);
+            }
             GC_TRY(hipMemcpyAsync(d_lab, in_source.data(), nv, hipMemcpyHostToDevice, s));
             launch_graphcut_apply(q, sm.mask[i], sm.mask[j], d_lab, gap, s);
             GC_TRY(hipStreamSynchronize(s));  // in_source is reused by the next pair
@@ -1781,7 +1792,10 @@ static pano_status build_masks_graphcut_impl(pano_ctx* c, const uint8_t* const* 
     {
         Scratch pairs;
         pairs.pool = &c->pairs_pool;  // no refresh thread is running (waited for above)
-        if ((st = graphcut_pairs(n, sm, pairs, s, err)) != PANO_OK) return fail(c, st, err.c_str());
+        FILE* dump = c->gc_dump_path.empty() ? nullptr : fopen(c->gc_dump_path.c_str(), "ab");
+        st = graphcut_pairs(n, sm, pairs, s, err, dump);
+        if (dump) fclose(dump);
+        if (st != PANO_OK) return fail(c, st, err.c_str());
     }
     return finish_seam_masks(c, sm, tmp, s);
 }
@@ -2072,6 +2086,12 @@ pano_status pano_compose(pano_ctx* c, const uint8_t* const* d_frames, const size
     }
     if ((st = pano_feed_cameras(c, (1u << n) - 1u, d_frames, strides, stream)) != PANO_OK) return st;
     return pano_blend(c, d_out, out_stride, stream);
+}
+
+pano_status pano_debug_graphcut_dump(pano_ctx* c, const char* path) {
+    if (!c) return PANO_EINVAL;
+    c->gc_dump_path = path ? path : "";
+    return PANO_OK;
 }
 
 pano_status pano_debug_graph_stats(const pano_ctx* c, int* graphs_held, uint64_t* replays) {

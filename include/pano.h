@@ -346,6 +346,12 @@ pano_status pano_get_live_rect(const pano_ctx* ctx, int i, int level, int rect[4
 pano_status pano_get_live_gap(const pano_ctx* ctx, int i, int level, int gap[2]);
 /* Gaussian level `level` of camera i's bordered tile, int16 x3 interleaved, tight rows */
 pano_status pano_debug_get_level(pano_ctx* ctx, int i, int level, int16_t* h_dst, int* w, int* h);
+/* For tests of the graph-cut seam finder: with a path set (nullptr / "" clears it), every later pano_build_masks_graphcut appends,
+ * per overlapping pair in PairwiseSeamFinder::run order, the grid graph of GraphCutSeamFinder::Impl::findInPair exactly as the GPU
+ * built it and the labels the max-flow gave it: int32 {i, j, W, H}, W*H f32 term (source - sink weight), wh (k <-> k + 1), wv
+ * (k <-> k + W), W*H label bytes (1: source side = image i).  tests/test_gpu_parity.py checks on these graphs that the labelling is a
+ * MINIMUM cut (its capacity equals an independent max-flow's value). */
+pano_status pano_debug_graphcut_dump(pano_ctx* ctx, const char* path);
 /* hipGraph replay of the frame's launch sequence (environment PANO_GRAPH=1 at pano_prepare; BASELINE config 5 "hipGraph capture"):
  * *graphs_held = graphs captured and kept (one per set of caller buffers and frame slot; -1: replay is off, or capture was not
  * available and the library launches directly), *replays = hipGraphLaunch calls so far.  For tests: proof that the graph path ran. */

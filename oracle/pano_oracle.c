@@ -13,6 +13,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -1077,6 +1078,30 @@ static void graphcut_in_pair(const float* img1, const float* img2, const int* tl
             }
         }
     gc_max_flow(&g);
+    if (getenv("PO_GC_DUMP")) {
+        /* test hook: the pair's graph and labels in the product's pano_debug_graphcut_dump record format (i, j unknown here: -1) */
+        FILE* df = fopen(getenv("PO_GC_DUMP"), "ab");
+        if (df) {
+            const int hdr[4] = {-1, -1, W, H};
+            fwrite(hdr, sizeof(int), 4, df);
+            for (int pass = 0; pass < 3; pass++)
+                for (int k = 0; k < W * H; k++) {
+                    float v = 0.f;
+                    const int x = k % W, y = k / W;
+                    if (pass == 0) v = (m1[k] ? terminal_cost : 0.f) - (m2[k] ? terminal_cost : 0.f);
+                    else {
+                        const int u = pass == 1 ? k + 1 : k + W;
+                        if ((pass == 1 && x < W - 1) || (pass == 2 && y < H - 1)) {
+                            v = gc_norm2(s1 + 3 * k, s2 + 3 * k) + gc_norm2(s1 + 3 * u, s2 + 3 * u) + weight_eps;
+                            if (!m1[k] || !m1[u] || !m2[k] || !m2[u]) v += bad_region_penalty;
+                        }
+                    }
+                    fwrite(&v, sizeof(float), 1, df);
+                }
+            for (int k = 0; k < W * H; k++) { const uint8_t l = g.v[k].t == 0; fwrite(&l, 1, 1, df); }
+            fclose(df);
+        }
+    }
     for (int y = 0; y < roi[3]; ++y)
         for (int x = 0; x < roi[2]; ++x) {
             const size_t k1 = (size_t)(roi[1] - tl1[1] + y) * sz1[0] + (roi[0] - tl1[0] + x);

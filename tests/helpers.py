@@ -63,3 +63,55 @@ def build_fake_rccl():
         subprocess.check_call([hipcc, "-O1", "-std=c++17", "-shared", "-fPIC", src, "-o", out + ".tmp", "-lrt", "-lpthread"])
         os.replace(out + ".tmp", out)
     return out
+
+
+def read_graphcut_dump(path):
+    """pano_debug_graphcut_dump's records: (i, j, term, wh, wv, labels) with (H, W) arrays"""
+    raw = open(path, "rb").read()
+    out, o = [], 0
+    while o < len(raw):
+        i, j, W, H = np.frombuffer(raw, np.int32, 4, o); o += 16
+        n = int(W) * int(H)
+        f = np.frombuffer(raw, np.float32, 3 * n, o).reshape(3, H, W); o += 12 * n
+        lab = np.frombuffer(raw, np.uint8, n, o).reshape(H, W); o += n
+        out.append((int(i), int(j), f[0], f[1], f[2], lab))
+    return out
+
+
+def min_cut_capacity(term, wh, wv, lab):
+    """capacity of the cut (source side = lab == 1) of the grid graph of GraphCutSeamFinder::Impl::findInPair: terminal edges of
+    weight |term| (to the source where term > 0, to the sink where term < 0), wh between (y, x) and (y, x + 1), wv between (y, x)
+    and (y + 1, x).  All weights are integers carried in f32"""
+    t, s_ = term.astype(np.int64), lab.astype(bool)
+    cut = int((-t[s_ & (t < 0)]).sum() + t[~s_ & (t > 0)].sum())
+    cut += int(wh.astype(np.int64)[:, :-1][s_[:, :-1] != s_[:, 1:]].sum())
+    cut += int(wv.astype(np.int64)[:-1, :][s_[:-1, :] != s_[1:, :]].sum())
+    return cut
+
+
+def scipy_max_flow(term, wh, wv, sides=False):
+    """max-flow value of the grid graph; sides=True: also the (H, W) masks of the vertices the source reaches / that reach the sink
+    in the residual graph"""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import breadth_first_order, maximum_flow
+    H, W = term.shape
+    n = H * W
+    idx = np.arange(n).reshape(H, W)
+    t = term.astype(np.int64).reshape(-1)
+    rows = [np.full(int((t > 0).sum()), n), idx.reshape(-1)[t < 0]]
+    cols = [idx.reshape(-1)[t > 0], np.full(int((t < 0).sum()), n + 1)]
+    caps = [t[t > 0], -t[t < 0]]
+    a, b, c = idx[:, :-1].reshape(-1), idx[:, 1:].reshape(-1), wh.astype(np.int64)[:, :-1].reshape(-1)
+    rows += [a, b]; cols += [b, a]; caps += [c, c]
+    a, b, c = idx[:-1, :].reshape(-1), idx[1:, :].reshape(-1), wv.astype(np.int64)[:-1, :].reshape(-1)
+    rows += [a, b]; cols += [b, a]; caps += [c, c]
+    g = csr_matrix((np.concatenate(caps).astype(np.int32), (np.concatenate(rows), np.concatenate(cols))), shape=(n + 2, n + 2))
+    r = maximum_flow(g, n, n + 1)
+    if not sides:
+        return int(r.flow_value)
+    resid = (g - r.flow).tocsr()
+    resid.data = np.maximum(resid.data, 0)
+    resid.eliminate_zeros()
+    src = np.zeros(n + 2, bool); src[breadth_first_order(resid, n, return_predecessors=False)] = True
+    snk = np.zeros(n + 2, bool); snk[breadth_first_order(resid.T.tocsr(), n + 1, return_predecessors=False)] = True
+    return int(r.flow_value), src[:n].reshape(H, W), snk[:n].reshape(H, W)

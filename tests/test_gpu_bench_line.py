@@ -56,17 +56,20 @@ def test_bench_line_host_link_roofline():
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_rehearsal_through_the_rccl_double():
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on the box's ONE GPU:
-    gloo carries the votes and reductions, the data-path exchange is the C-ABI's pano_gather_slots between the two real peers
-    through the RCCL test double (PANO_RCCL_LIB; RCCL itself refuses two ranks on one device).  What tools/bench_rehearsal.sh
-    did by hand (VERDICT r03 #7b): exit 0, the contract keys, a communicator of 2 ranks, the exchange kind `cabi` - and bench.py
-    itself has compared the sharded panorama with rank 0's whole-rig one before it timed anything (it exits 3 otherwise)"""
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_n_ranks_rehearsal_through_the_rccl_double(world):
+    """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on the box's ONE GPU:
+    gloo carries the votes and reductions, the communicator and the data-path exchange are the C-ABI's (pano_rccl_comm_create,
+    pano_gather_slots) between real peers through the RCCL test double (PANO_RCCL_LIB; RCCL itself refuses two ranks on one
+    device).  What tools/bench_rehearsal.sh did by hand (VERDICT r03 #7b): exit 0, the contract keys, a communicator of N ranks.
+    N = 2: each rank owns a whole stitcher, so no pyramid slot moves (the finished half panorama does); N = 4: two cameras per
+    rank, the slots of ranks 1 and 3 land on ranks 0 and 2 through pano_gather_slots - exchange kind `cabi`.  bench.py itself has
+    compared the sharded panorama with rank 0's whole-rig one before it timed anything (it exits 3 otherwise)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import build_fake_rccl
     env = dict(os.environ, PANO_BENCH_BACKEND="gloo", PANO_RCCL_LIB=build_fake_rccl(), FAKE_RCCL_TIMEOUT_S="120")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(29630 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "20", "--warmup", "5"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:] + p.stdout[-1000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
@@ -75,8 +78,11 @@ def test_bench_two_ranks_rehearsal_through_the_rccl_double():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "multi_gpu"):
         assert k in d, k
-    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["n_gpus"] == world and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0 and d["scaling"] == "strong"
     mg = d["multi_gpu"]
-    assert mg["exchange"] == "cabi" and mg["rccl_ranks"] == 2 and "fake_rccl" in mg["rccl_library"], mg
-    assert "pano_gather_slots" in d["config"]["parallelism"]
+    assert mg["rccl_ranks"] == world and "fake_rccl" in mg["rccl_library"], mg
+    if world == 2:
+        assert mg["exchange"].startswith("none") and "whole stitchers" in d["config"]["parallelism"], mg
+    else:
+        assert mg["exchange"] == "cabi" and "pano_gather_slots" in d["config"]["parallelism"], (mg, d["config"])
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-3

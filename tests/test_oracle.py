@@ -2,6 +2,8 @@
 restatement, against the ROI integers pinned in SURVEY.md Appendix C, and against hand-computed
 known answers of the pyramid / resize / distance primitives.  PARITY UNPINNED: the reference holds no
 expected outputs, so these are the only pins that exist."""
+import os
+
 import numpy as np
 import pytest
 
@@ -450,6 +452,33 @@ def test_graphcut_max_flow_vs_scipy(po):
         assert flow == r.flow_value, trial
         lab = lab.reshape(-1)
         assert (lab[src[:n]] == 1).all() and (lab[snk[:n]] == 0).all(), trial
+
+
+def test_graphcut_on_real_overlaps_vs_scipy(po, c1, tmp_path, monkeypatch):
+    """the restated GraphCutSeamFinder on the config-1 frames, pair by pair (PO_GC_DUMP: the graph of findInPair and the labels of
+    GCGraph::maxFlow): against SciPy's max-flow on the same graph the labelling holds what every minimum cut holds (source-reachable
+    vertices labelled source, sink-reaching ones sink) and IS a minimum cut (capacity == flow value).  On flat frames - every edge
+    the same cost - OpenCV's labelling need not be one: vertices in neither search tree keep a stale label (inSourceSegment reads
+    t == 0); shown on the same rig with constant frames, where the capacity exceeds the flow for at least one pair"""
+    from helpers import c2_group, min_cut_capacity, read_graphcut_dump, scipy_max_flow
+    path = str(tmp_path / "g.bin")
+    monkeypatch.setenv("PO_GC_DUMP", path)
+    po.prepare_masks_graphcut(c1["frames"], c1["K"], c1["R"], c1["scale"])
+    pairs = read_graphcut_dump(path)
+    assert len(pairs) == 3
+    for (_, _, term, wh, wv, lab) in pairs:
+        flow, src, snk = scipy_max_flow(term, wh, wv, sides=True)
+        assert (lab[src] == 1).all() and (lab[snk] == 0).all()
+        assert min_cut_capacity(term, wh, wv, lab) == flow
+    os.remove(path)
+    d = c2_group(w=640, h=360, f=334.0)
+    po.prepare_masks_graphcut([np.full((360, 640, 3), 90 + 20 * i, np.uint8) for i in range(4)], d["K"], d["R"], d["scale"])
+    excess = []
+    for (_, _, term, wh, wv, lab) in read_graphcut_dump(path):
+        flow, src, snk = scipy_max_flow(term, wh, wv, sides=True)
+        assert (lab[src] == 1).all() and (lab[snk] == 0).all()
+        excess.append(min_cut_capacity(term, wh, wv, lab) - flow)
+    assert min(excess) >= 0 and max(excess) > 0, excess
 
 
 def test_graphcut_find_properties(po, c1):
