@@ -141,12 +141,15 @@ def main():
     # stream k % F and the chains of consecutive frames overlap - what a capture loop feeding frames back to back does.
     F = max(1, min(args.frames_in_flight, pano.MAX_FRAME_SLOTS)) if world == 1 and not args.force_sharded_path else 1
     flight = [stream]
+    flight_distinct = 1
     outs_f = [outs]
     if F > 1:
         for c in ctxs:
             c.set_frame_slots(F)
-        flight_streams = [torch.cuda.Stream() for _ in range(F)]
-        flight = [st.cuda_stream for st in flight_streams]
+        # the library's own flight streams, probed to sit on DISTINCT hardware queues: the HIP runtime multiplexes a process's
+        # streams onto GPU_MAX_HW_QUEUES (default 4) queues in creation order, and two flight streams on one queue run their
+        # frames one after the other (-15 %: docs/EXPERIMENTS.md, round 4) - torch.cuda.Stream()s land where luck puts them
+        flight, flight_distinct = ctxs[0].frame_streams(F)
         outs_f = [outs] + [[torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in range(NG)] for _ in range(F - 1)]
 
     def step_single(k=0, slots=None):
@@ -563,7 +566,7 @@ def main():
             "config": {"workload": "C2: 8x1920x1080 BGR8 frames resident in HBM (device pointers in, device panoramas out: no PCIe in the "
                                    "timed region; the link-inclusive rate is `h2d_inclusive`) -> 2 groups x 4 cameras, spherical warp + %d-band "
                                    "multi-band blend, Voronoi seams, pano 2 x %dx%d" % (args.bands, ow, oh),
-                       "parallelism": ("single GPU, %d frames in flight" % F) if world == 1 else
+                       "parallelism": ("single GPU, %d frames in flight on %d distinct hardware queues (pano_frame_streams)" % (F, flight_distinct)) if world == 1 else
                                       ("cameras sharded %d/rank, %s" % (per_rank,
                                                                           "every rank composes whole stitchers; the finished half panoramas move to rank 0 (torch.distributed send / recv)"
                                                                           if not any(pl["moves"] for pl in plans) else

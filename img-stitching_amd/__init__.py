@@ -84,7 +84,7 @@ def load_library():
 MAX_FRAME_SLOTS = 4  # PANO_MAX_FRAME_SLOTS
 
 EXPORTS = [
-    "pano_create", "pano_destroy", "pano_last_error", "pano_version", "pano_set_camera", "pano_verify_cameras", "pano_debug_graph_stats", "pano_debug_graphcut_dump",
+    "pano_create", "pano_destroy", "pano_last_error", "pano_version", "pano_set_camera", "pano_verify_cameras", "pano_debug_graph_stats", "pano_debug_graphcut_dump", "pano_frame_streams",
     "pano_set_cameras_from_list", "pano_load_camera_file", "pano_get_camera", "pano_save_camera_file", "pano_prepare", "pano_get_roi", "pano_get_pano_rect",
     "pano_get_num_bands", "pano_get_feed_tile", "pano_set_cut", "pano_get_output_size", "pano_set_mask",
     "pano_build_masks_voronoi", "pano_build_masks_graphcut", "pano_refresh_masks_begin", "pano_refresh_masks_poll", "pano_refresh_masks_wait", "pano_get_mask", "pano_set_gain_map", "pano_estimate_gains", "pano_get_gain_map", "pano_set_undistort", "pano_get_new_camera_matrix", "pano_warp", "pano_warp_mask", "pano_compose",
@@ -342,6 +342,13 @@ class Context:
         self._ck(self.lib.pano_warp_mask(self.h, i, _vp(d_dst), C.c_size_t(dst_stride), _vp(stream)))
 
     # -- streaming slots: numpy views of the library's pinned buffers
+    def frame_streams(self, n):
+        """(n hipStream_t handles as ints - probed to run side by side -, how many sit on a hardware queue of their own)"""
+        arr = (C.c_void_p * n)(); d = C.c_int()
+        self.lib.pano_frame_streams.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self._ck(self.lib.pano_frame_streams(self.h, n, arr, C.addressof(d)))
+        return [int(arr[i]) for i in range(n)], d.value
+
     def graphcut_dump(self, path):
         self.lib.pano_debug_graphcut_dump.argtypes = [C.c_void_p, C.c_char_p]
         self._ck(self.lib.pano_debug_graphcut_dump(self.h, os.fsencode(path) if path else None))

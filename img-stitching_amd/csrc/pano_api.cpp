@@ -127,6 +127,8 @@ struct pano_ctx {
     uint8_t* stage_out = nullptr;
     size_t stage_out_pitch = 0, stage_out_bytes = 0;
     hipStream_t own_stream = nullptr;
+    std::vector<hipStream_t> flight_streams;  // pano_frame_streams: owned here
+    int flight_distinct = 0;
     // ... and its page-locked host side (pageable caller memory is copied through these by the pool's threads)
     uint8_t* pin_in[kMaxCams] = {};
     size_t pin_in_pitch = 0;
@@ -306,6 +308,8 @@ void free_device(pano_ctx* c) {
     c->ev_valid = false;
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     c->own_stream = nullptr;
+    for (hipStream_t fs : c->flight_streams) (void)hipStreamDestroy(fs);
+    c->flight_streams.clear();
 }
 
 // WarpCam for the bordered feed() tile of camera i (pipeline) or its plain ROI (stage entries)
@@ -2950,6 +2954,61 @@ pano_status pano_prepare(pano_ctx* c) {
 
 pano_status pano_set_frame_slots(pano_ctx* c, int n) {
     return guarded(c, [&]() { return set_frame_slots_impl(c, n); });
+}
+
+// Streams for frames in flight that really run side by side.  The HIP runtime multiplexes a process's streams onto a few hardware
+// queues (GPU_MAX_HW_QUEUES, default 4), by an order the caller does not control; two flight streams on one queue run their frames
+// one after the other (15 % fewer panoramas/s on config 2, docs/EXPERIMENTS.md).  So: candidates are created one by one and PROBED
+// against the streams already taken - a 150 us one-wave spin on each of the pair; on a shared queue the two take 300 us - and kept
+// when they overlap with all of them.  Rejected candidates stay alive until the search is over (the runtime gives a new stream the
+// least-used queue: destroying a reject would hand its queue to the next candidate again).
+static pano_status frame_streams_impl(pano_ctx* c, int n, void** streams, int* distinct) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if (n < 1 || n > PANO_MAX_FRAME_SLOTS || !streams) return PANO_EINVAL;
+    if ((int)c->flight_streams.size() < n) {
+        HIP_TRY(c, hipDeviceSynchronize());
+        for (hipStream_t fs : c->flight_streams) (void)hipStreamDestroy(fs);
+        c->flight_streams.clear();
+        constexpr double kSpinUs = 150.0;
+        auto pair_us = [&](hipStream_t a, hipStream_t b) {
+            double best = 1e30;
+            for (int rep = 0; rep < 2; rep++) {
+                (void)hipStreamSynchronize(a);
+                (void)hipStreamSynchronize(b);
+                const auto t0 = std::chrono::steady_clock::now();
+                launch_spin((unsigned long long)(kSpinUs * 100.0), a);
+                launch_spin((unsigned long long)(kSpinUs * 100.0), b);
+                (void)hipStreamSynchronize(a);
+                (void)hipStreamSynchronize(b);
+                best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+            }
+            return best;
+        };
+        std::vector<hipStream_t> rejects;
+        for (int tries = 0; tries < 6 * n + 8 && (int)c->flight_streams.size() < n; tries++) {
+            hipStream_t cand = nullptr;
+            if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+            launch_spin(100ull, cand);  // first use: the queue is bound (and the kernel's code loaded) before anything is timed
+            (void)hipStreamSynchronize(cand);
+            bool alone = true;
+            for (hipStream_t taken : c->flight_streams)
+                if (pair_us(taken, cand) > 1.6 * kSpinUs) { alone = false; break; }
+            (alone ? c->flight_streams : rejects).push_back(cand);
+        }
+        c->flight_distinct = (int)c->flight_streams.size();
+        // fewer hardware queues than streams asked for: the rest share (they work, they do not overlap)
+        while ((int)c->flight_streams.size() < n && !rejects.empty()) { c->flight_streams.push_back(rejects.back()); rejects.pop_back(); }
+        for (hipStream_t r : rejects) (void)hipStreamDestroy(r);
+        (void)hipGetLastError();
+        if ((int)c->flight_streams.size() < n) return fail(c, PANO_EHIP, "hipStreamCreate (flight streams)");
+    }
+    for (int i = 0; i < n; i++) streams[i] = (void*)c->flight_streams[i];
+    if (distinct) *distinct = std::min(c->flight_distinct, n);
+    return PANO_OK;
+}
+pano_status pano_frame_streams(pano_ctx* c, int n, void** streams, int* distinct) {
+    return guarded(c, [&]() { return frame_streams_impl(c, n, streams, distinct); });
 }
 
 pano_status pano_set_mask(pano_ctx* c, int i, const uint8_t* h_mask, int w, int h, size_t stride) {

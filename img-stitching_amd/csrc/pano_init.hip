@@ -301,6 +301,17 @@ __global__ __launch_bounds__(256) void and_kernel(const uint8_t* a, const uint8_
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) d[i] = a[i] & b[i];
 }
+// One wave that occupies its stream for `ticks` of the 100 MHz wall clock and nothing else (the probe of pano_frame_streams: two
+// of these on two streams take twice as long when the streams share a hardware queue).  Bounded: at most 2^20 naps of about 1 us.
+__global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < (1 << 20); i++) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+void launch_spin(unsigned long long ticks_100mhz, hipStream_t s) { hipLaunchKernelGGL(spin_kernel, dim3(1, 1, 1), dim3(64, 1, 1), 0, s, ticks_100mhz); }
+
 void launch_and(const uint8_t* a, const uint8_t* b, uint8_t* dst, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(and_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, dst, n);
 }

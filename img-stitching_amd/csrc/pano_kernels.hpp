@@ -258,6 +258,8 @@ void launch_graphcut_apply(const GcPair& q, uint8_t* mask_a, uint8_t* mask_b, co
 void launch_gain_pairs(const GainImages& g, const GainPair* pairs, int npairs, int* count, double* sum_a, double* sum_b,
                        hipStream_t s);
 void launch_and(const uint8_t* a, const uint8_t* b, uint8_t* dst, size_t n, hipStream_t s);
+// one wave that keeps stream s busy for ticks / 100 MHz seconds (pano_frame_streams' probe)
+void launch_spin(unsigned long long ticks_100mhz, hipStream_t s);
 // one VoronoiSeamFinder::findInPair on device masks
 void launch_voronoi_pair(uint8_t* mask1, int w1, int h1, int tlx1, int tly1,
                          uint8_t* mask2, int w2, int h2, int tlx2, int tly2,

@@ -230,6 +230,15 @@ pano_status pano_compose_pair(pano_ctx* a, pano_ctx* b,
 #define PANO_MAX_FRAME_SLOTS 4
 pano_status pano_set_frame_slots(pano_ctx* ctx, int n);
 pano_status pano_select_frame_slot(pano_ctx* ctx, int k);
+/* The streams to run the slots on: n hipStream_t (1 <= n <= PANO_MAX_FRAME_SLOTS) owned by the context, PROBED to run side by side.
+ * The HIP runtime multiplexes all of a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) in an order the
+ * caller does not control, and two slots' streams that land on one queue run their frames one after the other: measured on
+ * config 2, 73.9 instead of 62.2 us per frame (docs/EXPERIMENTS.md, round 4).  The library creates candidates, times a pair of
+ * one-wave spin kernels against every stream already taken and keeps the candidates that overlap; *distinct (optional) = how many
+ * of the n sit on hardware queues of their own (fewer than n only when the runtime has fewer queues to give).  A few milliseconds,
+ * once; call it while the device is otherwise idle.  The reference has no counterpart: it composes one frame at a time
+ * (src/master.cpp:302-411). */
+pano_status pano_frame_streams(pano_ctx* ctx, int n, void** streams, int* distinct);
 
 /* ---- streaming form for a capture loop (BASELINE config 5: frames arrive in host memory at camera rate) ------
  * The reference's loop (src/master.cpp:302-411) pops one cv::Mat per camera from the capture queues and calls

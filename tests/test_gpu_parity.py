@@ -1240,6 +1240,33 @@ def test_host_entries_upload_only_what_the_warp_reads(pano, po):
         b.close()
 
 
+def test_frame_streams_run_side_by_side_and_compose_right(pano, po, torch, c1):
+    """pano_frame_streams: four streams of the library's own, probed against each other with spin kernels so that each sits on a
+    hardware queue of its own (the runtime's default gives a process four) - and frames composed on them, four in flight, are the
+    oracle's.  A second call hands out the same streams"""
+    masks = oracle_masks(po, c1)
+    ctx = make_ctx(pano, c1, 0, num_bands=3)
+    for i in range(4):
+        ctx.set_mask(i, masks[i])
+    streams, distinct = ctx.frame_streams(4)
+    assert len(set(streams)) == 4 and all(streams) and 3 <= distinct <= 4, (streams, distinct)
+    assert ctx.frame_streams(4)[0] == streams and ctx.frame_streams(2)[0] == streams[:2]
+    ctx.set_frame_slots(4)
+    sets = [c1["frames"], [np.ascontiguousarray(f[::-1]) for f in c1["frames"]], [np.ascontiguousarray(f[:, ::-1]) for f in c1["frames"]]]
+    wants = [po.compose(fr, c1["K"], c1["R"], c1["scale"], masks, 3)[0] for fr in sets]
+    dev = [[torch.from_numpy(f).cuda() for f in fr] for fr in sets]
+    ow, oh = ctx.output_size()
+    outs = [torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        for k in range(4):
+            ctx.select_frame_slot(k)
+            ctx.compose([t.data_ptr() for t in dev[(k + rnd) % 3]], [480 * 3] * 4, outs[k].data_ptr(), ow * 3, streams[k])
+        torch.cuda.synchronize()
+        for k in range(4):
+            assert np.array_equal(outs[k].cpu().numpy(), wants[(k + rnd) % 3]), (rnd, k)
+
+
 def test_258st_frames_bit_exact(pano, po, st258):
     """the last of the bundled inputs, 2222/258st/1..8.png (320x180 after a 2x2 box), as two 4-camera groups: Voronoi masks and the
     4-band panorama equal the oracle's and the committed hashes; graph-cut masks from these frames equal the oracle's too"""

@@ -27,7 +27,12 @@ ptr = [[[t.data_ptr() for t in fr] for fr in s] for s in sets]
 ow, oh = ctxs[0].output_size()
 for c in ctxs:
     c.set_frame_slots(F)
-streams = [torch.cuda.Stream() for _ in range(F)]
+# PANO_TORCH_STREAMS=1: torch.cuda.Stream()s (wherever the runtime puts them) instead of the library's probed flight streams
+if os.environ.get("PANO_TORCH_STREAMS") == "1" or F > pano.MAX_FRAME_SLOTS:
+    _ts = [torch.cuda.Stream() for _ in range(F)]
+    fstreams, distinct = [t.cuda_stream for t in _ts], None
+else:
+    fstreams, distinct = ctxs[0].frame_streams(F)
 outs = [[torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(F)]
 strides = [g["w"] * 3] * 4
 def step(k):
@@ -35,7 +40,7 @@ def step(k):
     ctxs[0].select_frame_slot(f); ctxs[1].select_frame_slot(f)
     p = ptr[k % nsets]
     ctxs[0].compose_pair(ctxs[1], p[0], strides, outs[f][0].data_ptr(), ow * 3, p[1], strides, outs[f][1].data_ptr(), ow * 3,
-                         streams[f].cuda_stream)
+                         fstreams[f])
 for k in range(400): step(k)
 torch.cuda.synchronize()
 best = []
@@ -44,5 +49,5 @@ for rep in range(3):
     for k in range(steps): step(k)
     torch.cuda.synchronize()
     best.append((time.perf_counter() - t0) / steps * 1e6)
-print(json.dumps({"lib": os.path.basename(os.environ.get("PANO_LIB", "product")), "skip": os.environ.get("PANO_SKIP", "0"), "F": F,
+print(json.dumps({"lib": os.path.basename(os.environ.get("PANO_LIB", "product")), "skip": os.environ.get("PANO_SKIP", "0"), "F": F, "distinct_hw_queues": distinct,
                   "rotate": rotate, "us_per_frame": [round(b, 2) for b in best]}))
