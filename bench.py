@@ -541,6 +541,17 @@ def main():
                 copy_gbs = 2 * x.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
                 roofline["device_copy_ceiling_GBps"] = round(copy_gbs, 1)
                 roofline["frac_of_copy_ceiling"] = round(lead["achieved"] / copy_gbs, 4)
+                # the whole frame in the timed region: every kernel's HBM traffic (PMC passes, profiles/) over the time of a step
+                fp = os.path.join(ROOT, "profiles", "r04_hbm_bytes_per_kernel_per_frame.json")
+                if os.path.exists(fp):
+                    fb = float(json.load(open(fp)).get("_total_hbm_MB_per_frame", 0.0)) * 1e6
+                    if fb > 0:
+                        fr_gbs = fb / (dt / args.steps) / 1e9
+                        roofline["frame_in_timed_region"] = {
+                            "hbm_traffic_bytes_per_step": int(fb), "us_per_step": round(dt / args.steps * 1e6, 2), "achieved_GBps": round(fr_gbs, 1),
+                            "frac_of_peak": round(fr_gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(fr_gbs / copy_gbs, 4),
+                            "algorithmic_bytes_per_step": int(NG * NC * W * H * 3 + NG * ow * oh * 3),
+                            "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of all nine launches of a frame, separate --pmc passes (profiles/r04_hbm_bytes_per_kernel_per_frame.json); algorithmic = the frames in + the panoramas out"}
                 del x, y
             except Exception:  # the side measurement never breaks the line
                 pass

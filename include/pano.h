@@ -236,7 +236,8 @@ pano_status pano_select_frame_slot(pano_ctx* ctx, int k);
  * config 2, 73.9 instead of 62.2 us per frame (docs/EXPERIMENTS.md, round 4).  The library creates candidates, times a pair of
  * one-wave spin kernels against every stream already taken and keeps the candidates that overlap; *distinct (optional) = how many
  * of the n sit on hardware queues of their own (fewer than n only when the runtime has fewer queues to give).  A few milliseconds,
- * once; call it while the device is otherwise idle.  The reference has no counterpart: it composes one frame at a time
+ * once; call it while the device is otherwise idle.  Later calls hand out the same streams; a call that asks for MORE than the
+ * context holds waits for the device, destroys the old ones and probes a new set (the handles of earlier calls are then dead).  The reference has no counterpart: it composes one frame at a time
  * (src/master.cpp:302-411). */
 pano_status pano_frame_streams(pano_ctx* ctx, int n, void** streams, int* distinct);
 
