@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from helpers import c2_group, synth_frame
 pano = importlib.import_module("img-stitching_amd")
+PHASE_FRONT, PHASE_MIDDLE, PHASE_BACK, PHASE_ALL = 1, 2, 4, 7   # include/pano.h of the patched build
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 check = len(sys.argv) > 2 and sys.argv[2] == "check"
 mode = os.environ.get("MODE", "phases")
@@ -61,13 +62,13 @@ def step_phases(k):
     f, s = k % F, k % nsets
     front, back, mid = fs[0], fs[1], fs[2 + (k % NMID)]
     if used[f]: hip.hipStreamWaitEvent(front, ev_done[f], 0)          # the slot's previous frame has left its last kernel
-    phase(f, s, pano.PHASE_FRONT, front); hip.hipEventRecord(ev_front[f], front)
-    hip.hipStreamWaitEvent(mid, ev_front[f], 0); phase(f, s, pano.PHASE_MIDDLE, mid); hip.hipEventRecord(ev_mid[f], mid)
-    hip.hipStreamWaitEvent(back, ev_mid[f], 0); phase(f, s, pano.PHASE_BACK, back); hip.hipEventRecord(ev_done[f], back)
+    phase(f, s, PHASE_FRONT, front); hip.hipEventRecord(ev_front[f], front)
+    hip.hipStreamWaitEvent(mid, ev_front[f], 0); phase(f, s, PHASE_MIDDLE, mid); hip.hipEventRecord(ev_mid[f], mid)
+    hip.hipStreamWaitEvent(back, ev_mid[f], 0); phase(f, s, PHASE_BACK, back); hip.hipEventRecord(ev_done[f], back)
     used[f] = True
 def step_frames(k):
     f, s = k % F, k % nsets
-    phase(f, s, pano.PHASE_ALL, fs[f])
+    phase(f, s, PHASE_ALL, fs[f])
 step = step_phases if mode == "phases" else step_frames
 bad = 0
 if check:
