@@ -113,11 +113,13 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
             ctxs[grp].stream_submit(slot)
         if refresh_every and refresh_async:
             # behind the submit: the frame is on its way while the refresh's frames are uploaded and warped (begin) or its
-            # masks installed (poll); the two stitchers half a period apart
+            # masks installed (poll).  Both stitchers of the rig begin in the SAME tick: they are independent contexts with a
+            # refresh thread each, so the rig's refresh takes one stitcher's graph-cut time (58 ms for 8 x 1080p) instead of two
+            # (103 ms: profiles/r04_refresh_rig_beside_the_loop.json)
             for grp in range(NG):
                 if ctxs[grp].refresh_masks_poll():
                     refreshed[0] += 1
-                if k and k % refresh_every == (grp * refresh_every) // NG:
+                if k and k % refresh_every == 0:
                     ctxs[grp].refresh_masks_begin(fs[grp])
         if pipeline:
             if pending is not None:
