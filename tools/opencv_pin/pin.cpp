@@ -22,9 +22,11 @@
 // Inputs are the committed fixtures tests/golden/<prefix>_cam<i>.png + <prefix>_cams.json; outputs follow the schema of
 // tests/golden/<prefix>_golden.json (tests/golden/make_golden.py), with SHA-256 over the same bytes (BGR, row-major, tight).
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
