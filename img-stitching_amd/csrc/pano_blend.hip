@@ -263,7 +263,11 @@ __device__ __forceinline__ void store_block(const BlendLevel& C, int l, int X0, 
                 pk.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
                 pk.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
                 pk.z = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
-                *(blend_u32x3u PANO_G*)d = blend_u32x3u{pk.x, pk.y, pk.z};
+                // non-temporal: nothing on the device reads the panorama back, and without the hint its 23 MB per frame pair push
+                // the pyramids of the frames in flight out of the caches (-1.0 to -1.9 us per frame with four in flight; the same
+                // hint on stores that ARE read back - G0, the pyramid levels, the canvas - or on any load of this kernel costs
+                // 1 to 8 us: docs/EXPERIMENTS.md, round 4)
+                __builtin_nontemporal_store(blend_u32x3u{pk.x, pk.y, pk.z}, (blend_u32x3u PANO_G*)d);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++)

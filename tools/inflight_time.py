@@ -28,7 +28,29 @@ ow, oh = ctxs[0].output_size()
 for c in ctxs:
     c.set_frame_slots(F)
 # PANO_TORCH_STREAMS=1: torch.cuda.Stream()s (wherever the runtime puts them) instead of the library's probed flight streams
-if os.environ.get("PANO_TORCH_STREAMS") == "1" or F > pano.MAX_FRAME_SLOTS:
+# PANO_CU_MASK=block|stride|halves: every flight stream gets its own share of the 256 CUs (hipExtStreamCreateWithCUMask) - bits
+# F*k .. in one run ("block"), every F-th bit ("stride"), or two streams per half ("halves")
+_cm = os.environ.get("PANO_CU_MASK")
+if _cm:
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    fstreams, distinct = [], None
+    for f in range(F):
+        if _cm == "block":
+            bits = [i for i in range(ncu) if i * F // ncu == f]
+        elif _cm == "stride":
+            bits = [i for i in range(ncu) if i % F == f]
+        else:
+            bits = [i for i in range(ncu) if (i * 2 // ncu) == (f % 2)]
+        words = (ctypes.c_uint32 * ((ncu + 31) // 32))()
+        for b in bits:
+            words[b // 32] |= 1 << (b % 32)
+        st = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(words), words)
+        assert rc == 0, rc
+        fstreams.append(st.value)
+elif os.environ.get("PANO_TORCH_STREAMS") == "1" or F > pano.MAX_FRAME_SLOTS:
     _ts = [torch.cuda.Stream() for _ in range(F)]
     fstreams, distinct = [t.cuda_stream for t in _ts], None
 else:
@@ -50,4 +72,4 @@ for rep in range(3):
     torch.cuda.synchronize()
     best.append((time.perf_counter() - t0) / steps * 1e6)
 print(json.dumps({"lib": os.path.basename(os.environ.get("PANO_LIB", "product")), "skip": os.environ.get("PANO_SKIP", "0"), "F": F, "distinct_hw_queues": distinct,
-                  "rotate": rotate, "us_per_frame": [round(b, 2) for b in best]}))
+                  "rotate": rotate, "cu_mask": os.environ.get("PANO_CU_MASK"), "us_per_frame": [round(b, 2) for b in best]}))
