@@ -196,6 +196,39 @@ def test_mask_primitives(po):
     assert np.array_equal(dist, (np.abs(yy - 2) + np.abs(xx - 1)).astype(np.float32))
 
 
+def test_mask_primitives_vs_scipy(po):
+    """The mask pipeline's primitives (ocvstitcher.hpp:1097-1101 dilate / resize / &, seam_finders.cpp VoronoiSeamFinder's
+    distanceTransform) against implementations that share no code with the restatement: scipy.ndimage's grey dilation and
+    city-block chamfer transform on random masks, and a float64 evaluation of INTER_LINEAR_EXACT's sampling grid
+    (src = (dst + .5) * scale - .5, taps clamped) which the fixed-point result must round like to within one count."""
+    from scipy import ndimage
+    rng = np.random.default_rng(7)
+    for shape, p0 in (((37, 53), 0.02), ((64, 64), 0.3), ((5, 91), 0.1), ((120, 7), 0.005)):
+        m = (rng.random(shape) < 0.5).astype(np.uint8) * 255
+        assert np.array_equal(po.dilate3x3(m), ndimage.grey_dilation(m, size=(3, 3), mode="constant", cval=0))
+        g = rng.integers(0, 256, shape, dtype=np.uint8)   # grey values too: the maximum of the 3 x 3 neighbourhood
+        assert np.array_equal(po.dilate3x3(g), ndimage.grey_dilation(g, size=(3, 3), mode="constant", cval=0))
+        z = np.where(rng.random(shape) < p0, 0, 255).astype(np.uint8)
+        z[shape[0] // 2, shape[1] // 2] = 0                # at least one zero: the transform is finite
+        want = ndimage.distance_transform_cdt(z != 0, metric="taxicab").astype(np.float32)
+        assert np.array_equal(po.distance_l1(z), want)
+    for (h, w), (dh, dw) in (((40, 60), (17, 23)), ((33, 47), (66, 94)), ((50, 50), (49, 51)), ((9, 200), (4, 77))):
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        got = po.resize_linear_exact(a, dw, dh).astype(np.float64)
+        fy = np.clip((np.arange(dh) + 0.5) * (h / dh) - 0.5, 0, h - 1)
+        fx = np.clip((np.arange(dw) + 0.5) * (w / dw) - 0.5, 0, w - 1)
+        y0 = np.floor(fy).astype(int); x0 = np.floor(fx).astype(int)
+        y1 = np.minimum(y0 + 1, h - 1); x1 = np.minimum(x0 + 1, w - 1)
+        wy = (fy - y0)[:, None]; wx = (fx - x0)[None, :]
+        A = a.astype(np.float64)
+        ref = (A[y0][:, x0] * (1 - wx) + A[y0][:, x1] * wx) * (1 - wy) + (A[y1][:, x0] * (1 - wx) + A[y1][:, x1] * wx) * wy
+        err = np.abs(got - ref)
+        # the weights are quantised to 1/256 per axis and the result rounded: every pixel within one count of the float64 value,
+        # most equal to its rounding
+        assert err.max() < 1.0, (h, w, dh, dw, err.max())
+        assert np.all(np.abs(got - np.rint(ref)) <= 1) and np.mean(got == np.rint(ref)) > 0.8
+
+
 def test_voronoi_partitions_overlap(po, c1):
     masks = po.prepare_masks_voronoi(0, 480, 270, c1["K"], c1["R"], c1["scale"])
     rois = [po.warp_roi(po.projector(0, c1["scale"], c1["K"][i], c1["R"][i]), 480, 270) for i in range(4)]
