@@ -229,6 +229,60 @@ def test_mask_primitives_vs_scipy(po):
         assert np.all(np.abs(got - np.rint(ref)) <= 1) and np.mean(got == np.rint(ref)) > 0.8
 
 
+def test_front_end_vs_numpy(po):
+    """The fused front end's oracle (nvcam.hpp:823-833,898-921: getOptimalNewCameraMatrix(alpha = 1) +
+    initUndistortRectifyMap + crop + two resizes) against a numpy evaluation written from the model, not from the C: the new camera
+    matrix maps the bounding box of the undistorted 9 x 9 grid onto the viewport, undistortion is the fixed-point iteration of the
+    (k1, k2, p1, p2) model and must invert the forward model the map uses, and the composed map is the five inverse steps in
+    float64.  Lens: cameras.yaml sensing / imx390 / fov120 / 960."""
+    import ctypes as C
+    K = np.array([4.890925118101495e+02, 0, 4.940763211103715e+02, 0, 4.912630345468579e+02, 2.865820139005963e+02, 0, 0, 1])
+    dist = np.array([-0.2838, 0.0628, 0.0007, -0.0004])          # tangential terms too
+    w, h = 960, 540
+
+    def distort(x, y):   # forward model, normalised coordinates
+        r2 = x * x + y * y
+        kr = 1 + dist[0] * r2 + dist[1] * r2 * r2
+        return x * kr + 2 * dist[2] * x * y + dist[3] * (r2 + 2 * x * x), y * kr + dist[2] * (r2 + 2 * y * y) + 2 * dist[3] * x * y
+
+    gx, gy = np.meshgrid(np.arange(9, dtype=np.float32) * w / 8, np.arange(9, dtype=np.float32) * h / 8)
+    x0 = (gx.astype(np.float64) - K[2]) / K[0]; y0 = (gy.astype(np.float64) - K[5]) / K[4]
+    x, y = x0.copy(), y0.copy()
+    for _ in range(5):   # cvUndistortPoints: five rounds of the fixed-point iteration
+        r2 = x * x + y * y
+        icd = 1.0 / (1 + dist[0] * r2 + dist[1] * r2 * r2)
+        dx = 2 * dist[2] * x * y + dist[3] * (r2 + 2 * x * x); dy = dist[2] * (r2 + 2 * y * y) + 2 * dist[3] * x * y
+        x = (x0 - dx) * icd; y = (y0 - dy) * icd
+    bx, by = distort(x, y)   # five rounds invert the model to a few hundredths of a pixel over the middle of this 120-degree lens'
+    ex = np.abs(bx * K[0] + K[2] - gx); ey = np.abs(by * K[4] + K[5] - gy)   # field and to 2.4 pixels in its corners (3.4 stops at five)
+    mid = (np.abs(x0) < 0.55) & (np.abs(y0) < 0.35)
+    assert ex[mid].max() < 0.05 and ey[mid].max() < 0.05 and ex.max() < 3 and ey.max() < 3
+    x = x.astype(np.float32).astype(np.float64); y = y.astype(np.float32).astype(np.float64)   # CvPoint2D32f
+    fx1 = (w - 1) / (x.max() - x.min()); fy1 = (h - 1) / (y.max() - y.min())
+    want = np.array([fx1, 0, -fx1 * x.min(), 0, fy1, -fy1 * y.min(), 0, 0, 1])
+    newK = np.array(po.optimal_new_camera_matrix(K, dist, w, h))
+    assert np.allclose(newK, want, rtol=2e-6, atol=1e-4), (newK, want)
+    # the outer rectangle lands on the viewport: its corners project to 0 and (w - 1, h - 1)
+    assert abs(newK[0] * x.min() + newK[2]) < 1e-3 and abs(newK[0] * x.max() + newK[2] - (w - 1)) < 1e-3
+    # the composed map at scattered stitcher-frame positions (raw 1920 x 1080, crop (70, 66, 885, 410), stitcher frame 960 x 540)
+    rect = (70, 66, 885, 410)
+    fe = po.front_end((1920, 1080), (w, h), K, dist, rect, (960, 540))
+    f = po.lib().po_front_end_map
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    f.restype = None
+    nk = (C.c_double * 9)(*newK)
+    rng = np.random.default_rng(3)
+    for xo, yo in rng.uniform([0, 0], [959, 539], (200, 2)).astype(np.float32):
+        xr, yr = C.c_float(), C.c_float()
+        f(C.addressof(fe), nk, float(xo), float(yo), C.byref(xr), C.byref(yr))
+        u = (float(xo) + 0.5) * (rect[2] / 960) - 0.5 + rect[0]      # stitcher frame -> undistorted frame (two resizes and the crop)
+        v = (float(yo) + 0.5) * (rect[3] / 540) - 0.5 + rect[1]
+        dxn, dyn = distort((u - newK[2]) / newK[0], (v - newK[5]) / newK[4])
+        ur = (dxn * K[0] + K[2] + 0.5) * 2 - 0.5                      # undistorted 960 x 540 -> raw 1920 x 1080
+        vr = (dyn * K[4] + K[5] + 0.5) * 2 - 0.5
+        assert abs(xr.value - ur) < 2e-3 and abs(yr.value - vr) < 2e-3, (xo, yo, xr.value, ur, yr.value, vr)
+
+
 def test_voronoi_partitions_overlap(po, c1):
     masks = po.prepare_masks_voronoi(0, 480, 270, c1["K"], c1["R"], c1["scale"])
     rois = [po.warp_roi(po.projector(0, c1["scale"], c1["K"][i], c1["R"][i]), 480, 270) for i in range(4)]
