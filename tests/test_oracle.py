@@ -283,6 +283,51 @@ def test_front_end_vs_numpy(po):
         assert abs(xr.value - ur) < 2e-3 and abs(yr.value - vr) < 2e-3, (xo, yo, xr.value, ur, yr.value, vr)
 
 
+def test_voronoi_find_vs_scipy(po):
+    """VoronoiSeamFinder::find (stitching_detailed.cpp:728-729; PairwiseSeamFinder::run over every overlapping pair i < j) written
+    again with numpy slices and scipy's city-block transform: sub-masks of the overlap + a gap of 10, collisions removed, distance
+    to what each image owns alone, `dist1 < dist2` gives the overlap to the first image.  Masks with holes and ragged edges, three
+    images whose overlaps chain (the second pair sees what the first pair left)."""
+    from scipy import ndimage
+    rng = np.random.default_rng(11)
+    corners = [(-40, 7), (55, -12), (150, 20), (10, 60)]
+    sizes = [(130, 90), (140, 100), (120, 80), (200, 70)]
+    masks = []
+    for (w, h) in sizes:
+        m = np.full((h, w), 255, np.uint8)
+        m[rng.random((h, w)) < 0.03] = 0                      # holes
+        m[:, : rng.integers(0, 9)] = 0; m[: rng.integers(0, 9), :] = 0   # ragged borders
+        yy, xx = np.mgrid[0:h, 0:w]
+        m[(xx - w) ** 2 + (yy - h) ** 2 < 30 ** 2] = 0        # a rounded corner
+        masks.append(m)
+    got = po.voronoi_find(corners, sizes, [m.copy() for m in masks])
+    want = [m.copy() for m in masks]
+    gap = 10
+    for i in range(len(want) - 1):
+        for j in range(i + 1, len(want)):
+            (x1, y1), (w1, h1), (x2, y2), (w2, h2) = corners[i], sizes[i], corners[j], sizes[j]
+            rx0, ry0 = max(x1, x2), max(y1, y2)
+            rx1, ry1 = min(x1 + w1, x2 + w2), min(y1 + h1, y2 + h2)
+            if rx1 <= rx0 or ry1 <= ry0:
+                continue
+            rw, rh = rx1 - rx0, ry1 - ry0
+            sub = []
+            for (cx, cy), (w, h), m in ((corners[i], sizes[i], want[i]), (corners[j], sizes[j], want[j])):
+                big = np.zeros((rh + 2 * gap, rw + 2 * gap), np.uint8)
+                ox, oy = rx0 - cx - gap, ry0 - cy - gap     # big[y, x] = m[y + oy, x + ox] where that is inside m
+                ys = slice(max(0, -oy), min(big.shape[0], h - oy)); xs = slice(max(0, -ox), min(big.shape[1], w - ox))
+                big[ys, xs] = m[ys.start + oy:ys.stop + oy, xs.start + ox:xs.stop + ox]
+                sub.append(big)
+            coll = (sub[0] != 0) & (sub[1] != 0)
+            d = [ndimage.distance_transform_cdt(~((sb != 0) & ~coll), metric="taxicab") for sb in sub]
+            seam = (d[0] < d[1])[gap:gap + rh, gap:gap + rw]
+            v1 = want[i][ry0 - y1:ry0 - y1 + rh, rx0 - x1:rx0 - x1 + rw]; v2 = want[j][ry0 - y2:ry0 - y2 + rh, rx0 - x2:rx0 - x2 + rw]
+            v2[seam] = 0
+            v1[~seam] = 0
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert sum(int((a != b).sum()) for a, b in zip(got, masks)) > 1000   # the seams did cut something
+
+
 def test_voronoi_partitions_overlap(po, c1):
     masks = po.prepare_masks_voronoi(0, 480, 270, c1["K"], c1["R"], c1["scale"])
     rois = [po.warp_roi(po.projector(0, c1["scale"], c1["K"][i], c1["R"][i]), 480, 270) for i in range(4)]
