@@ -343,6 +343,22 @@ def test_voronoi_partitions_overlap(po, c1):
 def test_gain_apply(po):
     g = po.resize_linear_32f(np.array([[1.0, 2.0]], np.float32), 4, 1)
     assert g.tolist() == [[1.0, 1.25, 1.75, 2.0]]
+    # BlocksGainCompensator::apply's upsampling of the block map (cv::resize INTER_LINEAR, f32) at the sizes of the rigs: the
+    # float64 value of the same sampling grid, to f32 rounding
+    rng = np.random.default_rng(2)
+    for (h, w), (dh, dw) in (((9, 13), (270, 422)), ((34, 48), (1080, 1531)), ((3, 4), (75, 110))):
+        a = rng.uniform(0.8, 1.25, (h, w)).astype(np.float32)
+        got = po.resize_linear_32f(a, dw, dh).astype(np.float64)
+        fy = (np.arange(dh) + 0.5) * (h / dh) - 0.5; fx = (np.arange(dw) + 0.5) * (w / dw) - 0.5
+        y0 = np.floor(fy).astype(int); x0 = np.floor(fx).astype(int)
+        wy = (fy - y0)[:, None]; wx = (fx - x0)[None, :]
+        # a tap left of / above the first sample takes the first sample with weight 1 (cv::resize: fx = 0 there); beyond the last: the last
+        wy[y0 < 0] = 0; wx[:, x0 < 0] = 0
+        y0 = np.clip(y0, 0, h - 1); x0 = np.clip(x0, 0, w - 1)
+        y1 = np.minimum(y0 + 1, h - 1); x1 = np.minimum(x0 + 1, w - 1)
+        A = a.astype(np.float64)
+        ref = (A[y0][:, x0] * (1 - wx) + A[y0][:, x1] * wx) * (1 - wy) + (A[y1][:, x0] * (1 - wx) + A[y1][:, x1] * wx) * wy
+        assert np.abs(got - ref).max() < 3e-6, np.abs(got - ref).max()   # f32 weights and two f32 passes
 
 
 def test_compose_cut_and_threads(po, c1):
