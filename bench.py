@@ -13,9 +13,11 @@ spherical warp + 5-band multi-band blend per group, fixed K/R (imx390-derived f=
   fixed -> "scaling": "strong".  (`replicas_panoramas_per_s` reports, as extra information, the same ranks each
   composing their own rig with no exchange.)
 
-At N = 1 the K steps are dealt round-robin over --frames-in-flight frame slots / streams (default 4): one frame is a
-chain of ten dependent launches, several too small to fill the GPU, and the chains of consecutive frames overlap the
-way they do behind a capture loop (2 -> 10.4k, 3 -> 11.1k, 4 -> 11.3k panoramas/s).  --frames-in-flight 1 composes one frame at a time.
+At N = 1 the K steps are dealt round-robin over --frames-in-flight frame slots / streams (default 3): one frame is a
+chain of nine dependent launches, several too small to fill the GPU, and the chains of consecutive frames overlap the
+way they do behind a capture loop (round 4, us per frame: 1 -> 110, 2 -> 62-63, 3 -> 58-61, 4 -> 62-64: since the panorama is stored
+with the non-temporal hint three frames in flight beat four; before it they were level).
+--frames-in-flight 1 composes one frame at a time.
 
 The driver runs `--steps 20 --warmup 5`: 1.5 ms of GPU time, which straight after set-up finds the device at its idle clocks
 (every kernel 8-10 % slower than in a loop that has been running).  SURVEY 8(d) defines the metric at steady state, so the bench
@@ -69,7 +71,7 @@ def main():
     ap.add_argument("--bands", type=int, default=5)
     ap.add_argument("--one-stream", action="store_true", help="both groups on one stream (no overlap)")
     ap.add_argument("--force-sharded-path", action="store_true", help="diagnostic: run the N>1 step code at N=1")
-    ap.add_argument("--frames-in-flight", type=int, default=4,
+    ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="N=1: frame slots / streams the K steps are dealt over round-robin (1 = one frame at a time)")
     ap.add_argument("--cold-only", action="store_true",
                     help="N=1: ONLY K steps one frame at a time over six rotating frame sets (the roofline.cold measurement), for a "
@@ -709,13 +711,16 @@ def main():
                     torch.cuda.synchronize()
                     return nb * reps / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9, nb * reps / (ev[2].elapsed_time(ev[3]) * 1e-3) / 1e9
                 both(2)
-                c_up, c_dn = both(12)
+                c_up = c_dn = 0.0
+                for _ in range(3):   # the best of three: a ceiling, and one hiccup of the host would put the fraction above 1
+                    u_, d_ = both(12)
+                    c_up, c_dn = max(c_up, u_), max(c_dn, d_)
                 t_link = max(up_b / (c_up * 1e9), down_b / (c_dn * 1e9))
                 result["h2d_inclusive"] = {
                     "panoramas_per_s": rate, "bound": "host link (PCIe), full duplex", "up_bytes_per_step": int(up_b), "down_bytes_per_step": int(down_b),
                     "up_GBps": round(rate * up_b / 1e9, 2), "down_GBps": round(rate * down_b / 1e9, 2),
                     "pinned_copy_ceiling_GBps": {"up": round(c_up, 2), "down": round(c_dn, 2),
-                                                 "measured": "hipMemcpyAsync of page-locked 64 MiB blocks, 12 each way, both directions at once"},
+                                                 "measured": "hipMemcpyAsync of page-locked 64 MiB blocks, 12 each way, both directions at once, best of 3"},
                     "frac": round(t_link * rate, 4),
                     "note": "frames of %d steps land in the library's page-locked slots; H2D, compose and D2H of consecutive steps overlap (pano_stream_*)" % nstream}
                 del hp_up, hp_dn, d_up, d_dn
@@ -755,12 +760,12 @@ def config4_leg(pano, torch, steps):
     fp, strides = [t.data_ptr() for t in frames], [W * 3] * NC
     ow, oh = ctx.output_size()
     outs = [torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in range(F)]
-    streams = [torch.cuda.Stream() for _ in range(F)]
+    streams, _ = ctx.frame_streams(F)   # probed onto distinct hardware queues, like the timed region's
 
     def step(k):
         f = k % F
         ctx.select_frame_slot(f)
-        ctx.compose(fp, strides, outs[f].data_ptr(), ow * 3, streams[f].cuda_stream)
+        ctx.compose(fp, strides, outs[f].data_ptr(), ow * 3, streams[f])
     for k in range(12):
         step(k)
     torch.cuda.synchronize()
@@ -774,7 +779,7 @@ def config4_leg(pano, torch, steps):
     torch.cuda.synchronize()
     ctx.stage_stats(True)
     for k in range(steps):
-        ctx.compose(fp, strides, outs[0].data_ptr(), ow * 3, streams[0].cuda_stream)
+        ctx.compose(fp, strides, outs[0].data_ptr(), ow * 3, streams[0])
     torch.cuda.synchronize()
     ms, n = ctx.stage_stats(True)
     sb, db = ctx.warp_bytes()

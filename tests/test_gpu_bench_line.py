@@ -52,7 +52,7 @@ def test_bench_line_host_link_roofline():
     assert abs(h["up_GBps"] - h["panoramas_per_s"] * h["up_bytes_per_step"] / 1e9) < 0.02 * h["up_GBps"]
     assert 0 < h["up_bytes_per_step"] <= 8 * 1920 * 1080 * 3 and h["down_bytes_per_step"] == 2 * 3893 * 991 * 3
     c = h["pinned_copy_ceiling_GBps"]
-    assert c["up"] > 1.0 and c["down"] > 1.0 and 0.05 < h["frac"] < 1.1, h
+    assert c["up"] > 1.0 and c["down"] > 1.0 and 0.05 < h["frac"] < 1.25, h   # the ceiling is a measurement on a shared host
 
 
 @pytest.mark.gpu

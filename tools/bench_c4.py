@@ -25,12 +25,16 @@ ctx.set_frame_slots(F)
 frames = [torch.from_numpy(synth_frame(g["w"], g["h"], 900 + i)).cuda() for i in range(4)]
 ow, oh = ctx.output_size()
 outs = [torch.zeros((oh, ow, 3), dtype=torch.uint8, device="cuda") for _ in range(F)]
-streams = [torch.cuda.Stream() for _ in range(F)]
+if os.environ.get("PANO_TORCH_STREAMS") == "1":
+    _ts = [torch.cuda.Stream() for _ in range(F)]
+    streams = [t.cuda_stream for t in _ts]
+else:
+    streams, _distinct = ctx.frame_streams(F)   # probed onto distinct hardware queues
 fp = [t.data_ptr() for t in frames]
 def step(k):
     f = k % F
     ctx.select_frame_slot(f)
-    ctx.compose(fp, [g["w"] * 3] * 4, outs[f].data_ptr(), ow * 3, streams[f].cuda_stream)
+    ctx.compose(fp, [g["w"] * 3] * 4, outs[f].data_ptr(), ow * 3, streams[f])
 for k in range(12): step(k)
 torch.cuda.synchronize()
 N = 200
@@ -44,7 +48,7 @@ ctx.select_frame_slot(0)
 torch.cuda.synchronize()
 ctx.stage_stats(True)
 for k in range(50):
-    ctx.compose(fp, [g["w"] * 3] * 4, outs[0].data_ptr(), ow * 3, streams[0].cuda_stream)
+    ctx.compose(fp, [g["w"] * 3] * 4, outs[0].data_ptr(), ow * 3, streams[0])
 torch.cuda.synchronize()
 ms, n = ctx.stage_stats(True)
 sb, db = ctx.warp_bytes()
