@@ -8,7 +8,7 @@ import torch
 from helpers import c2_group, synth_frame
 pano = importlib.import_module("img-stitching_amd")
 g = c2_group()
-F, SETS, STEPS = 4, 6, int(os.environ.get("STEPS", "600"))
+F, SETS, STEPS = int(os.environ.get("F", "4")), 6, int(os.environ.get("STEPS", "600"))
 ctxs = []
 for k in range(2):
     ctx = pano.Context(4, g["w"], g["h"], scale=g["scale"], num_bands=5, device=0)
