@@ -193,6 +193,10 @@ class Stitcher {
             cfg_.blendStrength = std::stof(kv.at("stitcherBlenderStrength"));
             cfg_.cfgPath = kv.count("camcfgpath") ? kv["camcfgpath"] : std::string();
             cfg_.initMode = kv.count("initMode") ? std::stoi(kv["initMode"]) : (int)enInitByDefault;
+            if (kv.count("stitcherMatchConf")) cfg_.matchConf = std::stof(kv["stitcherMatchConf"]);
+            if (kv.count("stitcherAdjusterConf")) cfg_.adjusterConf = std::stof(kv["stitcherAdjusterConf"]);
+            if (kv.count("stitcherCameraExThres")) cfg_.stitchercameraExThres = std::stof(kv["stitcherCameraExThres"]);
+            if (kv.count("stitcherCameraInThres")) cfg_.stitchercameraInThres = std::stof(kv["stitcherCameraInThres"]);
             std::vector<detail::Structure> st;
             if (!detail::read_structures(kv.at("cameraparams"), st)) return RET_ERR;
             defaultCamParams_.clear();
@@ -220,38 +224,24 @@ class Stitcher {
     }
 
     // calibration(imgs) (ocvstitcher.hpp:592-650).  K/R come from the defaults (mode 2) or from the last
-    // record of <cfgPath>cameraparaout_<id>.txt (mode 3, falling back to the defaults like the reference falls
-    // back after failures); then the mask half of initSeam (:975-1101) runs on the GPU.
-    int calibration(const std::vector<Mat>& imgs) {
-        // the frames feed the graph-cut seam finder and, when it is on, the exposure compensator
-        pano_destroy(ctx_);
-        ctx_ = nullptr;
-        pano_config c{};
-        c.num_images = cfg_.num_images; c.width = cfg_.width; c.height = cfg_.height;
-        c.projector = projector; c.blend_strength = cfg_.blendStrength; c.num_bands = PANO_BANDS_FROM_STRENGTH;
-        c.device = device;
-        if (cut_.size() == 4 && cfg_.initMode == enInitByDefault)  // the reference keeps the yaml cut only in mode 2 (:959-964)
-            for (int i = 0; i < 4; i++) c.cut[i] = cut_[i];
-        if (pano_create(&c, &ctx_) != PANO_OK) return RET_ERR;
-        bool loaded = false;
-        if (cfg_.initMode == enInitByCfg) {
-            std::string file = cfg_.cfgPath + "cameraparaout_" + std::to_string(cfg_.id) + ".txt";
-            loaded = pano_load_camera_file(ctx_, file.c_str()) == PANO_OK;
-        }
-        if (!loaded && pano_set_cameras_from_list(ctx_, defaultCamParams_.c_str()) != PANO_OK) return RET_ERR;
-        if (pano_prepare(ctx_) != PANO_OK) return RET_ERR;
-        if (device >= 0) {
-            if (buildMasks(imgs) != RET_OK) return RET_ERR;
-            if (exposureCompensation) {
-                const uint8_t* frames[PANO_MAX_CAMS];
-                size_t strides[PANO_MAX_CAMS];
-                if (!borrow(imgs, frames, strides)) return RET_ERR;
-                if (pano_estimate_gains(ctx_, frames, strides, 32, 32) != PANO_OK) return RET_ERR;
-            }
-        }
-        frame_ = 0;
-        refreshing_ = false;  // a refresh that was under way died with the old context
-        return RET_OK;
+    // record of <cfgPath>cameraparaout_<id>.txt (mode 3, falling back to the defaults: the state the reference ends in
+    // when its own fallback, initAll, has failed five times and it flips to mode 2, :639-643); then the mask half of
+    // initSeam (:975-1101) runs on the GPU.  Mode 1 (initAll: features, matching, bundle adjustment) is not rebuilt
+    // here - the north star fixes K and R - and is served like the reference's "calibration failed due to environment,
+    // use default parameters"; a caller that runs its own bundle adjustment hands the result to the overload below.
+    //
+    // The cut (m_cutParams).  init(yaml) loads the structure's `cut` in EVERY mode (:333-337) and initSeam never touches
+    // it, so modes 2 and 3 and every fallback onto the defaults crop with the yaml cut; only a successful initAll
+    // rewrites it to [0, (rows - cut_h) / 2, cols, cut_h] (:959-964) - here: the overload with estimated cameras.
+    int calibration(const std::vector<Mat>& imgs) { return calibrate(imgs, nullptr, nullptr, 0.f); }
+
+    // The tail of initAll (ocvstitcher.hpp:783-964) for a caller that estimated the cameras itself: K_est / R_est are
+    // N x 9 row-major f32, scale_est the median focal (:736-751).  verifyCamParams against the defaults (:783-795) with
+    // the yaml thresholds; a plausible estimate is installed and the cut becomes initAll's (:959-964); an implausible one
+    // is RET_ERR, where the reference's loop retries and finally takes the defaults - calibration(imgs) does that.
+    int calibration(const std::vector<Mat>& imgs, const float* K_est, const float* R_est, float scale_est) {
+        if (!K_est || !R_est) return RET_ERR;
+        return calibrate(imgs, K_est, R_est, scale_est);
     }
 
     // process(imgs, ret) (ocvstitcher.hpp:1141-1216).  The reference's returns nothing and cannot fail visibly; here a frame
@@ -286,6 +276,55 @@ class Stitcher {
     const char* lastError() const { return pano_last_error(ctx_); }
 
   private:
+    int calibrate(const std::vector<Mat>& imgs, const float* K_est, const float* R_est, float scale_est) {
+        // the frames feed the graph-cut seam finder and, when it is on, the exposure compensator
+        pano_destroy(ctx_);
+        ctx_ = nullptr;
+        pano_config c{};
+        c.num_images = cfg_.num_images; c.width = cfg_.width; c.height = cfg_.height;
+        c.projector = projector; c.blend_strength = cfg_.blendStrength; c.num_bands = PANO_BANDS_FROM_STRENGTH;
+        c.device = device;
+        if (cut_.size() == 4)  // the yaml cut, whatever the mode (:333-337); initAll's rewrite follows pano_prepare below
+            for (int i = 0; i < 4; i++) c.cut[i] = cut_[i];
+        if (pano_create(&c, &ctx_) != PANO_OK) return RET_ERR;
+        if (pano_set_cameras_from_list(ctx_, defaultCamParams_.c_str()) != PANO_OK) return RET_ERR;  // useDefaultCamParams
+        if (K_est) {
+            if (pano_verify_cameras(ctx_, K_est, R_est, cfg_.stitchercameraExThres, cfg_.stitchercameraInThres, nullptr) != PANO_OK)
+                return RET_ERR;  // "environment is not suitable for calibration" (:415-418)
+            std::string list;
+            char buf[32];
+            for (int i = 0; i < cfg_.num_images; i++)
+                for (int k = 0; k < 18; k++) {
+                    snprintf(buf, sizeof buf, "%.9g,", k < 9 ? K_est[9 * i + k] : R_est[9 * i + k - 9]);
+                    list += buf;
+                }
+            snprintf(buf, sizeof buf, "%.9g", scale_est);
+            list += buf;
+            if (pano_set_cameras_from_list(ctx_, list.c_str()) != PANO_OK) return RET_ERR;
+        } else if (cfg_.initMode == enInitByCfg) {
+            std::string file = cfg_.cfgPath + "cameraparaout_" + std::to_string(cfg_.id) + ".txt";
+            (void)pano_load_camera_file(ctx_, file.c_str());  // all or nothing: a record that does not load leaves the defaults
+        }
+        if (pano_prepare(ctx_) != PANO_OK) return RET_ERR;
+        if (K_est && cut_.size() == 4) {  // initAll's cut (:959-964): full width, the yaml height centred
+            int rect[4];
+            if (pano_get_pano_rect(ctx_, rect) != PANO_OK) return RET_ERR;
+            const int cut[4] = {0, (rect[3] - cut_[3]) / 2, rect[2], cut_[3]};
+            if (pano_set_cut(ctx_, cut) != PANO_OK) return RET_ERR;
+        }
+        if (device >= 0) {
+            if (buildMasks(imgs) != RET_OK) return RET_ERR;
+            if (exposureCompensation) {
+                const uint8_t* frames[PANO_MAX_CAMS];
+                size_t strides[PANO_MAX_CAMS];
+                if (!borrow(imgs, frames, strides)) return RET_ERR;
+                if (pano_estimate_gains(ctx_, frames, strides, 32, 32) != PANO_OK) return RET_ERR;
+            }
+        }
+        frame_ = 0;
+        refreshing_ = false;  // a refresh that was under way died with the old context
+        return RET_OK;
+    }
     // the frames as the C-ABI takes them; false when there are too few or they are not stitcher sized
     bool borrow(const std::vector<Mat>& imgs, const uint8_t** frames, size_t* strides) const {
         if ((int)imgs.size() < cfg_.num_images) return false;

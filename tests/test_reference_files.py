@@ -144,3 +144,33 @@ def test_stitcher_init_on_the_reference_yaml_as_committed(replay_bin, tmp_path):
     cfg = reference_cfg(tmp_path, sttype="4cam-silver")
     r = subprocess.run([replay_bin, str(cfg), "--plan"], capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 1 and "calibration failed" in r.stderr
+
+
+def test_stitcher_mode_3_on_the_reference_yaml_keeps_the_yaml_cut(replay_bin, tmp_path):
+    """cfg/stitcher-imx390cfg.yaml with `initMode: 3`: the reference loads the structure's cut in every mode
+    (ocvstitcher.hpp:333-337) and mode 3's initCamParams -> initSeam path (:627-628) never rewrites it (:959-964 is initAll's).
+    The reference's own cfg/390camcfg/ logs show what that means: cameraparaout_0.txt / _1.txt end in records of ANOTHER
+    calibration (panoramas 1026 and 1038 wide at 960 x 540), which the structure's 1430-wide cut does not fit - the reference would
+    die in cv::Mat::operator()(Rect) (:1210), the mirror refuses at calibration(); cameraparaout_2.txt ends in a record the cut
+    does fit (1510 x 527)."""
+    import shutil
+    cfg = reference_cfg(tmp_path, outPutWidth=960, outPutHeight=540, initMode=3,
+                        camcfgpath='"%s/"' % os.path.join(REF, "cfg/390camcfg"))
+    r = subprocess.run([replay_bin, str(cfg), "--plan"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and "stitcher 0 calibration failed" in r.stderr and "cut" in r.stderr, r.stderr
+    # the record the cut fits, offered to both stitchers: ITS cameras (not the yaml defaults' 1452x523 / 1484x509), the yaml cuts
+    d = tmp_path / "camcfg"
+    d.mkdir()
+    for i in (0, 1):
+        shutil.copy(os.path.join(REF, "cfg/390camcfg/cameraparaout_2.txt"), d / ("cameraparaout_%d.txt" % i))
+    cfg = reference_cfg(tmp_path, outPutWidth=960, outPutHeight=540, initMode=3, camcfgpath='"%s/"' % d)
+    r = subprocess.run([replay_bin, str(cfg), "--plan"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "stitcher 0: pano 1510x527 at (-762,829), output 1430x250, bands 3" in r.stdout, r.stdout
+    assert "stitcher 1: pano 1510x527 at (-762,829), output 1470x250, bands 3" in r.stdout, r.stdout
+    # no record on file: the defaults (where the reference ends after its fallbacks, :639-643), the same cuts
+    cfg = reference_cfg(tmp_path, outPutWidth=960, outPutHeight=540, initMode=3, camcfgpath='"%s/"' % tmp_path)
+    r = subprocess.run([replay_bin, str(cfg), "--plan"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "stitcher 0: pano 1452x523 at (-721,497), output 1430x250, bands 3" in r.stdout
+    assert "stitcher 1: pano 1484x509 at (-733,523), output 1470x250, bands 3" in r.stdout
