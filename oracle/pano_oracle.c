@@ -114,6 +114,37 @@ void po_projector_set(po_projector* p, int kind, float scale, const float K[9], 
     matmul3x3_f(K, p->rinv, p->k_rinv);
 }
 
+/* ---- variant switches (test infrastructure for the OpenCV pin, tests/test_oracle_variants.py) ---------------------------------
+ * The transcendental functions of the projectors come from the platform's libm (glibc on x86-64 here, glibc on aarch64 on the
+ * reference's Jetson): sinf / cosf / atan2f / acosf are not correctly rounded and may differ by an ulp between builds.  With a
+ * perturbation set, every result of those four is moved by a whole number of ulps before it is used: 1: +1 ulp, 2: -1 ulp,
+ * 3: -1 / 0 / +1 by a hash of the argument bits and the seed (a platform that disagrees "sometimes").  0 (default): libm as is. */
+static int g_trig_mode = 0;
+static unsigned g_trig_seed = 0;
+void po_set_trig_perturbation(int mode, unsigned seed) { g_trig_mode = mode; g_trig_seed = seed; }
+static inline float ulp_step(float v, int k) {  /* k in {-1, 0, +1}: the next representable float towards -inf / +inf */
+    if (k == 0 || v != v || v == 0.f || isinf(v)) return v;
+    return nextafterf(v, k > 0 ? INFINITY : -INFINITY);
+}
+static inline float trig_fix(float result, float arg, unsigned site) {
+    if (!g_trig_mode) return result;
+    int k;
+    if (g_trig_mode == 1) k = 1;
+    else if (g_trig_mode == 2) k = -1;
+    else {
+        union { float f; uint32_t u; } a;
+        a.f = arg;
+        uint32_t h = (a.u ^ (site * 0x9e3779b9u) ^ g_trig_seed) * 0x85ebca6bu;
+        h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        k = (int)(h % 3u) - 1;
+    }
+    return ulp_step(result, k);
+}
+#define PO_SINF(x, site) trig_fix(sinf(x), (x), (site))
+#define PO_COSF(x, site) trig_fix(cosf(x), (x), (site))
+#define PO_ATAN2F(y, x, site) trig_fix(atan2f((y), (x)), (y) + (x), (site))
+#define PO_ACOSF(x, site) trig_fix(acosf(x), (x), (site))
+
 /* SphericalProjector::mapForward / CylindricalProjector::mapForward (warpers_inl.hpp) */
 void po_map_forward(const po_projector* p, float x, float y, float* u, float* v) {
     const float* m = p->r_kinv;
@@ -121,11 +152,11 @@ void po_map_forward(const po_projector* p, float x, float y, float* u, float* v)
     float y_ = m[3] * x + m[4] * y + m[5];
     float z_ = m[6] * x + m[7] * y + m[8];
     if (p->kind == PO_SPHERICAL) {
-        *u = p->scale * atan2f(x_, z_);
+        *u = p->scale * PO_ATAN2F(x_, z_, 1u);
         float w = y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_);
-        *v = p->scale * (PO_PI_F - acosf(w == w ? w : 0));
+        *v = p->scale * (PO_PI_F - PO_ACOSF(w == w ? w : 0, 2u));
     } else {
-        *u = p->scale * atan2f(x_, z_);
+        *u = p->scale * PO_ATAN2F(x_, z_, 1u);
         *v = p->scale * y_ / sqrtf(x_ * x_ + z_ * z_);
     }
 }
@@ -137,14 +168,14 @@ void po_map_backward(const po_projector* p, float u, float v, float* x, float* y
     u /= p->scale;
     v /= p->scale;
     if (p->kind == PO_SPHERICAL) {
-        float sinv = sinf(PO_PI_F - v);
-        x_ = sinv * sinf(u);
-        y_ = cosf(PO_PI_F - v);
-        z_ = sinv * cosf(u);
+        float sinv = PO_SINF(PO_PI_F - v, 3u);
+        x_ = sinv * PO_SINF(u, 4u);
+        y_ = PO_COSF(PO_PI_F - v, 5u);
+        z_ = sinv * PO_COSF(u, 6u);
     } else {
-        x_ = sinf(u);
+        x_ = PO_SINF(u, 4u);
         y_ = v;
-        z_ = cosf(u);
+        z_ = PO_COSF(u, 6u);
     }
     float z;
     *x = m[0] * x_ + m[1] * y_ + m[2] * z_;
@@ -344,13 +375,35 @@ void po_pyr_down_16s(const int16_t* src, int w, int h, int cn, int16_t* dst) {
     }
 }
 
-/* cv::pyrDown, CV_32F (pyrDown_<FltCast<float,8>>), scalar (non-SIMD) evaluation order:
- * row = s2*6 + (s1+s3)*4 + s0 + s4;  dst = (r2*6 + (r1+r3)*4 + r0 + r4) * (1/256).
- * NOTE: OpenCV's SSE2/NEON vertical kernels associate the same sum differently
- * ((r0+r4)+(r2+r2) + ((r1+r3)+r2)*4); the last ulp of f32 weights is therefore
- * platform-defined in OpenCV itself.  We fix the scalar order. */
+/* cv::pyrDown, CV_32F (pyrDown_<FltCast<float,8>>, imgproc/src/pyramids.cpp).  The sum 6 c + 4 (l1 + r1) + l2 + r2 is evaluated
+ * in an order that depends on the OpenCV BUILD - in f32 the order decides the last ulp of the blend weights:
+ *   scalar code (every build's borders and tails; the whole of a build without SIMD):
+ *       row = s2*6 + (s1+s3)*4 + s0 + s4             dst = (r2*6 + (r1+r3)*4 + r0 + r4) * (1/256)
+ *   vertical vector body (PyrDownVec_32f: SSE2 since 2.x, NEON since 3.0, universal intrinsics in late 3.4.x), x in
+ *   [0, floor(width / n) * n), n = 8 (the hand-written SSE2 / NEON loops step 8 floats), 4 or 8 or 16 (v_float32::nlanes):
+ *       SSE2 / universal   t = ((r0+r4) + (r2+r2)) + ((r1+r3)+r2)*4          dst = t * (1/256)
+ *       NEON               t = ((r0+r4) + (r2+r2)) + ((r1+r2)+r3)*4
+ *     (the multiply by 4 is exact, so a fused multiply-add gives the same bits)
+ *   horizontal vector body (PyrDownVecH<float,float,1>, universal intrinsics, late 3.4.x and 4.x only), x in [1, 1 + floor((width0
+ *   - 1) / n) * n):
+ *       row = r2*6 + ((r1+r3)*4 + (r0+r4)), the outer multiply-add fused where the build dispatches to FMA3 / NEON-FMA (6 x is not
+ *       exact in f32: fused and unfused differ)
+ * Recalled from the OpenCV sources, NOT checkable here (no OpenCV in this container): which of these a given build runs is exactly
+ * what tools/opencv_pin/pin.cpp's unit stages `pyrdown32f_*` settle.  Default = scalar everywhere (what the product's weight kernel
+ * computes, pano_init.hip); po_set_pyrdown32f_variant selects the others for the pin loader and the robustness test. */
+static int g_pd_vert = 0, g_pd_vbody = 8, g_pd_horz = 0, g_pd_hbody = 4;
+void po_set_pyrdown32f_variant(int vertical, int vbody, int horizontal, int hbody) {
+    g_pd_vert = vertical; g_pd_vbody = vbody > 0 ? vbody : 8;
+    g_pd_horz = horizontal; g_pd_hbody = hbody > 0 ? hbody : 4;
+}
 void po_pyr_down_32f(const float* src, int w, int h, float* dst) {
     int dw = (w + 1) / 2, dh = (h + 1) / 2;
+    const int vert = g_pd_vert, horz = g_pd_horz;
+    const int vend = vert ? dw / g_pd_vbody * g_pd_vbody : 0;            /* the vertical vector body ends here */
+    /* pyrDown_: width0 = min((ssize.width - PD_SZ/2 - 1) / 2 + 1, dsize.width): the columns whose five taps need no border table */
+    int width0 = (w - 2 - 1) / 2 + 1;
+    if (width0 > dw) width0 = dw;
+    const int hend = horz && width0 > 1 ? 1 + (width0 - 1) / g_pd_hbody * g_pd_hbody : 0;
 #pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int y = 0; y < dh; y++) {
         float* rows = (float*)malloc(sizeof(float) * 5 * (size_t)dw);
@@ -363,12 +416,23 @@ void po_pyr_down_32f(const float* src, int w, int h, float* dst) {
                 int x1 = border_interpolate(2 * x - 1, w, PO_BORDER_REFLECT_101);
                 int x3 = border_interpolate(2 * x + 1, w, PO_BORDER_REFLECT_101);
                 int x4 = border_interpolate(2 * x + 2, w, PO_BORDER_REFLECT_101);
-                row[x] = s[2 * x] * 6 + (s[x1] + s[x3]) * 4 + s[x0] + s[x4];
+                if (x >= 1 && x < hend) {
+                    const float inner = (s[x1] + s[x3]) * 4 + (s[x0] + s[x4]);
+                    row[x] = horz == 2 ? fmaf(s[2 * x], 6.f, inner) : s[2 * x] * 6 + inner;
+                } else
+                    row[x] = s[2 * x] * 6 + (s[x1] + s[x3]) * 4 + s[x0] + s[x4];
             }
         }
         const float *r0 = rows, *r1 = rows + dw, *r2 = r1 + dw, *r3 = r2 + dw, *r4 = r3 + dw;
         float* d = dst + (size_t)y * dw;
-        for (int x = 0; x < dw; x++) d[x] = (r2[x] * 6 + (r1[x] + r3[x]) * 4 + r0[x] + r4[x]) * (1.f / 256);
+        for (int x = 0; x < dw; x++) {
+            if (x < vend) {
+                const float a = (r0[x] + r4[x]) + (r2[x] + r2[x]);
+                const float b = vert == 2 ? (r1[x] + r2[x]) + r3[x] : (r1[x] + r3[x]) + r2[x];
+                d[x] = (a + b * 4) * (1.f / 256);
+            } else
+                d[x] = (r2[x] * 6 + (r1[x] + r3[x]) * 4 + r0[x] + r4[x]) * (1.f / 256);
+        }
         free(rows);
     }
 }

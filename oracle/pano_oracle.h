@@ -62,6 +62,12 @@ void po_warp_8u(const po_projector* p, const uint8_t* src, int sw, int sh, size_
 /* ---- A4: pyramids (pyramids.cpp pyrDown_/pyrUp_, BORDER_REFLECT_101 / default) */
 void po_pyr_down_16s(const int16_t* src, int w, int h, int cn, int16_t* dst);
 void po_pyr_down_32f(const float* src, int w, int h, float* dst);
+/* which association of cv::pyrDown CV_32F's sum the restatement follows (see pano_oracle.c): vertical 0 scalar / 1 SSE2 or universal
+ * intrinsics / 2 NEON, with a vector body of vbody floats; horizontal 0 scalar / 1 universal intrinsics / 2 the same with a fused
+ * multiply-add, body hbody floats.  (0, *, 0, *) is the default and what the product computes. */
+void po_set_pyrdown32f_variant(int vertical, int vbody, int horizontal, int hbody);
+/* libm disagreement model for the projectors' sinf / cosf / atan2f / acosf: 0 none, 1 +1 ulp, 2 -1 ulp, 3 hashed -1 / 0 / +1 */
+void po_set_trig_perturbation(int mode, unsigned seed);
 void po_pyr_up_16s(const int16_t* src, int w, int h, int cn, int16_t* dst); /* dst is exactly 2w x 2h */
 
 /* ---- misc imgproc used on the path */

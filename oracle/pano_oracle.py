@@ -113,6 +113,16 @@ def set_threads(n):
     lib().po_set_threads(int(n))
 
 
+def set_pyrdown32f_variant(vertical=0, vbody=8, horizontal=0, hbody=4):
+    """which association of cv::pyrDown CV_32F the oracle follows (pano_oracle.c): (0, *, 0, *) = scalar = the default"""
+    lib().po_set_pyrdown32f_variant(int(vertical), int(vbody), int(horizontal), int(hbody))
+
+
+def set_trig_perturbation(mode=0, seed=0):
+    """libm disagreement model for the projectors (0 none, 1 +1 ulp, 2 -1 ulp, 3 hashed -1/0/+1)"""
+    lib().po_set_trig_perturbation(int(mode), C.c_uint(int(seed)))
+
+
 def projector(kind, scale, K, R):
     p = Projector()
     K = _f9(K); R = _f9(R)

@@ -19,8 +19,17 @@
 //     prepare / feed / blend (Blender::NO below one band), convertTo(CV_8U), the cut;
 //   * src/stitching_detailed.cpp:841: ExposureCompensator::apply between warp and feed;
 //   * src/master.cpp:321-326: cv::resize of the upper panorama to the lower one's size, vconcat, the 10-row bar.
-// Inputs are the committed fixtures tests/golden/<prefix>_cam<i>.png + <prefix>_cams.json; outputs follow the schema of
-// tests/golden/<prefix>_golden.json (tests/golden/make_golden.py), with SHA-256 over the same bytes (BGR, row-major, tight).
+// Inputs are the committed fixtures tests/golden/<prefix>_cam<i>.png + <prefix>_cams.json.  Outputs, two kinds:
+//   (1) <prefix>_golden.json in the schema of tests/golden/<prefix>_golden.json (tests/golden/make_golden.py), with SHA-256 over the
+//       same bytes (BGR, row-major, tight) - small, comparable key by key;
+//   (2) EVERY STAGE AS RAW DATA: <out>/<group>/manifest.json + one .npy per array, in the schema of
+//       tests/pin_stages.py (compute_group names the arrays; groups c1, c1b, r0, r1, s0, s1, r_stack, s_stack): ROIs, the float maps
+//       of buildMaps, the warps, the NEAREST masks, the seam-scale frames / maps / warps / masks, both seam finders' masks, the blend
+//       masks, gain maps and gain-applied warps, cv::pyrDown / pyrUp CV_16S and cv::pyrDown CV_32F by themselves ("unit" stages: they
+//       tell WHICH association of the f32 sum this OpenCV build runs - scalar, SSE2, NEON, universal intrinsics), MultiBandBlender's
+//       accumulated Laplacian and weight pyramids (private members, read through #define private public), its result, the panoramas.
+//       tests/test_oracle.py::test_opencv_pin_files_when_present runs the oracle stage by stage ON THESE INPUTS and names the first
+//       stage that diverges.  A few hundred MB; commit the manifests and what you can, or keep them beside the run.
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -38,10 +47,13 @@
 #include <opencv2/core.hpp>
 #include <opencv2/imgcodecs.hpp>
 #include <opencv2/imgproc.hpp>
-#include <opencv2/stitching/detail/blenders.hpp>
-// BlocksGainCompensator keeps its gain maps private in 3.4 (getMatGains arrived in 4.x): the kit reads them as they are
+// BlocksGainCompensator keeps its gain maps private in 3.4 (getMatGains arrived in 4.x), MultiBandBlender its pyramids
+// (dst_pyr_laplace_, dst_band_weights_): the kit reads them as they are
 #define private public
+#define protected public
+#include <opencv2/stitching/detail/blenders.hpp>
 #include <opencv2/stitching/detail/exposure_compensate.hpp>
+#undef protected
 #undef private
 #include <opencv2/stitching/detail/seam_finders.hpp>
 #include <opencv2/stitching/detail/util.hpp>
@@ -269,6 +281,218 @@ Mat process(const Rig& g, const std::vector<Mat>& blend_mask, int bands, float s
 
 void save(const std::string& dir, const std::string& name, const Mat& m) { imwrite(dir + "/" + name + ".png", m); }
 
+// ---- raw stages: .npy files + manifest.json, the schema of tests/pin_stages.py -------------------------------------------------
+struct StageDir {
+    std::string dir, group;
+    std::ostringstream man;
+    bool first = true;
+    StageDir(const std::string& out, const std::string& g) : dir(out + "/" + g), group(g) {
+#ifdef _WIN32
+        const std::string cmd = "mkdir \"" + dir + "\"";
+#else
+        const std::string cmd = "mkdir -p \"" + dir + "\"";
+#endif
+        if (std::system(cmd.c_str()) != 0) { std::cerr << "cannot create " << dir << "\n"; std::exit(2); }
+    }
+    // NumPy format 1.0: magic, version, little-endian u16 header length, a Python dict literal padded with spaces to a multiple of
+    // 64 bytes and ended by a newline, then the array C-contiguous
+    void put(const std::string& name, const Mat& m_in) {
+        Mat m = m_in.isContinuous() ? m_in : m_in.clone();
+        const char* descr = nullptr;
+        const char* dtype = nullptr;
+        switch (m.depth()) {
+            case CV_8U: descr = "|u1"; dtype = "uint8"; break;
+            case CV_16S: descr = "<i2"; dtype = "int16"; break;
+            case CV_32S: descr = "<i4"; dtype = "int32"; break;
+            case CV_32F: descr = "<f4"; dtype = "float32"; break;
+            default: std::cerr << "stage " << name << ": depth " << m.depth() << " has no .npy form here\n"; std::exit(2);
+        }
+        std::ostringstream shape, jshape;
+        shape << "(" << m.rows << ", " << m.cols;
+        jshape << "[" << m.rows << ", " << m.cols;
+        if (m.channels() > 1) { shape << ", " << m.channels(); jshape << ", " << m.channels(); }
+        shape << ")"; jshape << "]";
+        std::string hdr = std::string("{'descr': '") + descr + "', 'fortran_order': False, 'shape': " + shape.str() + ", }";
+        while ((10 + hdr.size() + 1) % 64) hdr += ' ';
+        hdr += '\n';
+        std::string fn = name;
+        for (size_t p = 0; (p = fn.find('/', p)) != std::string::npos;) fn.replace(p, 1, "__");
+        fn += ".npy";
+        std::ofstream f((dir + "/" + fn).c_str(), std::ios::binary);
+        if (!f) { std::cerr << "cannot write " << dir << "/" << fn << "\n"; std::exit(2); }
+        const unsigned char magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
+        f.write((const char*)magic, 8);
+        const unsigned short hl = (unsigned short)hdr.size();
+        const unsigned char le[2] = {(unsigned char)(hl & 0xff), (unsigned char)(hl >> 8)};
+        f.write((const char*)le, 2);
+        f.write(hdr.data(), (std::streamsize)hdr.size());
+        f.write((const char*)m.data, (std::streamsize)(m.total() * m.elemSize()));
+        man << (first ? "" : ",\n") << "  \"" << name << "\": {\"file\": \"" << fn << "\", \"dtype\": \"" << dtype << "\", \"shape\": " << jshape.str() << "}";
+        first = false;
+    }
+    void put(const std::string& name, const UMat& u) { put(name, u.getMat(ACCESS_READ)); }
+    void finish() {
+        std::ofstream f((dir + "/manifest.json").c_str());
+        f << "{\n \"group\": \"" << group << "\",\n \"meta\": {\"generator\": \"tools/opencv_pin/pin.cpp\", \"opencv\": \"" << CV_VERSION << "\"},\n \"arrays\": {\n"
+          << man.str() << "\n }\n}\n";
+    }
+};
+
+struct Run {
+    std::string tag;
+    int seam;          // 0 graph cut, 1 Voronoi
+    int bands;         // >= 0, -1 Blender::NO, -2 from strength
+    float strength;
+    bool gains;
+    std::vector<int> cut;
+    bool levels;       // dump the blender's pyramids
+};
+
+// every stage of one fixture group, in the order and under the names of tests/pin_stages.py compute_group; returns the panoramas of
+// the runs (the rig's cut panorama is stacked by the caller)
+std::vector<Mat> dump_group(const std::string& out, const std::string& name, const Rig& g, const std::vector<Run>& runs) {
+    StageDir sd(out, name);
+    const int n = g.n;
+    auto cam = [](int i, const char* what) { return "cam" + std::to_string(i) + "/" + what; };
+    Ptr<RotationWarper> bw = make_warper(g.kind, g.scale);
+    // ocvstitcher.hpp:1054-1063 (warpRoi), :1171 (warp = buildMaps + remap), :1085 (mask warp)
+    Mat_<int> roi(n, 4);
+    std::vector<Point> corners(n);
+    std::vector<Size> sizes(n);
+    for (int i = 0; i < n; i++) {
+        const Rect r = bw->warpRoi(Size(g.w, g.h), g.K[i], g.R[i]);
+        roi(i, 0) = r.x; roi(i, 1) = r.y; roi(i, 2) = r.width; roi(i, 3) = r.height;
+        corners[i] = r.tl(); sizes[i] = r.size();
+    }
+    sd.put("roi", roi);
+    std::vector<Mat> warps(n), full_masks(n);
+    for (int i = 0; i < n; i++) {
+        Mat xmap, ymap;
+        bw->buildMaps(Size(g.w, g.h), g.K[i], g.R[i], xmap, ymap);
+        sd.put(cam(i, "xmap"), xmap); sd.put(cam(i, "ymap"), ymap);
+        bw->warp(g.frames[i], g.K[i], g.R[i], INTER_LINEAR, BORDER_REFLECT, warps[i]);
+        sd.put(cam(i, "warp"), warps[i]);
+        Mat mask(g.frames[i].size(), CV_8U, Scalar::all(255));
+        bw->warp(mask, g.K[i], g.R[i], INTER_NEAREST, BORDER_CONSTANT, full_masks[i]);
+        sd.put(cam(i, "full_mask"), full_masks[i]);
+    }
+    // initSeam / updateMask at the seam scale (ocvstitcher.hpp:988-1017, :1218-1243)
+    const double swa_d = std::min(1.0, std::sqrt(1e5 / ((double)g.h * g.w)));
+    Ptr<RotationWarper> sw = make_warper(g.kind, static_cast<float>(g.scale * swa_d));
+    std::vector<UMat> images_warped(n), masks_warped(n), images_warped_f(n);
+    std::vector<Point> scorners(n);
+    for (int i = 0; i < n; i++) {
+        Mat seamSized;
+        resize(g.frames[i], seamSized, Size(), swa_d, swa_d, INTER_LINEAR_EXACT);
+        sd.put(cam(i, "seam_frame"), seamSized);
+        Mat_<float> K = g.K[i].clone();
+        const float swa = (float)swa_d;
+        K(0, 0) *= swa; K(0, 2) *= swa; K(1, 1) *= swa; K(1, 2) *= swa;
+        Mat sx, sy;
+        sw->buildMaps(seamSized.size(), K, g.R[i], sx, sy);
+        sd.put(cam(i, "seam_xmap"), sx); sd.put(cam(i, "seam_ymap"), sy);
+        UMat m; m.create(seamSized.size(), CV_8U); m.setTo(Scalar::all(255));
+        scorners[i] = sw->warp(seamSized, K, g.R[i], INTER_LINEAR, BORDER_REFLECT, images_warped[i]);
+        sw->warp(m, K, g.R[i], INTER_NEAREST, BORDER_CONSTANT, masks_warped[i]);
+        images_warped[i].convertTo(images_warped_f[i], CV_32F);
+        sd.put(cam(i, "seam_warp"), images_warped[i]); sd.put(cam(i, "seam_mask_warp"), masks_warped[i]);
+    }
+    Mat_<int> sc(n, 2);
+    for (int i = 0; i < n; i++) { sc(i, 0) = scorners[i].x; sc(i, 1) = scorners[i].y; }
+    sd.put("seam_corners", sc);
+    bool need_gains = false;
+    for (const Run& r : runs) need_gains |= r.gains;
+    Ptr<ExposureCompensator> comp;
+    if (need_gains) {   // fed BEFORE the seam finder touches the masks (ocvstitcher.hpp:1031-1032)
+        comp = ExposureCompensator::createDefault(ExposureCompensator::GAIN_BLOCKS);
+        comp->feed(scorners, images_warped, masks_warped);
+    }
+    // both seam finders on copies of the NEAREST masks; dilate, resize, AND (ocvstitcher.hpp:1033-1035, :1097-1101)
+    std::vector<Mat> blend[2];   // [seam kind: 0 graph cut, 1 Voronoi]
+    const char* kname[2] = {"graphcut", "voronoi"};
+    for (int kind = 1; kind >= 0; kind--) {
+        std::vector<UMat> mv(n);
+        for (int i = 0; i < n; i++) masks_warped[i].copyTo(mv[i]);
+        Ptr<SeamFinder> finder;
+        if (kind == 0) finder = makePtr<detail::GraphCutSeamFinder>(GraphCutSeamFinderBase::COST_COLOR);
+        else finder = makePtr<detail::VoronoiSeamFinder>();
+        finder->find(images_warped_f, scorners, mv);
+        blend[kind].resize(n);
+        for (int i = 0; i < n; i++) {
+            sd.put(cam(i, (std::string(kname[kind]) + "_seam_mask").c_str()), mv[i]);
+            Mat dilated, seam_mask;
+            dilate(mv[i], dilated, Mat());
+            resize(dilated, seam_mask, full_masks[i].size(), 0, 0, INTER_LINEAR_EXACT);
+            blend[kind][i] = seam_mask & full_masks[i];
+            sd.put(cam(i, (std::string(kname[kind]) + "_blend_mask").c_str()), blend[kind][i]);
+        }
+    }
+    std::vector<Mat> gain_warps;
+    if (need_gains) {
+        BlocksGainCompensator* bc = dynamic_cast<BlocksGainCompensator*>(comp.get());
+        gain_warps.resize(n);
+        for (int i = 0; i < n; i++) {
+            sd.put(cam(i, "gain_map"), bc->gain_maps_[i]);
+            gain_warps[i] = warps[i].clone();
+            comp->apply(i, corners[i], gain_warps[i], full_masks[i]);   // src/stitching_detailed.cpp:841
+            sd.put(cam(i, "warp_gain"), gain_warps[i]);
+        }
+    }
+    // the pyramid primitives by themselves, on real data
+    {
+        Mat u_in, down, up;
+        warps[0].convertTo(u_in, CV_16S);
+        pyrDown(u_in, down);
+        pyrUp(down, up);
+        sd.put("unit/pyrdown16s_in", u_in); sd.put("unit/pyrdown16s_out", down); sd.put("unit/pyrup16s_out", up);
+        Mat wm, nx;
+        blend[runs[0].seam][0].convertTo(wm, CV_32F, 1. / 255.);   // MultiBandBlender::feed's weight map (blenders.cpp)
+        sd.put("unit/pyrdown32f_in", wm);
+        for (int l = 1; l <= 3; l++) {
+            pyrDown(wm, nx);
+            sd.put("unit/pyrdown32f_l" + std::to_string(l), nx);
+            wm = nx.clone();
+        }
+    }
+    // process() per run (ocvstitcher.hpp:1141-1216)
+    std::vector<Mat> panos;
+    for (const Run& r : runs) {
+        const std::string pre = "blend_" + r.tag + "/";
+        const Rect full = resultRoi(corners, sizes);
+        int nb = r.bands;
+        if (r.bands == -2) {
+            const float blend_width = std::sqrt(static_cast<float>(full.size().area())) * r.strength / 100.f;
+            nb = blend_width < 1.f ? -1 : static_cast<int>(std::ceil(std::log(blend_width) / std::log(2.)) - 1.);
+        }
+        Ptr<Blender> blender;
+        if (nb < 0) blender = Blender::createDefault(Blender::NO, false);
+        else blender = makePtr<MultiBandBlender>(false, nb);
+        blender->prepare(corners, sizes);
+        for (int i = 0; i < n; i++) {
+            Mat s16;
+            (r.gains ? gain_warps[i] : warps[i]).convertTo(s16, CV_16S);
+            blender->feed(s16, blend[r.seam][i], corners[i]);
+        }
+        if (r.levels && nb >= 0) {
+            MultiBandBlender* mb = dynamic_cast<MultiBandBlender*>(blender.get());
+            for (int l = 0; l <= mb->numBands(); l++) {
+                sd.put(pre + "laplace_l" + std::to_string(l), mb->dst_pyr_laplace_[l]);
+                sd.put(pre + "weights_l" + std::to_string(l), mb->dst_band_weights_[l]);
+            }
+        }
+        Mat result, result_mask, pano;
+        blender->blend(result, result_mask);
+        sd.put(pre + "result", result); sd.put(pre + "result_mask", result_mask);
+        result.convertTo(pano, CV_8U);
+        if (r.cut.size() == 4) pano = pano(Rect(r.cut[0], r.cut[1], r.cut[2], r.cut[3])).clone();
+        sd.put(pre + "pano", pano);
+        panos.push_back(pano);
+    }
+    sd.finish();
+    std::cout << name << ": " << "raw stages written\n";
+    return panos;
+}
+
 // config 1 / 1b: 4 x 480 x 270 under one shared K (tests/golden/make_golden.py group_480)
 void group_480(const std::string& in, const std::string& out, const std::string& prefix, bool all_bands) {
     const std::string js = slurp(in + "/" + prefix + "_cams.json");
@@ -278,6 +502,19 @@ void group_480(const std::string& in, const std::string& out, const std::string&
         g.K.push_back(mat3(K.data())); g.R.push_back(mat3(R.data() + 9 * i));
         g.frames.push_back(imread(in + "/" + prefix + "_cam" + std::to_string(i) + ".png", IMREAD_COLOR));
         if (g.frames.back().empty()) { std::cerr << "missing frame\n"; std::exit(2); }
+    }
+    {   // every stage as raw data (tests/pin_stages.py load_groups: the same runs under the same tags)
+        std::vector<Run> runs;
+        if (all_bands) {
+            runs.push_back(Run{"bNO", 1, -1, 0.f, false, {}, false});
+            runs.push_back(Run{"b0", 1, 0, 0.f, false, {}, false});
+            runs.push_back(Run{"b2", 1, 2, 0.f, false, {}, false});
+        }
+        runs.push_back(Run{"b4", 1, 4, 0.f, false, {}, true});
+        if (all_bands) runs.push_back(Run{"b2cut", 1, 2, 0.f, false, {100, 20, 1000, 200}, false});
+        runs.push_back(Run{"gc4", 0, 4, 0.f, false, {}, false});
+        runs.push_back(Run{"gain4", 1, 4, 0.f, true, {}, false});
+        dump_group(out, prefix, g, runs);
     }
     Json j;
     std::vector<Mat> vor = blend_masks(g, 1);
@@ -341,7 +578,7 @@ void rig(const std::string& in, const std::string& out, const std::string& prefi
     const std::string js = slurp(in + "/" + prefix + "_cams.json");
     const int W = (int)numbers_after(js, "width")[0], H = (int)numbers_after(js, "height")[0];
     std::ostringstream st; st << "[";
-    std::vector<Mat> halves;
+    std::vector<Mat> halves, raw_halves;
     size_t pos = js.find("\"stitchers\"");
     for (int s = 0; s < 2; s++) {
         size_t e1 = 0, e2 = 0;
@@ -355,6 +592,7 @@ void rig(const std::string& in, const std::string& out, const std::string& prefi
             if (g.frames.back().empty()) { std::cerr << "missing frame\n"; std::exit(2); }
         }
         const std::vector<int> cut = {(int)cutd[0], (int)cutd[1], (int)cutd[2], (int)cutd[3]};
+        raw_halves.push_back(dump_group(out, prefix + std::to_string(s), g, {Run{"rig", 0, -2, 1.0f, false, cut, true}})[0]);
         std::vector<Mat> gc = blend_masks(g, 0);
         int bands = 0; std::vector<Rect> rois; Rect full;
         Mat pano = process(g, gc, -2, 1.0f, nullptr, cut, &bands, &rois, &full);   // stitcherBlenderStrength: 1 (cfg/stitcher-imx390cfg.yaml:49)
@@ -372,6 +610,15 @@ void rig(const std::string& in, const std::string& out, const std::string& prefi
     cv::vconcat(up, halves[1], ret);
     cv::rectangle(ret, cv::Rect(0, ret.rows / 2 - 5, ret.cols, 10), cv::Scalar(0, 0, 0), -1);
     save(out, prefix + "_stacked", ret);
+    {
+        Mat up2, ret2;
+        cv::resize(raw_halves[0], up2, raw_halves[1].size());
+        cv::vconcat(up2, raw_halves[1], ret2);
+        cv::rectangle(ret2, cv::Rect(0, ret2.rows / 2 - 5, ret2.cols, 10), cv::Scalar(0, 0, 0), -1);
+        StageDir sd(out, prefix + "_stack");
+        sd.put("stacked", ret2);
+        sd.finish();
+    }
     Json j;
     j.raw("stitchers", st.str());
     j.str("stack_master_sha256", sha(ret));
