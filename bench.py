@@ -476,11 +476,22 @@ def main():
         roofline = None
         stage_ms, stage_n = fold(stats_timed if stats_timed is not None else [c.stage_stats(reset=True) for c in ctxs])
         if world == 1 and stage_n[0]:
-            traffic = None
+            # HBM traffic of the K1 launch from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/warp_traffic.json): a figure of
+            # the build it was collected on.  It is printed only when that build's kernel sources are the ones this library was made
+            # from (pano_kernel_source_id) and the run is the profiled configuration; otherwise null, with the reason beside it
+            traffic, traffic_note = None, None
+            kid = pano.kernel_source_id()
             tp = os.path.join(ROOT, "profiles", "warp_traffic.json")
             if os.path.exists(tp):
                 try:
-                    traffic = json.load(open(tp)).get("hbm_bytes_per_launch_8cam")
+                    tj = json.load(open(tp))
+                    cur = tj.get("current", {})
+                    if cur.get("kernel_source_id") != kid:
+                        traffic_note = "profiles/warp_traffic.json was collected on kernel sources %s, this library is %s: re-run tools/pmc_traffic_all.sh" % (cur.get("kernel_source_id"), kid)
+                    elif args.bands != 5 or (W, H) != (1920, 1080):
+                        traffic_note = "the counters were collected on the default configuration (5 bands, 1920x1080)"
+                    else:
+                        traffic = cur.get("hbm_bytes_per_launch_8cam")
                 except Exception:
                     traffic = None
             # the kernel's roofline fraction is taken where its launches have the GPU to themselves (one frame at a
@@ -518,7 +529,7 @@ def main():
             lead = cold if cold is not None else alone
             roofline = {"kernel": "warp_tiles_lut_kernel", "bound": "hbm", "achieved": lead["achieved"],
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lead["frac"],
-                        "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                        "traffic": traffic, "traffic_note": traffic_note, "kernel_source_id": kid, "algorithmic_bytes_per_launch": alg_bytes,
                         "avg_launch_us": lead["avg_launch_us"], "launches_per_step": launches_per_step,
                         "measured": ("K steps, one frame at a time over %d rotating frame sets (larger than the 256 MiB Infinity Cache: no "
                                      "launch finds its frames where an earlier one left them), dispatch events of the kernel" % cold_sets)
@@ -528,35 +539,45 @@ def main():
                         "one_frame_at_a_time_panoramas_per_s": alone_rate,
                         "one_frame_at_a_time_stage_us": alone_stage,
                         "cold": cold, "blend_level0": blend0}
-            # also against a measured device-copy ceiling - a 256 MB device-to-device copy (bytes read + written)
+            # also against measured device-copy ceilings - the library's own probes (pano_probe_copy), with
+            # the launch and timing machinery of its kernels: a float4 grid-stride copy of 512 MiB (what the part streams), and a copy
+            # with K1's traffic SHAPE and SIZE (direct-to-LDS box + table in, one dword per lane and plane out, as many workgroups as K1
+            # has live patches) warm and over rotating buffers - what a kernel launched like K1 can reach at all
             try:
-                x = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
-                y = torch.empty_like(x)
-                for _ in range(3):
-                    y.copy_(x)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(10):
-                    y.copy_(x)
-                e1.record()
-                torch.cuda.synchronize()
-                copy_gbs = 2 * x.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-                roofline["device_copy_ceiling_GBps"] = round(copy_gbs, 1)
-                roofline["frac_of_copy_ceiling"] = round(lead["achieved"] / copy_gbs, 4)
-                # the whole frame in the timed region: every kernel's HBM traffic (PMC passes, profiles/) over the time of a step
-                fp = os.path.join(ROOT, "profiles", "r04_hbm_bytes_per_kernel_per_frame.json")
-                if os.path.exists(fp):
-                    fb = float(json.load(open(fp)).get("_total_hbm_MB_per_frame", 0.0)) * 1e6
-                    if fb > 0:
+                C_ = pano.Context
+                f4 = max(ctxs[0].probe_copy(C_.PROBE_COPY_F4, 512 << 20, sets=1, reps=20)["GBps"],
+                         ctxs[0].probe_copy(C_.PROBE_COPY_F4_FLAT, 512 << 20, sets=1, reps=20)["GBps"])
+                nwg = int(sum(c.warp_table_stats()["blocks"] for c in ctxs) * 0.70) or 9300   # live share of the 64 x 16 patches (config 2: 70 %)
+                per = nwg * (4608 + 2048 + 3072)
+                kw = ctxs[0].probe_copy(C_.PROBE_COPY_K1_SHAPE, nwg, sets=1, reps=100)
+                kc = ctxs[0].probe_copy(C_.PROBE_COPY_K1_SHAPE, nwg, sets=max(2, -(-(320 << 20) // per)), reps=100)
+                copy_gbs = f4
+                roofline["device_copy_ceiling_GBps"] = round(f4, 1)
+                roofline["frac_of_copy_ceiling"] = round(lead["achieved"] / f4, 4)
+                roofline["k1_shaped_copy"] = {
+                    "workgroups": nwg, "bytes_per_launch": int(kw["bytes_per_launch"]),
+                    "warm": {"us_per_launch": round(kw["us_per_launch"], 2), "GBps": round(kw["GBps"], 1)},
+                    "cold": {"us_per_launch": round(kc["us_per_launch"], 2), "GBps": round(kc["GBps"], 1)},
+                    "k1_us_over_copy_us": {"warm": round(alone["avg_launch_us"] / kw["us_per_launch"], 3),
+                                           "cold": round(lead["avg_launch_us"] / kc["us_per_launch"], 3) if cold is not None else None},
+                    "note": "a copy with K1's traffic shape, size and launch shape and none of its arithmetic (pano_probe.hip): the time K1 "
+                            "cannot beat without moving fewer bytes"}
+                # the whole frame in the timed region: every kernel's HBM traffic (PMC passes, profiles/) over the time of a step - only
+                # for the configuration and the kernel sources the counters were collected on
+                fp = os.path.join(ROOT, "profiles", "hbm_bytes_per_kernel_per_frame.json")
+                if os.path.exists(fp) and args.bands == 5 and (W, H) == (1920, 1080):
+                    fj = json.load(open(fp))
+                    fb = float(fj.get("_total_hbm_MB_per_frame", 0.0)) * 1e6
+                    if fb > 0 and fj.get("kernel_source_id") == kid:
                         fr_gbs = fb / (dt / args.steps) / 1e9
                         roofline["frame_in_timed_region"] = {
                             "hbm_traffic_bytes_per_step": int(fb), "us_per_step": round(dt / args.steps * 1e6, 2), "achieved_GBps": round(fr_gbs, 1),
                             "frac_of_peak": round(fr_gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(fr_gbs / copy_gbs, 4),
                             "algorithmic_bytes_per_step": int(NG * NC * W * H * 3 + NG * ow * oh * 3),
-                            "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of all nine launches of a frame, separate --pmc passes (profiles/r04_hbm_bytes_per_kernel_per_frame.json); algorithmic = the frames in + the panoramas out"}
-                del x, y
-            except Exception:  # the side measurement never breaks the line
-                pass
+                            "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of all launches of a frame, separate --pmc passes (profiles/hbm_bytes_per_kernel_per_frame.json, "
+                                    "same kernel sources, same configuration); algorithmic = the frames in + the panoramas out"}
+            except Exception as exc:  # the side measurement never breaks the line
+                roofline["device_copy_ceiling_error"] = repr(exc)[:200]
         if world > 1 and stage_n[0]:
             # N > 1: rank 0's own K1 launches (its cameras of each group, one launch per group it feeds), taken from the
             # event pass; the algorithmic bytes are its cameras' share of the group's
@@ -576,9 +597,10 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8/int16 fixed-point (f32 weights)",
             "data": "synthetic",
-            "config": {"workload": "C2: 8x1920x1080 BGR8 frames resident in HBM (device pointers in, device panoramas out: no PCIe in the "
-                                   "timed region; the link-inclusive rate is `h2d_inclusive`) -> 2 groups x 4 cameras, spherical warp + %d-band "
-                                   "multi-band blend, Voronoi seams, pano 2 x %dx%d" % (args.bands, ow, oh),
+            "config": {"workload": "C2: 8x1920x1080 BGR8 frames resident in HBM, THE SAME frames every step (device pointers in, device panoramas "
+                                   "out: no PCIe in the timed region; over rotating frame sets the rate is `rotating_inputs_panoramas_per_s`%s, with the "
+                                   "host link in the loop `h2d_inclusive`) -> 2 groups x 4 cameras, spherical warp + %d-band "
+                                   "multi-band blend, Voronoi seams, pano 2 x %dx%d" % ((" = %.0f" % rotating_rate) if rotating_rate else "", args.bands, ow, oh),
                        "parallelism": ("single GPU, %d frames in flight on %d distinct hardware queues (pano_frame_streams)" % (F, flight_distinct)) if world == 1 else
                                       ("cameras sharded %d/rank, %s" % (per_rank,
                                                                           "every rank composes whole stitchers; the finished half panoramas move to rank 0 (torch.distributed send / recv)"
@@ -608,12 +630,21 @@ def main():
                     mg["rccl_ranks"] = None
             if gather_events:
                 us = [a.elapsed_time(b) * 1e3 for a, b in gather_events]
-                recv_bytes = sum(cnt for pl, (_, slot) in zip(plans, slot_views) for (_, _, n_) in pl["moves"] for cnt in [n_ * slot])
+                if exchange["kind"] == "cabi":
+                    # the C-ABI exchange moves the live rectangles of every level, packed (pano_get_exchange_stats), not whole slots
+                    recv_bytes = 0
+                    for grp, pl in enumerate(plans):
+                        pk = ctxs[grp].exchange_stats()["packed_bytes_per_camera"]
+                        recv_bytes += sum(sum(pk[first:first + n_]) for (_, first, n_) in pl["moves"])
+                else:
+                    recv_bytes = sum(cnt for pl, (_, slot) in zip(plans, slot_views) for (_, _, n_) in pl["moves"] for cnt in [n_ * slot])
                 senders = sum(len(pl["moves"]) for pl in plans)
                 mean_us = sum(us) / len(us)
                 per_group = recv_bytes / max(1, sum(1 for pl in plans if pl["moves"]))
                 mg.update({"gather_us_mean": round(mean_us, 1), "gather_bytes_per_group": int(per_group), "senders_per_step": senders,
                            "root_ingress_GBps": round(per_group / mean_us / 1e3, 2),
+                           "whole_slot_bytes_per_group": int(sum(n_ * slot for pl, (_, slot) in zip(plans, slot_views) for (_, _, n_) in pl["moves"]) /
+                                                             max(1, sum(1 for pl in plans if pl["moves"]))),
                            "note": "events on rank 0's launch stream around its side of the exchange (one ncclGroup per stitcher); "
                                    "includes waiting for the senders' warps"})
             if per_rank_warp:

@@ -75,9 +75,15 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     lib.pano_last_error.restype = C.c_char_p
     lib.pano_version.restype = C.c_char_p
+    lib.pano_kernel_source_id.restype = C.c_char_p
     lib.pano_last_error.argtypes = [C.c_void_p]
     _lib = lib
     return lib
+
+
+def kernel_source_id():
+    """16 hex digits naming the device code the loaded library was built from (pano_kernel_source_id)"""
+    return load_library().pano_kernel_source_id().decode()
 
 
 # every symbol include/pano.h declares (checked by tests/test_abi.py against the header text)
@@ -91,7 +97,7 @@ EXPORTS = [
     "pano_compose_host", "pano_host_alloc", "pano_host_free", "pano_compose_pair", "pano_set_frame_slots", "pano_select_frame_slot", "pano_feed_cameras", "pano_get_pyramid_slots", "pano_blend", "pano_feed_cameras_host", "pano_blend_host", "pano_rccl_unique_id", "pano_rccl_comm_create", "pano_rccl_comm_destroy", "pano_gather_slots", "pano_rccl_comm_count", "pano_rccl_library", "pano_stack_master", "pano_stack_finalcut", "pano_stack_master_host", "pano_stack_finalcut_host", "pano_stream_input", "pano_stream_output",
     "pano_stream_submit", "pano_stream_wait", "pano_set_profiling",
     "pano_get_stage_ms", "pano_get_stage_stats", "pano_get_warp_bytes", "pano_get_live_rect", "pano_get_source_rect", "pano_get_live_gap", "pano_get_warp_table_stats", "pano_debug_get_level", "pano_debug_get_weights",
-    "pano_debug_get_canvas_weights", "pano_debug_get_canvas",
+    "pano_debug_get_canvas_weights", "pano_debug_get_canvas", "pano_probe_copy", "pano_kernel_source_id", "pano_get_exchange_stats",
 ]
 
 
@@ -498,6 +504,20 @@ class Context:
         a = C.c_uint64(); nb = C.c_uint64(); nf = C.c_uint64()
         self._ck(self.lib.pano_get_warp_table_stats(self.h, C.byref(a), C.byref(nb), C.byref(nf)))
         return {"table_bytes": a.value, "blocks": nb.value, "blocks_checked": nf.value}
+
+    def exchange_stats(self):
+        """what pano_gather_slots moves: {"packed_bytes_per_camera": [...], "slot_bytes", "bytes_moved"}"""
+        per = (C.c_uint64 * self.n)(); sb = C.c_uint64(); mv = C.c_uint64()
+        self._ck(self.lib.pano_get_exchange_stats(self.h, per, C.byref(sb), C.byref(mv)))
+        return {"packed_bytes_per_camera": [int(v) for v in per], "slot_bytes": int(sb.value), "bytes_moved": int(mv.value)}
+
+    PROBE_COPY_F4, PROBE_COPY_K1_SHAPE, PROBE_COPY_F4_FLAT = 0, 1, 2
+
+    def probe_copy(self, kind, units, sets=1, reps=50):
+        """device-copy ceiling measured by the library (pano_probe_copy): {"GBps", "us_per_launch", "bytes_per_launch"}"""
+        g = C.c_double(); us = C.c_double(); b = C.c_uint64()
+        self._ck(self.lib.pano_probe_copy(self.h, int(kind), C.c_uint64(int(units)), int(sets), int(reps), C.byref(g), C.byref(us), C.byref(b)))
+        return {"GBps": g.value, "us_per_launch": us.value, "bytes_per_launch": b.value}
 
     # -- stage inspection
     def debug_level(self, i, level):

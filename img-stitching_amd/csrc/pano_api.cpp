@@ -45,6 +45,8 @@ void free_device(pano_ctx* c) {
         dfree(c->stage_in[i]);
         for (int l = 0; l < kMaxLevels; l++) dfree(c->wgt[i][l]);
     }
+    dfree(c->d_xch_segs); dfree(c->xch_stage);
+    c->xch_stage_bytes = 0; c->xch_dirty = true; c->xch_segs.clear();
     for (int l = 0; l < kOrderLevels; l++) {
         dfree(c->order[l]);
         c->order_cap[l] = 0;
@@ -249,6 +251,7 @@ void live_rects(pano_ctx* c, const std::vector<std::vector<uint8_t>>& masks) {
             for (int k = 0; k < 2; k++) c->pyr.cam[i].gap[l][k] = c->gap[i][l][k];
         }
     live_source_rects(c);
+    c->xch_dirty = true;   // the sharded exchange packs these rectangles (pano_gather_slots)
 }
 
 
@@ -460,7 +463,7 @@ pano_status ensure_weights(pano_ctx* c, hipStream_t s) {
                               c->mask0[i], c->lvl_pitch[i][0], t.rect.w, t.rect.h, s);
         for (int l = 0; l < P.bands; l++)
             launch_pyr_down_f32(c->wgt[i][l], t.rect.w >> l, t.rect.h >> l, c->wpitch[i][l], c->wgt[i][l + 1],
-                                c->wpitch[i][l + 1], s);
+                                c->wpitch[i][l + 1], c->f32_order, s);
     }
     // the summed canvas weights are not read by the blend (it re-adds the same f32 terms in the same
     // order); they are kept for stage inspection
@@ -810,6 +813,19 @@ static pano_status prepare_impl(pano_ctx* c) {
         if (k >= 1 && P.bands - k + 1 >= 2) c->cv.small_base = k;
     }
     c->full_tiles = getenv("PANO_FULL_TILES") && atoi(getenv("PANO_FULL_TILES"));
+    c->xch_whole_slots = getenv("PANO_GATHER_WHOLE_SLOTS") && atoi(getenv("PANO_GATHER_WHOLE_SLOTS"));
+    // the association of cv::pyrDown CV_32F the blend weights follow: "vertical,vbody,horizontal,hbody" (default: scalar order, what
+    // an OpenCV build without SIMD computes; the day the pin kit says which build the reference's results come from, this is where
+    // the product follows it - tests/pin_stages.py PYRDOWN32F_VARIANTS names the forms)
+    c->f32_order = F32Order{};
+    if (const char* fo = getenv("PANO_PYRDOWN32F_ORDER")) {
+        int v[4] = {0, 8, 0, 4};
+        if (sscanf(fo, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) >= 1 && v[0] >= 0 && v[0] <= 2 && v[2] >= 0 && v[2] <= 2 && v[1] >= 1 && v[1] <= 64 &&
+            v[3] >= 1 && v[3] <= 64)
+            c->f32_order = F32Order{v[0], v[1], v[2], v[3]};
+        else
+            return fail(c, PANO_EINVAL, "PANO_PYRDOWN32F_ORDER wants vertical,vbody,horizontal,hbody with vertical, horizontal in 0..2 and bodies in 1..64");
+    }
     // level 0 walks its tiles seam tiles first, with the owner codes of their waves in the order table (A/B lever; PANO_L0_ORDER=0:
     // plain XCD-band order, every wave looks its owners up; no result changes)
     c->l0_order = !(getenv("PANO_L0_ORDER") && atoi(getenv("PANO_L0_ORDER")) == 0);
@@ -1126,8 +1142,7 @@ pano_status pano_compose(pano_ctx* c, const uint8_t* const* d_frames, const size
 
 pano_status pano_debug_graphcut_dump(pano_ctx* c, const char* path) {
     if (!c) return PANO_EINVAL;
-    c->gc_dump_path = path ? path : "";
-    return PANO_OK;
+    return guarded(c, [&]() { c->gc_dump_path = path ? path : ""; return PANO_OK; });  // the assignment allocates
 }
 
 pano_status pano_debug_graph_stats(const pano_ctx* c, int* graphs_held, uint64_t* replays) {
@@ -1314,6 +1329,98 @@ pano_status pano_get_warp_table_stats(const pano_ctx* c, uint64_t* table_bytes, 
     return PANO_OK;
 }
 
+// Device-copy ceilings, measured in the library with the kernels' own launch and timing machinery (per-launch begin / end events of
+// hipExtLaunchKernelGGL - the interval rocprofv3 reports per dispatch).  `sets` rotating buffer sets: with sets x the bytes of one
+// launch above the 256 MiB Infinity Cache no launch finds its input where an earlier one left it (the COLD figure K1's roofline leads
+// with); sets = 1 is the warm figure.
+static pano_status probe_copy_impl(pano_ctx* c, int kind, uint64_t units, int sets, int reps, double* gbps, double* us, uint64_t* bytes_moved) {
+    pano_status st = check_compute(c);
+    if (st != PANO_OK) return st;
+    if ((kind != PANO_PROBE_COPY_F4 && kind != PANO_PROBE_COPY_K1_SHAPE && kind != PANO_PROBE_COPY_F4_FLAT) || units == 0 || sets < 1 || sets > 64 || reps < 1 || reps > 4096 ||
+        !gbps || !us)
+        return PANO_EINVAL;
+    size_t in_bytes, out_bytes, tab_bytes = 0;
+    const bool f4 = kind == PANO_PROBE_COPY_F4 || kind == PANO_PROBE_COPY_F4_FLAT;
+    if (f4) {
+        in_bytes = out_bytes = (size_t)((units + 15) / 16 * 16);
+    } else {
+        if (units > (1u << 22)) return PANO_EINVAL;
+        in_bytes = (size_t)units * kProbeBoxBytes + 1024;  // the last workgroup's surplus lanes re-read its last chunk only
+        tab_bytes = (size_t)units * 256 * 8;
+        out_bytes = (size_t)units * 3072;
+    }
+    if ((in_bytes + tab_bytes + out_bytes) * (size_t)sets > ((size_t)6 << 30)) return PANO_EINVAL;
+    std::vector<void*> in(sets, nullptr), tab(sets, nullptr), out(sets, nullptr);
+    std::vector<hipEvent_t> ev;
+    hipStream_t s = c->own_stream;
+    auto cleanup = [&]() {
+        for (void* p : in) if (p) (void)hipFree(p);
+        for (void* p : tab) if (p) (void)hipFree(p);
+        for (void* p : out) if (p) (void)hipFree(p);
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    };
+    hipError_t err = hipSuccess;
+#define PROBE_TRY(expr)                         \
+    do {                                        \
+        if ((err = (expr)) != hipSuccess) {     \
+            cleanup();                          \
+            return fail(c, PANO_EHIP, #expr);   \
+        }                                       \
+    } while (0)
+    for (int k = 0; k < sets; k++) {
+        PROBE_TRY(hipMalloc(&in[k], in_bytes));
+        PROBE_TRY(hipMalloc(&out[k], out_bytes));
+        PROBE_TRY(hipMemsetAsync(in[k], 0x5a, in_bytes, s));
+        PROBE_TRY(hipMemsetAsync(out[k], 0, out_bytes, s));
+        if (tab_bytes) {
+            PROBE_TRY(hipMalloc(&tab[k], tab_bytes));
+            PROBE_TRY(hipMemsetAsync(tab[k], 0x33, tab_bytes, s));
+        }
+    }
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int blocks = cus * 8;  // 8 workgroups of 4 waves per CU: every wave slot taken
+    const int warm = std::max(2 * sets, 4);
+    ev.resize(2 * (size_t)reps, nullptr);
+    for (auto& e : ev) PROBE_TRY(hipEventCreate(&e));
+    for (int k = 0; k < warm + reps; k++) {
+        const int b = k % sets;
+        hipEvent_t e0 = k >= warm ? ev[2 * (size_t)(k - warm)] : nullptr, e1 = k >= warm ? ev[2 * (size_t)(k - warm) + 1] : nullptr;
+        if (f4) launch_probe_copy_f4(in[b], out[b], in_bytes, kind == PANO_PROBE_COPY_F4 ? blocks : 0, s, e0, e1);
+        else launch_probe_copy_k1_shape(in[b], tab[b], out[b], (unsigned)units, s, e0, e1);
+    }
+    PROBE_TRY(hipGetLastError());
+    PROBE_TRY(hipStreamSynchronize(s));
+    double total_ms = 0.0;
+    for (int k = 0; k < reps; k++) {
+        float ms = 0.f;
+        PROBE_TRY(hipEventElapsedTime(&ms, ev[2 * (size_t)k], ev[2 * (size_t)k + 1]));
+        total_ms += ms;
+    }
+#undef PROBE_TRY
+    cleanup();
+    const uint64_t moved = f4 ? (uint64_t)in_bytes * 2 : (uint64_t)units * (kProbeBoxBytes + 2048 + 3072);
+    *us = total_ms / reps * 1e3;
+    *gbps = (double)moved / (*us * 1e-6) / 1e9;
+    if (bytes_moved) *bytes_moved = moved;
+    return PANO_OK;
+}
+pano_status pano_probe_copy(pano_ctx* c, int kind, uint64_t units, int sets, int reps, double* gbps, double* us_per_launch, uint64_t* bytes_moved) {
+    return guarded(c, [&]() { return probe_copy_impl(c, kind, units, sets, reps, gbps, us_per_launch, bytes_moved); });
+}
+
+// the identity of the device code this library was built from: the first 16 hex digits of the SHA-256 over the kernel sources
+// (csrc/*.hip, pano_dev.hpp, pano_kernels.hpp), computed by the Makefile.  profiles/warp_traffic.json records the id its counters
+// were taken with; bench.py prints a counter figure only beside the id it belongs to.
+const char* pano_kernel_source_id(void) {
+#ifdef PANO_KERNEL_SOURCE_ID
+    return PANO_KERNEL_SOURCE_ID;
+#else
+    return "unknown";
+#endif
+}
+
 pano_status pano_get_source_rect(const pano_ctx* c, int i, int rect[4]) {
     if (!c || !c->prepared || !rect || i < 0 || i >= c->plan.n) return PANO_EINVAL;
     const pano_ctx::SrcRect& r = c->src_rect[i];
@@ -1450,30 +1557,41 @@ static pano_status frame_streams_impl(pano_ctx* c, int n, void** streams, int* d
         for (hipStream_t fs : c->flight_streams) (void)hipStreamDestroy(fs);
         c->flight_streams.clear();
         constexpr double kSpinUs = 150.0;
+        // < 0: the probe itself failed (a launch or a wait returned an error, or the pair came back faster than ONE spin can -
+        // the kernels did not run): such a pair is never counted as overlapping
         auto pair_us = [&](hipStream_t a, hipStream_t b) {
             double best = 1e30;
             for (int rep = 0; rep < 2; rep++) {
-                (void)hipStreamSynchronize(a);
-                (void)hipStreamSynchronize(b);
+                if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1.0;
                 const auto t0 = std::chrono::steady_clock::now();
                 launch_spin((unsigned long long)(kSpinUs * 100.0), a);
                 launch_spin((unsigned long long)(kSpinUs * 100.0), b);
-                (void)hipStreamSynchronize(a);
-                (void)hipStreamSynchronize(b);
+                if (hipGetLastError() != hipSuccess) return -1.0;
+                if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1.0;
                 best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
             }
-            return best;
+            return best < 0.8 * kSpinUs ? -1.0 : best;
         };
         std::vector<hipStream_t> rejects;
+        bool probe_failed = false;
         for (int tries = 0; tries < 6 * n + 8 && (int)c->flight_streams.size() < n; tries++) {
             hipStream_t cand = nullptr;
             if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
             launch_spin(100ull, cand);  // first use: the queue is bound (and the kernel's code loaded) before anything is timed
-            (void)hipStreamSynchronize(cand);
-            bool alone = true;
-            for (hipStream_t taken : c->flight_streams)
-                if (pair_us(taken, cand) > 1.6 * kSpinUs) { alone = false; break; }
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(cand) != hipSuccess) probe_failed = true;
+            bool alone = !probe_failed || c->flight_streams.empty();
+            for (hipStream_t taken : c->flight_streams) {
+                if (probe_failed) break;
+                const double us = pair_us(taken, cand);
+                if (us < 0.0) { probe_failed = true; alone = false; break; }
+                if (us > 1.6 * kSpinUs) { alone = false; break; }
+            }
             (alone ? c->flight_streams : rejects).push_back(cand);
+        }
+        if (probe_failed) {
+            // nothing was measured: the streams still work, but nothing is known about their queues - say one, not n
+            (void)hipGetLastError();
+            while ((int)c->flight_streams.size() > 1) { rejects.push_back(c->flight_streams.back()); c->flight_streams.pop_back(); }
         }
         c->flight_distinct = (int)c->flight_streams.size();
         // fewer hardware queues than streams asked for: the rest share (they work, they do not overlap)

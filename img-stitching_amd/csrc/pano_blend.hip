@@ -263,7 +263,8 @@ __device__ __forceinline__ void store_block(const BlendLevel& C, int l, int X0, 
                 pk.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
                 pk.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
                 pk.z = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
-                // non-temporal: nothing on the device reads the panorama back, and without the hint its 23 MB per frame pair push
+                // non-temporal (a cache hint only): nothing in the FRAME reads the panorama back (pano_stack_* and the D2H copy do, later and
+                // once), and without the hint its 23 MB per frame pair push
                 // the pyramids of the frames in flight out of the caches (-1.0 to -1.9 us per frame with four in flight; the same
                 // hint on stores that ARE read back - G0, the pyramid levels, the canvas - or on any load of this kernel costs
                 // 1 to 8 us: docs/EXPERIMENTS.md, round 4)
@@ -612,7 +613,10 @@ struct BlendOrderedArgs {  // the kernel's argument list as the kernarg segment 
     PyrParams P;
     CanvasSet CS;
 };
-// L0 (NPL 3): 5 waves / SIMD = at most 96 VGPRs (the allocator stopped at 97: a granule more, and a wave less).
+// L0 (NPL 3): 5 waves / SIMD = at most 96 VGPRs (the allocator stops at 97 - 99 uncapped: a granule more, and a wave less - and puts ONE
+// dword of the seam path, 5 % of the waves, in scratch: two stores and a load per seam lane.  Round 5 tried to take that dword out -
+// finished samples packed to bytes as they appear, the coarse canvas windows loaded plane by plane, the weights converted where they
+// are used, scheduling barriers between the planes: the allocator lands on 97 every time; without its seam path the kernel needs 84).
 // Levels >= 1 (NPL 1): one plane per lane, l = the level.
 template <bool L0, int NPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(L0 ? 5 : 8, 8))) void blend_level_ordered_kernel(

@@ -17,10 +17,6 @@ bool parse_floats(const std::string& s, std::vector<float>& out) {
     return true;
 }
 
-// INTER_LINEAR_EXACT coefficient tables (resize.cpp interpolationLinear<uchar>::getCoeffs), IEEE double.
-// inv_scale is what cv::resize hands down: dsize/ssize when the caller gave a dsize (pass 0), but the caller's fx when
-// dsize was empty - resize(src, dst, Size(), fx, fy) samples on a 1/fx grid although dsize = cvRound(ssize*fx)
-
 extern "C" {
 
 static pano_status validate_camera(pano_ctx* c, const float K[9], const float R[9]) {

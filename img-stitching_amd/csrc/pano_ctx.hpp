@@ -122,6 +122,7 @@ struct pano_ctx {
     // dead columns {x0, x1} (inclusive, x1 < x0 = none) inside the live rect: the middle of a +-pi straddler's tile
     int gap[kMaxCams][kMaxLevels][2] = {};
     bool full_tiles = false;  // PANO_FULL_TILES=1: produce every pixel of every level (stage inspection)
+    F32Order f32_order;       // PANO_PYRDOWN32F_ORDER=v,vbody,h,hbody: the association of cv::pyrDown CV_32F the weights follow
     int nslots = 1, cur_slot = 0;
     char* slot_pyr[PANO_MAX_FRAME_SLOTS] = {};
     int16_t* slot_canvas[PANO_MAX_FRAME_SLOTS][kMaxLevels] = {};
@@ -186,6 +187,19 @@ struct pano_ctx {
     bool use_graph = false;
     uint64_t graph_replays = 0;   // hipGraphLaunch calls so far (pano_debug_graph_stats)
     std::string gc_dump_path;     // pano_debug_graphcut_dump
+
+    // the sharded exchange's packed form (pano_gather_slots): per camera the live rectangles of its levels as copy segments, where the
+    // camera's packed bytes start in the staging buffer and how many they are; rebuilt when the live rects change
+    std::vector<XchSeg> xch_segs;
+    int xch_first[kMaxCams + 1] = {};      // segments of camera i: [xch_first[i], xch_first[i + 1])
+    int xch_rows[kMaxCams] = {};           // the tallest segment of camera i
+    size_t xch_off[kMaxCams + 1] = {};     // packed bytes of camera i: [xch_off[i], xch_off[i + 1]) of the staging buffer
+    XchSeg* d_xch_segs = nullptr;
+    uint8_t* xch_stage = nullptr;
+    size_t xch_stage_bytes = 0;
+    bool xch_dirty = true;
+    bool xch_whole_slots = false;          // PANO_GATHER_WHOLE_SLOTS=1: whole slots travel, in place (rounds 1 - 4)
+    uint64_t xch_bytes_moved = 0;          // bytes this rank handed to ncclSend / ncclRecv so far (pano_get_exchange_stats)
 
     MaskJob* job = nullptr;
     MaskJob* job_trash = nullptr;  // (unused since the pool: kept for a refresh that failed half way)

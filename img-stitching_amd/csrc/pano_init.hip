@@ -6,7 +6,7 @@
 namespace pano {
 
 // ------------------------------------------------------------------------------------------------
-// weights: mask * (1/255.f) with copyMakeBorder(CONSTANT 0); pyrDown CV_32F (scalar evaluation order);
+// weights: mask * (1/255.f) with copyMakeBorder(CONSTANT 0); pyrDown CV_32F (scalar evaluation order unless told otherwise);
 // canvas sum in feed order
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_to_weight_kernel(const uint8_t* mask, int mw, int mh, int mpitch, int left,
@@ -27,11 +27,18 @@ void launch_mask_to_weight(const uint8_t* mask, int mw, int mh, int mpitch, int 
                        tw, th);
 }
 
+// cv::pyrDown CV_32F.  The five-tap sums are associated as the OpenCV build does that the weights are to match (F32Order: scalar
+// code by default; the SSE2 / NEON vertical body, the universal-intrinsics horizontal body - oracle/pano_oracle.c has the forms and
+// where each applies).  -ffp-contract=off: nothing is fused but the one multiply-add that such a build fuses itself.
 __global__ __launch_bounds__(256) void pyr_down_f32_kernel(const float* __restrict__ src, int sw, int sh, int spitch,
-                                                           float* __restrict__ dst, int dpitch) {
+                                                           float* __restrict__ dst, int dpitch, F32Order o) {
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= dw || y >= dh) return;
+    const int vend = o.vertical ? dw / o.vbody * o.vbody : 0;   // the vertical vector body ends here
+    const int width0 = min((sw - 2 - 1) / 2 + 1, dw);           // pyrDown_: the columns whose five taps need no border table
+    const int hend = o.horizontal && width0 > 1 ? 1 + (width0 - 1) / o.hbody * o.hbody : 0;
+    const bool hvec = x >= 1 && x < hend, vvec = x < vend;
     int xs[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) xs[k] = reflect101_idx(2 * x + k - 2, sw);
@@ -39,14 +46,52 @@ __global__ __launch_bounds__(256) void pyr_down_f32_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const float* r = src + (size_t)reflect101_idx(2 * y + k - 2, sh) * spitch;
-        row[k] = r[xs[2]] * 6 + (r[xs[1]] + r[xs[3]]) * 4 + r[xs[0]] + r[xs[4]];
+        if (hvec) {
+            const float inner = (r[xs[1]] + r[xs[3]]) * 4 + (r[xs[0]] + r[xs[4]]);
+            row[k] = o.horizontal == 2 ? __builtin_fmaf(r[xs[2]], 6.f, inner) : r[xs[2]] * 6 + inner;
+        } else {
+            row[k] = r[xs[2]] * 6 + (r[xs[1]] + r[xs[3]]) * 4 + r[xs[0]] + r[xs[4]];
+        }
     }
-    dst[(size_t)y * dpitch + x] = (row[2] * 6 + (row[1] + row[3]) * 4 + row[0] + row[4]) * (1.f / 256);
+    float v;
+    if (vvec) {
+        const float a = (row[0] + row[4]) + (row[2] + row[2]);
+        const float b = o.vertical == 2 ? (row[1] + row[2]) + row[3] : (row[1] + row[3]) + row[2];
+        v = (a + b * 4) * (1.f / 256);
+    } else {
+        v = (row[2] * 6 + (row[1] + row[3]) * 4 + row[0] + row[4]) * (1.f / 256);
+    }
+    dst[(size_t)y * dpitch + x] = v;
 }
-void launch_pyr_down_f32(const float* src, int sw, int sh, int spitch, float* dst, int dpitch, hipStream_t s) {
+void launch_pyr_down_f32(const float* src, int sw, int sh, int spitch, float* dst, int dpitch, F32Order o, hipStream_t s) {
     int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     dim3 block(64, 4, 1), grid((dw + 63) / 64, (dh + 3) / 4, 1);
-    hipLaunchKernelGGL(pyr_down_f32_kernel, grid, block, 0, s, src, sw, sh, spitch, dst, dpitch);
+    if (o.vbody < 1) o.vbody = 8;
+    if (o.hbody < 1) o.hbody = 4;
+    hipLaunchKernelGGL(pyr_down_f32_kernel, grid, block, 0, s, src, sw, sh, spitch, dst, dpitch, o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// the sharded exchange (pano_gather_slots): the LIVE rectangles of a camera's pyramid levels - what the blend on the root reads,
+// 70 % of a slot on config 2 - packed into one contiguous message and unpacked in place on the root.  One segment = rows x
+// width16 sixteen-byte chunks of one plane of one level; grid (segments, row blocks).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_segments_kernel(const XchSeg* __restrict__ segs, uint8_t* slots, uint8_t* stage, int unpack) {
+    const XchSeg g = segs[blockIdx.x];
+    const int rows_per_block = (g.rows + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, g.rows);
+    for (int r = r0 + (int)threadIdx.y; r < r1; r += 4)
+        for (int x = threadIdx.x; x < g.width16; x += 64) {
+            uint4* a = reinterpret_cast<uint4*>(slots + g.slot_off + (size_t)r * g.pitch) + x;
+            uint4* b = reinterpret_cast<uint4*>(stage + g.stage_off + (size_t)r * g.width16 * 16) + x;
+            if (unpack) *a = *b;
+            else *b = *a;
+        }
+}
+void launch_copy_segments(const XchSeg* d_segs, int first, int count, int max_rows, uint8_t* slots, uint8_t* stage, bool unpack, hipStream_t s) {
+    if (count <= 0) return;
+    const int yb = max(1, min(16, (max_rows + 31) / 32));
+    hipLaunchKernelGGL(copy_segments_kernel, dim3((unsigned)count, (unsigned)yb, 1), dim3(64, 4, 1), 0, s, d_segs + first, slots, stage, unpack ? 1 : 0);
 }
 
 __global__ __launch_bounds__(256) void sum_weights_kernel(PyrParams P, int l, float* wsum, int cw, int ch) {

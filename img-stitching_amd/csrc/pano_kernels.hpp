@@ -223,7 +223,11 @@ void launch_no_blend(const PyrParams& p, const CanvasSet& cs, hipStream_t s);
 // weights (run when masks change)
 void launch_mask_to_weight(const uint8_t* mask, int mw, int mh, int mpitch, int left, int top,
                            float* w0, int wpitch, uint8_t* m0, int mpitch0, int tw, int th, hipStream_t s);
-void launch_pyr_down_f32(const float* src, int sw, int sh, int spitch, float* dst, int dpitch, hipStream_t s);
+// which association of cv::pyrDown CV_32F's five-tap sums the weight pyramids follow (PANO_PYRDOWN32F_ORDER; oracle/pano_oracle.c):
+// vertical 0 scalar / 1 SSE2, universal intrinsics / 2 NEON with a vector body of vbody floats; horizontal 0 scalar / 1 universal
+// intrinsics / 2 the same with a fused multiply-add, body hbody floats
+struct F32Order { int vertical = 0, vbody = 8, horizontal = 0, hbody = 4; };
+void launch_pyr_down_f32(const float* src, int sw, int sh, int spitch, float* dst, int dpitch, F32Order o, hipStream_t s);
 void launch_sum_weights(const PyrParams& p, int l, float* wsum, int cw, int ch, hipStream_t s);
 
 // caller-side assembly: out rows [0, top_h) = up (resized to out_w x top_h with cv::resize INTER_LINEAR semantics, or
@@ -260,6 +264,19 @@ void launch_gain_pairs(const GainImages& g, const GainPair* pairs, int npairs, i
 void launch_and(const uint8_t* a, const uint8_t* b, uint8_t* dst, size_t n, hipStream_t s);
 // one wave that keeps stream s busy for ticks / 100 MHz seconds (pano_frame_streams' probe)
 void launch_spin(unsigned long long ticks_100mhz, hipStream_t s);
+// one rectangle of the sharded exchange: `rows` rows of `width16` 16-byte chunks at slots + slot_off (row pitch `pitch` bytes) <-> packed
+// at stage + stage_off (rows tight)
+struct XchSeg {
+    size_t slot_off, stage_off;
+    int pitch, width16, rows, pad;
+};
+void launch_copy_segments(const XchSeg* d_segs, int first, int count, int max_rows, uint8_t* slots, uint8_t* stage, bool unpack, hipStream_t s);
+// measurement probes (pano_probe.hip, pano_probe_copy): a float4 grid-stride copy and a copy in K1's traffic shape; each launch
+// carries its own begin / end events like K1's (hipExtLaunchKernelGGL)
+constexpr int kProbeBoxBytes = 4608;   // 18 rows x 256 B: config 2's K1 copies 4.4 KB of frame lines per workgroup
+void launch_probe_copy_f4(const void* src, void* dst, size_t bytes, int blocks, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+void launch_probe_copy_k1_shape(const void* box_src, const void* table, void* dst, unsigned workgroups, hipStream_t s, hipEvent_t e0,
+                                hipEvent_t e1);
 // one VoronoiSeamFinder::findInPair on device masks
 void launch_voronoi_pair(uint8_t* mask1, int w1, int h1, int tlx1, int tly1,
                          uint8_t* mask2, int w2, int h2, int tlx2, int tly2,

@@ -429,6 +429,8 @@ static pano_status build_masks_graphcut_impl(pano_ctx* c, const uint8_t* const* 
         Scratch pairs;
         pairs.pool = &c->pairs_pool;  // no refresh thread is running (waited for above)
         FILE* dump = c->gc_dump_path.empty() ? nullptr : fopen(c->gc_dump_path.c_str(), "ab");
+        if (!dump && !c->gc_dump_path.empty())  // a dump that was asked for and cannot be written is an error, not a silent OK
+            return fail(c, PANO_ERR, ("pano_debug_graphcut_dump: cannot open " + c->gc_dump_path).c_str());
         st = graphcut_pairs(n, sm, pairs, s, err, dump);
         if (dump) fclose(dump);
         if (st != PANO_OK) return fail(c, st, err.c_str());

@@ -283,6 +283,13 @@ pano_status pano_rccl_unique_id(char id[PANO_RCCL_ID_BYTES]);
 pano_status pano_rccl_comm_create(pano_ctx* ctx, const char id[PANO_RCCL_ID_BYTES], int world, int rank, void** rccl_comm);
 pano_status pano_rccl_comm_destroy(void* rccl_comm);
 pano_status pano_gather_slots(pano_ctx* ctx, void* rccl_comm, int rank, int root, const int* owner_rank, void* hip_stream);
+/* What pano_gather_slots moves: by default not whole slots but the LIVE rectangles of every pyramid level of a camera (pano_get_live_rect:
+ * what the blend on the root reads - on the 8 x 1080p rig 70 % of a slot), packed by a copy kernel into one message per owner and
+ * unpacked in place on the root; every rank derives the same message sizes from the same masks.  PANO_GATHER_WHOLE_SLOTS=1
+ * (environment, at pano_prepare) sends whole slots in place, as rounds 1 - 4 did.  packed_bytes_per_camera (optional, n values): the
+ * bytes camera i contributes to a message; *slot_bytes (optional): a whole slot; *bytes_moved (optional): what this context has handed
+ * to ncclSend / ncclRecv so far. */
+pano_status pano_get_exchange_stats(pano_ctx* ctx, uint64_t* packed_bytes_per_camera, uint64_t* slot_bytes, uint64_t* bytes_moved);
 /* ncclCommCount of a communicator (how many ranks RCCL itself says it spans), and the name the RCCL library was opened by
  * ("" when none could be).  Environment PANO_RCCL_LIB=<path>, read once at first use, names the library to open instead of the
  * system's librccl.so - a site build, or a test double that lets several ranks share one GPU (tests/src/fake_rccl.cpp). */
@@ -332,6 +339,24 @@ pano_status pano_get_warp_bytes(const pano_ctx* ctx, uint64_t* src_bytes, uint64
  * form cannot express (a BORDER_REFLECT fold inside a 4-pixel group, taps next to the last bytes of the frame) and
  * read the dense form with the per-pixel checked body.  Zeros when the warp projects on the fly. */
 pano_status pano_get_warp_table_stats(const pano_ctx* ctx, uint64_t* table_bytes, uint64_t* blocks, uint64_t* blocks_checked);
+
+/* Device-copy ceilings for the roofline ("also report against a measured device-copy ceiling"), measured by the library
+ * itself with the launch and timing machinery of its kernels (per-launch begin / end events, the interval rocprofv3 reports):
+ *   PANO_PROBE_COPY_F4        grid-stride copy, 16-byte loads and stores, four loads of a lane in flight; units = bytes to copy
+ *   PANO_PROBE_COPY_F4_FLAT   the same bytes, one 16-byte element per lane, as many workgroups as it takes
+ *   PANO_PROBE_COPY_K1_SHAPE  a copy with the warp kernel's traffic shape and none of its arithmetic: per 256-thread workgroup 4608 B of
+ *                             source box by direct-to-LDS 16-byte loads + one 8-byte table entry per lane in, one dword per lane into
+ *                             each of three planes out (6656 B in, 3072 B out); units = workgroups (config 2's warp launch: ~9300)
+ * `sets` buffer sets are rotated through (sets x the bytes of a launch above the 256 MiB Infinity Cache: the cold figure; 1: warm),
+ * `reps` timed launches follow max(2 sets, 4) untimed ones.  *GBps = bytes read + bytes written per launch / mean launch duration,
+ * *us_per_launch that duration, *bytes_moved (optional) the numerator.  After pano_prepare (it runs on the context's stream).
+ * Allocates and frees its own buffers; synchronises that stream.  The reference has no counterpart. */
+enum { PANO_PROBE_COPY_F4 = 0, PANO_PROBE_COPY_K1_SHAPE = 1, PANO_PROBE_COPY_F4_FLAT = 2 };
+pano_status pano_probe_copy(pano_ctx* ctx, int kind, uint64_t units, int sets, int reps, double* GBps, double* us_per_launch,
+                            uint64_t* bytes_moved);
+/* identity of the device code of this build: 16 hex digits of the SHA-256 over the kernel sources (csrc Makefile); the PMC traffic
+ * figures under profiles/ name the id they were collected with */
+const char* pano_kernel_source_id(void);
 
 /* ---- stage inspection (parity tests) ------------------------------------------------------- */
 /* The bytes of camera i's frame that the warp reads with the present masks: byte columns [rect[0], rect[0] + rect[2]) of rows

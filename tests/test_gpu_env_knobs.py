@@ -1,5 +1,7 @@
 """the library's environment switches do not change a result: each one, in a process of its own (they are
-read once per process), composes config 1 and a 4 x 960x540 group and compares with the oracle"""
+read once per process), composes config 1 and a 4 x 960x540 group and compares with the oracle.  The one exception is
+PANO_PYRDOWN32F_ORDER, which makes the blend weights follow another OpenCV build's association of cv::pyrDown CV_32F: there the
+oracle is switched to the same association and the weights and panoramas must again be equal bit for bit."""
 import os
 import subprocess
 import sys
@@ -28,6 +30,19 @@ for d, bands in ((c1, 4), (c2, 5)):
         ctx.set_camera(i, d["K"][i], d["R"][i])
     ctx.prepare(); ctx.build_masks_voronoi()
     masks = [ctx.get_mask(i) for i in range(4)]
+    # PANO_PYRDOWN32F_ORDER is the one switch that DOES change results, on purpose: the weights follow another OpenCV build's
+    # association of cv::pyrDown CV_32F, and the oracle is set to the same one
+    order = os.environ.get("PANO_PYRDOWN32F_ORDER")
+    if order:
+        po.set_pyrdown32f_variant(*[int(v) for v in order.split(",")])
+        for i in range(4):   # the f32 weight levels themselves, bit for bit
+            tile, tblr = ctx.feed_tile(i)   # (x, y, w, h) of the bordered tile, (top, bottom, left, right) border widths
+            w = np.zeros((tile[3], tile[2]), np.float32)
+            r = ctx.roi(i)
+            w[tblr[0]:tblr[0] + r[3], tblr[2]:tblr[2] + r[2]] = masks[i].astype(np.float32) * np.float32(1.0 / 255.0)
+            for l in range(1, bands + 1):
+                w = po.pyr_down_32f(w)
+                assert np.array_equal(ctx.debug_weights(i, l), w), ("weights", i, l)
     want, _ = po.compose(d["frames"], d["K"], d["R"], d["scale"], masks, bands)
     for rep in range(3):   # the third call replays the graph when PANO_GRAPH=1
         assert np.array_equal(ctx.compose_host(d["frames"]), want), (d["w"], rep)
@@ -37,7 +52,8 @@ print("knob ok")
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knob", ["PANO_GRAPH=1", "PANO_FULL_TILES=1", "PANO_WARP_ON_THE_FLY=1", "PANO_L0_ORDER=0",
-                                  "PANO_HOST_THREADS=1", "PANO_HOST_TRACE=1", "PANO_WRAP_IS_ERROR=1"])
+                                  "PANO_HOST_THREADS=1", "PANO_HOST_TRACE=1", "PANO_WRAP_IS_ERROR=1", "PANO_K1_STREAM=0",
+                                  "PANO_PYRDOWN32F_ORDER=1,8,0,4", "PANO_PYRDOWN32F_ORDER=2,8,0,4", "PANO_PYRDOWN32F_ORDER=1,4,2,4"])
 def test_environment_switch_keeps_the_result(knob):
     env = dict(os.environ)
     for kv in knob.split():

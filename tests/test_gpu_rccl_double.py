@@ -59,6 +59,8 @@ def _rank_main(rank, world, total_cams, uid, res):
                         out["why"] += f" group {g} rep {rep}: panorama differs from the oracle's;"
         _, slot = ctxs[0].pyramid_slots()
         out["slot_bytes"] = int(slot)
+        out["packed"] = [ctx.exchange_stats()["packed_bytes_per_camera"] for ctx in ctxs]   # per group, per camera: what a message carries
+        out["moved"] = [ctx.exchange_stats()["bytes_moved"] for ctx in ctxs]
         fk = C.CDLL(os.environ["PANO_RCCL_LIB"])
         fk.fake_rccl_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
         st = (C.c_ulonglong * 5)()
@@ -85,8 +87,11 @@ def _child(ranks, world, total_cams, uid_hex):
     print("RESULT " + json.dumps(res))
 
 
-@pytest.mark.parametrize("world,total_cams,per_proc", [(2, 4, 1), (4, 8, 1), (8, 8, 2)])
-def test_gather_slots_between_real_peers(world, total_cams, per_proc, fake_rccl_lib):
+@pytest.mark.parametrize("world,total_cams,per_proc,whole", [(2, 4, 1, False), (4, 8, 1, False), (8, 8, 2, False), (2, 4, 1, True)])
+def test_gather_slots_between_real_peers(world, total_cams, per_proc, whole, fake_rccl_lib):
+    """whole = False: the exchange moves the LIVE rectangles of every level, packed (the default); True: whole slots in place
+    (PANO_GATHER_WHOLE_SLOTS=1, rounds 1 - 4).  Either way rank 0's panoramas equal the oracle's and the double's byte counters equal
+    what the library says a message carries - sends and receives pair up byte for byte"""
     import json
 
     class UniqueId(C.Structure):
@@ -94,6 +99,8 @@ def test_gather_slots_between_real_peers(world, total_cams, per_proc, fake_rccl_
     uid = UniqueId()
     assert C.CDLL(fake_rccl_lib).ncclGetUniqueId(C.byref(uid)) == 0     # the id needs no GPU
     env = dict(os.environ, PANO_RCCL_LIB=fake_rccl_lib, FAKE_RCCL_TIMEOUT_S="120")
+    if whole:
+        env["PANO_GATHER_WHOLE_SLOTS"] = "1"
     procs = []
     for p0 in range(0, world, per_proc):
         ranks = list(range(p0, p0 + per_proc))
@@ -113,16 +120,27 @@ def test_gather_slots_between_real_peers(world, total_cams, per_proc, fake_rccl_
     slot = res[0]["slot_bytes"]
     per = total_cams // world
     reps, ngroups = 2, total_cams // NC
+    packed = res[0]["packed"]                                  # [group][camera] bytes; the same on every rank (same masks)
+    assert all(r["packed"] == packed for r in res)
+    if whole:
+        assert all(b == slot for g in packed for b in g)
+    else:
+        # the live rectangles are a real saving, and never more than the slot
+        assert all(0 < b <= slot for g in packed for b in g) and sum(map(sum, packed)) < 0.92 * slot * total_cams, (packed, slot)
+    shards = sh.camera_shards(total_cams, world)
+    sent_by = [sum(packed[c // NC][c % NC] for c in shards[r]) for r in range(world)]
     for r in res:
         groups, sends, recvs, b_out, b_in = r["stats"]
         if r["rank"] == 0:
             # everything rank 0 did not feed itself arrived from a peer: one message per rank and group it shares with
-            assert sends == 0 and b_out == 0 and b_in == reps * (total_cams - per) * slot
+            assert sends == 0 and b_out == 0 and b_in == reps * sum(sent_by[1:]), (b_in, sent_by)
             assert recvs == reps * sum(len({o for o in sh.owner_ranks(total_cams, NC, world, g) if o != 0}) for g in range(ngroups))
             # one ncclGroupStart / End per gather that moves anything
             assert groups == reps * sum(1 for g in range(ngroups) if any(o != 0 for o in sh.owner_ranks(total_cams, NC, world, g)))
+            assert sum(r["moved"]) == b_in                     # the library's own counter agrees with the transport's
         else:
-            assert recvs == 0 and b_in == 0 and sends == reps and b_out == reps * per * slot and groups == reps
+            assert recvs == 0 and b_in == 0 and sends == reps and b_out == reps * sent_by[r["rank"]] and groups == reps
+            assert sum(r["moved"]) == b_out
 
 
 def test_sharded_replay_world_2_through_the_double(fake_rccl_lib, tmp_path):

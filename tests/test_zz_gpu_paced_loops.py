@@ -60,10 +60,11 @@ def test_paced_60fps_stream_at_full_size_with_mask_refresh(pano, po):
     r = _harness().run(fps=60.0, frames=600, width=1920, height=1080, bands=5, check=True, refresh_every=200, refresh_async=True)
     _report("stream_8x1080p_600_ticks_refresh_beside_the_loop", r)
     assert r["frames_composed"] + r["dropped"] == 600, r
-    assert r["mask_refresh"]["masks_installed"] >= 2, r            # both stitchers' refreshes came through
-    assert r["sampled_frames_equal_oracle"] is True and r["sampled_frames"] == [0, 300, 599], r
+    assert r["mask_refresh"]["masks_installed"] >= 2, r            # both stitchers' refreshes came through (a refresh due on a dropped tick begins with the next composed one)
+    # a sample tick that is dropped hands its sample to the next composed tick: at least the first two samples exist whatever the clock does
+    assert r["sampled_frames_equal_oracle"] is True and len(r["sampled_frames"]) >= 2, r
     if STRICT:
-        assert r["dropped"] <= 2 and r["achieved_fps"] > 58.0, r
+        assert r["dropped"] <= 2 and r["achieved_fps"] > 58.0 and r["sampled_frames"] == [0, 300, 599], r
 
 
 def test_replay_paced_loop_with_mask_refresh_beside_it(pano, rig_r, tmp_path_factory, tmp_path):
@@ -102,8 +103,8 @@ def test_config5_as_baseline_states_it(pano, po):
     _report("config5_raw_undistort_hipgraph_120_ticks", r)
     assert "fused undistort front end" in r["config"] and "hipGraph replay" in r["config"], r["config"]
     assert r["frames_composed"] + r["dropped"] == 120, r
-    assert r["sampled_frames_equal_oracle"] is True and r["sampled_frames"] == [0, 60, 119], r
+    assert r["sampled_frames_equal_oracle"] is True and len(r["sampled_frames"]) >= 2, r
     for g in r["hipgraph"]:     # two page-locked slots -> two buffer sets -> two graphs per stitcher; every frame after the captures is a replay
         assert g["graphs_held"] == 2 and g["replays"] >= r["frames_composed"], r["hipgraph"]
     if STRICT:
-        assert r["dropped"] == 0 and r["achieved_fps"] > 58.0, r
+        assert r["dropped"] == 0 and r["achieved_fps"] > 58.0 and r["sampled_frames"] == [0, 60, 119], r

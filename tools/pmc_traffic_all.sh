@@ -26,6 +26,17 @@ for k, v in out.items():
     v["hbm_MB_per_frame"] = round((2 * v.get("FETCH_SIZE_KB_per_frame_raw", 0) + v.get("WRITE_SIZE_KB_per_frame_raw", 0)) * 1024 / 1e6, 2)
     tot += v["hbm_MB_per_frame"]
 out["_total_hbm_MB_per_frame"] = round(tot, 1)
+# the figures belong to the kernel sources they were counted on: bench.py prints them only beside a library of the same id
+import importlib, sys
+sys.path.insert(0, R)
+kid = importlib.import_module("img-stitching_amd").kernel_source_id()
+out["kernel_source_id"] = kid
+out["workload"] = "tools/frames_one_at_a_time.py: config 2 (8 x 1920x1080, 5 bands), both stitchers per launch sequence, one frame at a time"
 json.dump(out, open(R + "/gpurun_out/traffic_all.json", "w"), indent=1)
+k1 = [k for k in out if "warp_tiles_lut" in k][0]
+json.dump({"kernel_source_id": kid, "kernel": k1, "FETCH_SIZE_KB_raw": out[k1].get("FETCH_SIZE_KB_per_frame_raw"), "WRITE_SIZE_KB": out[k1].get("WRITE_SIZE_KB_per_frame_raw"),
+           "hbm_bytes_per_launch_8cam": int(out[k1]["hbm_MB_per_frame"] * 1e6),
+           "source": "tools/pmc_traffic_all.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/frames_one_at_a_time.py; FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM)"},
+          open(R + "/gpurun_out/warp_traffic_current.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY

@@ -64,7 +64,11 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
     period = 1.0 / fps
     tick_t, done_t = {}, {}
     sample, sample_masks = {}, {}
-    sample_ticks = (0, frames // 2, frames - 1) if check else ()
+    # the ticks to sample; a sample tick that is DROPPED hands its sample to the next composed tick, and a refresh that falls due on
+    # a dropped tick begins with the next composed one: one late tick changes the report, not the outcome of a check
+    sample_due = [0, frames // 2, frames - 1] if check else []
+    sample_ticks = set()
+    refresh_due = 0
     dropped = 0
     pending = None   # (frame index, slot)
     refreshed = [0]
@@ -90,9 +94,15 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
     for k in range(frames):
         target = t0 + k * period
         now = time.perf_counter()
+        if refresh_every and k and k % refresh_every == 0:
+            refresh_due += 1
         if now > target + period:      # this tick is over before we got here: the frame is lost
             dropped += 1
             continue
+        if sample_due and sample_due[0] <= k:
+            sample_ticks.add(k)
+            while sample_due and sample_due[0] <= k:
+                sample_due.pop(0)
         while now < target:
             if target - now > 0.002:
                 time.sleep(target - now - 0.001)
@@ -101,9 +111,10 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
         fs = sets[k % nsets]
         if refresh_every and not refresh_async:
             for grp in range(NG):
-                if k and k % refresh_every == 0:     # inside the tick, in front of the frame, like ocvStitcher::process
+                if refresh_due:     # inside the tick, in front of the frame, like ocvStitcher::process
                     ctxs[grp].build_masks_graphcut(fs[grp])
                     refreshed[0] += 1
+            refresh_due = 0
         if k in sample_ticks:   # the masks this tick's panoramas are composed with (a refresh may have installed new ones since the last sample)
             sample_masks[k] = [[ctxs[grp].get_mask(i) for i in range(NC)] for grp in range(NG)]
         for grp in range(NG):
@@ -119,8 +130,9 @@ def run(fps=60.0, frames=600, width=1920, height=1080, bands=5, nsets=4, check=F
             for grp in range(NG):
                 if ctxs[grp].refresh_masks_poll():
                     refreshed[0] += 1
-                if k and k % refresh_every == 0:
+                if refresh_due:
                     ctxs[grp].refresh_masks_begin(fs[grp])
+            refresh_due = 0
         if pipeline:
             if pending is not None:
                 finish(pending)
