@@ -97,9 +97,10 @@ static pano_status build_exchange_segments(pano_ctx* c) {
         HIP_TRY(c, hipMalloc((void**)&c->d_xch_segs, c->xch_segs.size() * sizeof(XchSeg)));
         HIP_TRY(c, hipMemcpy(c->d_xch_segs, c->xch_segs.data(), c->xch_segs.size() * sizeof(XchSeg), hipMemcpyHostToDevice));
     }
+    // one staging area per frame slot: frames in flight (pano_set_frame_slots) gather on streams of their own
     if (off > c->xch_stage_bytes) {
         dfree(c->xch_stage);
-        HIP_TRY(c, hipMalloc((void**)&c->xch_stage, off));
+        HIP_TRY(c, hipMalloc((void**)&c->xch_stage, off * PANO_MAX_FRAME_SLOTS));
         c->xch_stage_bytes = off;
     }
     c->xch_dirty = false;
@@ -135,18 +136,19 @@ pano_status pano_gather_slots(pano_ctx* c, void* comm, int rank, int root, const
         if ((st = ensure_weights(c, s)) != PANO_OK) return st;
         if (c->xch_dirty && (st = build_exchange_segments(c)) != PANO_OK) return st;
     }
-    char* const slots = c->pyr_base;
+    char* const slots = c->pyr_base;                                             // the frame slot in force (pano_select_frame_slot)
+    uint8_t* const stage = c->xch_stage + (size_t)c->cur_slot * c->xch_stage_bytes;
     // consecutive slots with the same peer travel as one message: a rank's cameras are a contiguous range of slots and of the staging buffer
     if (packed && rank != root)
         for (int i = 0; i < n; i++)
             if (owner_rank[i] == rank && owner_rank[i] != root)
-                launch_copy_segments(c->d_xch_segs, c->xch_first[i], c->xch_first[i + 1] - c->xch_first[i], c->xch_rows[i], (uint8_t*)slots, c->xch_stage, false, s);
+                launch_copy_segments(c->d_xch_segs, c->xch_first[i], c->xch_first[i + 1] - c->xch_first[i], c->xch_rows[i], (uint8_t*)slots, stage, false, s);
     RCCL_TRY(c, R.GroupStart());
     for (int i = 0; i < n;) {
         int j = i + 1;
         while (j < n && owner_rank[j] == owner_rank[i]) j++;
         const int owner = owner_rank[i];
-        char* base = packed ? (char*)c->xch_stage + c->xch_off[i] : slots + (size_t)i * c->slot_bytes;
+        char* base = packed ? (char*)stage + c->xch_off[i] : slots + (size_t)i * c->slot_bytes;
         const size_t bytes = packed ? c->xch_off[j] - c->xch_off[i] : (size_t)(j - i) * c->slot_bytes;
         ncclResult_t r = ncclSuccess;
         if (owner != root && bytes) {
@@ -165,7 +167,7 @@ pano_status pano_gather_slots(pano_ctx* c, void* comm, int rank, int root, const
     if (packed && rank == root)
         for (int i = 0; i < n; i++)
             if (owner_rank[i] != root)
-                launch_copy_segments(c->d_xch_segs, c->xch_first[i], c->xch_first[i + 1] - c->xch_first[i], c->xch_rows[i], (uint8_t*)slots, c->xch_stage, true, s);
+                launch_copy_segments(c->d_xch_segs, c->xch_first[i], c->xch_first[i + 1] - c->xch_first[i], c->xch_rows[i], (uint8_t*)slots, stage, true, s);
     return PANO_OK;
 }
 

@@ -33,6 +33,7 @@ def _rank_main(rank, world, total_cams, uid, res):
         for i in range(NC):
             ctx.set_camera(i, d["K"][i], d["R"][i])
         ctx.prepare(); ctx.build_masks_voronoi()
+        ctx.set_frame_slots(2)     # the two repetitions below run in two frame slots: each has a staging area of its own for the packed exchange
         ctxs.append(ctx)
     assert "fake_rccl" in pano.Context.rccl_library(), pano.Context.rccl_library()
     comm = ctxs[0].rccl_comm_create(uid, world, rank)      # collective: returns when all `world` ranks have joined
@@ -41,6 +42,7 @@ def _rank_main(rank, world, total_cams, uid, res):
     try:
         for rep in range(2):
             for g, ctx in enumerate(ctxs):
+                ctx.select_frame_slot(rep % 2)
                 # a rank only ever sees the frames of ITS cameras
                 mine = [c - g * NC for c in shards[rank] if g * NC <= c < (g + 1) * NC]
                 frames = [synth_frame(W, H, 700 + 31 * rep + NC * g + i) if i in mine else None for i in range(NC)]
