@@ -52,7 +52,7 @@ print("knob ok")
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knob", ["PANO_GRAPH=1", "PANO_FULL_TILES=1", "PANO_WARP_ON_THE_FLY=1", "PANO_L0_ORDER=0",
-                                  "PANO_HOST_THREADS=1", "PANO_HOST_TRACE=1", "PANO_WRAP_IS_ERROR=1", "PANO_K1_STREAM=0",
+                                  "PANO_HOST_THREADS=1", "PANO_HOST_TRACE=1", "PANO_WRAP_IS_ERROR=1",
                                   "PANO_PYRDOWN32F_ORDER=1,8,0,4", "PANO_PYRDOWN32F_ORDER=2,8,0,4", "PANO_PYRDOWN32F_ORDER=1,4,2,4"])
 def test_environment_switch_keeps_the_result(knob):
     env = dict(os.environ)
