@@ -43,11 +43,33 @@ for rep in range(3):
     for l in (2, 1, 0):
         m = lvl == l
         if not m.any(): continue
-        t = tr[m, :3].astype(np.int64); t0 = t[:, 0].min(); us = (t - t0) / 100.0
+        t = tr[m, :3].astype(np.int64)
+        hwid = (t[:, 2] >> 32) & 0xffff                      # HW_REG_HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
+        lo = t[:, 2] & 0xffffffff                              # stores issued: low 32 bits of the clock, the rest from the entry stamp
+        t[:, 2] = (t[:, 0] & ~0xffffffff) | lo
+        t[t[:, 2] < t[:, 0], 2] += 1 << 32
+        t0 = t[:, 0].min(); us = (t - t0) / 100.0
         life = done[m]; end = us[:, 0] + life; seam = hint[m] == 15; launch = float(end.max())
         bins = np.arange(0, launch + 0.5, 0.5)
         resident = [int(((us[:, 0] <= b) & (end > b)).sum()) for b in bins]
-        res.setdefault("level %d" % l, []).append({
+        # per SIMD (XCC, SE, SH, CU, SIMD): how many waves it holds over time, and how long after a wave's end the next one starts there
+        simd = xcc[m] * 65536 + (hwid & 0xfff0)
+        conc_time = {}; refill = []
+        for key in np.unique(simd):
+            k = simd == key
+            ev = sorted([(a, 1) for a in us[k, 0]] + [(b, -1) for b in end[k]])
+            c = 0; prev = ev[0][0]; ends_waiting = []
+            for tt, d in ev:
+                conc_time[c] = conc_time.get(c, 0.0) + (tt - prev); prev = tt
+                if d < 0: ends_waiting.append(tt)
+                elif ends_waiting: refill.append(tt - ends_waiting.pop(0))
+                c += d
+        tot = sum(v for kk, v in conc_time.items() if kk > 0)
+        simd_stats = {"simds_seen": int(len(np.unique(simd))), "waves_per_simd_max": int(max(conc_time)),
+                      "share_of_busy_time_at_n_waves": {str(kk): round(v / tot, 3) for kk, v in sorted(conc_time.items()) if kk > 0},
+                      "end_to_next_entry_on_the_same_simd_us": {"mean": round(float(np.mean(refill)), 2), "p50": round(float(np.percentile(refill, 50)), 2),
+                                                                 "p90": round(float(np.percentile(refill, 90)), 2)} if refill else None}
+        res.setdefault("level %d" % l, []).append({"per_simd": simd_stats,
             "waves": int(m.sum()), "seam_waves": int(seam.sum()), "first_entry_to_last_store_done_us": round(launch, 2),
             "entry_us_percentiles": {p: round(float(np.percentile(us[:, 0], p)), 2) for p in (50, 90, 99, 100)},
             "prologue_us_mean": round(float((us[:, 1] - us[:, 0]).mean()), 3),
