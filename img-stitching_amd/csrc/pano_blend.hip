@@ -618,6 +618,10 @@ struct BlendOrderedArgs {  // the kernel's argument list as the kernarg segment 
 // finished samples packed to bytes as they appear, the coarse canvas windows loaded plane by plane, the weights converted where they
 // are used, scheduling barriers between the planes: the allocator lands on 97 every time; without its seam path the kernel needs 84).
 // Levels >= 1 (NPL 1): one plane per lane, l = the level.
+// Read wave by wave in round 5 (tools/blend_timeline.py): level 0 is 15 128 waves of 4.5 us over 4 940 slots, a quarter of them empty at
+// any time (1.2 us from a wave's end to its successor's first instruction on the same SIMD).  Built on that and not kept, each bit-exact:
+// every wave a workgroup of its own, two or three tiles per wave in the same registers, long waves at the head of the list only
+// (experiments/blend_one_wave_workgroups.patch, blend_tiles_per_wave.patch; docs/EXPERIMENTS.md).
 template <bool L0, int NPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(L0 ? 5 : 8, 8))) void blend_level_ordered_kernel(
     const uint32_t* ord0, const uint32_t* ord1, unsigned per0, unsigned per1, int l, PyrParams P, CanvasSet CS) {

@@ -6,6 +6,7 @@ python -m pytest tests -m gpu -x -q > gpurun_out/r05_tests.log 2>&1 || { tail -4
 tail -2 gpurun_out/r05_tests.log
 python tools/copy_ceiling.py > gpurun_out/r05_copy_ceiling.json 2> gpurun_out/r05_copy_ceiling.err || { tail -20 gpurun_out/r05_copy_ceiling.err; exit 1; }
 bash tools/pmc_traffic_all.sh > gpurun_out/r05_traffic.log 2>&1 || { tail gpurun_out/r05_traffic.log; exit 1; }
+python tools/adopt_traffic.py || exit 1   # the bench prints counter traffic only beside the kernel source id it was counted on
 echo traffic done
 python bench.py > gpurun_out/r05_bench.json 2> gpurun_out/r05_bench.err || { tail -20 gpurun_out/r05_bench.err; exit 1; }
 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_driver_form.json 2> gpurun_out/r05_bench_driver_form.err || { tail -20 gpurun_out/r05_bench_driver_form.err; exit 1; }
