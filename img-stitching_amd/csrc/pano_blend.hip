@@ -502,6 +502,13 @@ __device__ __forceinline__ void blend_block(const PyrParams& P, const BlendLevel
     for (int pl = 0; pl < NPL; pl++) {
         int up[2][4];
         if (UP) {
+            if (L0) {
+                // the coarse canvas windows stay as loaded (6 registers a plane) until HERE: left alone the scheduler forms their
+                // horizontal sums (12 a plane) as soon as the loads land and the allocator carries them across the normalise - that
+                // was the kernel's 97th register and its one spilled dword (96 VGPRs + 8 B of scratch -> 85, none)
+#pragma unroll
+                for (int r = 0; r < 3; r++) asm volatile("" : "+v"(cp[pl][r][0]), "+v"(cp[pl][r][1]));
+            }
             up_block<int16_t>(cp[pl], up);
         } else {
 #pragma unroll
