@@ -620,10 +620,10 @@ struct BlendOrderedArgs {  // the kernel's argument list as the kernarg segment 
     PyrParams P;
     CanvasSet CS;
 };
-// L0 (NPL 3): 5 waves / SIMD = at most 96 VGPRs (the allocator stops at 97 - 99 uncapped: a granule more, and a wave less - and puts ONE
-// dword of the seam path, 5 % of the waves, in scratch: two stores and a load per seam lane.  Round 5 tried to take that dword out -
-// finished samples packed to bytes as they appear, the coarse canvas windows loaded plane by plane, the weights converted where they
-// are used, scheduling barriers between the planes: the allocator lands on 97 every time; without its seam path the kernel needs 84).
+// L0 (NPL 3): 85 VGPRs, 5 waves / SIMD (at most 96), no scratch.  Until round 5 the allocator needed 97 and kept ONE dword of the seam
+// path in scratch; five restructurings left it there, the sixth - the coarse canvas windows pinned as loaded until their use, see the
+// seam path's last phase - took it out and eleven registers with it.  A sixth wave needs <= 80: the single-owner path's arithmetic
+// phase holds 84 (at 80 the compiler spills 24 - 32 B there; the level-0 rows through LDS instead of registers do not help).
 // Levels >= 1 (NPL 1): one plane per lane, l = the level.
 // Read wave by wave in round 5 (tools/blend_timeline.py): level 0 is 15 128 waves of 4.5 us over 4 940 slots, a quarter of them empty at
 // any time (1.2 us from a wave's end to its successor's first instruction on the same SIMD).  Built on that and not kept, each bit-exact:
